@@ -1,0 +1,99 @@
+// Shared host/device helpers for libs2s_mi355x (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/s2s_mi355x.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+namespace s2s {
+
+// ---- error plumbing: no exceptions cross the C ABI -------------------------
+void set_error(const std::string& msg);
+int fail(int code, const char* fmt, ...);
+
+#define S2S_HIP_CHECK(expr)                                                         \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return ::s2s::fail(S2S_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__,   \
+                               #expr, hipGetErrorString(_e));                       \
+    } while (0)
+
+#define S2S_LAUNCH_CHECK()                                                          \
+    do {                                                                            \
+        hipError_t _e = hipGetLastError();                                          \
+        if (_e != hipSuccess)                                                       \
+            return ::s2s::fail(S2S_ERR_HIP, "%s:%d launch -> %s", __FILE__,         \
+                               __LINE__, hipGetErrorString(_e));                    \
+    } while (0)
+
+#define S2S_REQUIRE(cond, ...)                                                      \
+    do {                                                                            \
+        if (!(cond)) return ::s2s::fail(S2S_ERR_ARG, __VA_ARGS__);                  \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers --------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even f32 -> bf16 bits (NaN kept quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<__hip_bfloat16> {
+    static __device__ __forceinline__ float ld(const __hip_bfloat16* p) {
+        return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p));
+    }
+    static __device__ __forceinline__ void st(__hip_bfloat16* p, float v) {
+        *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// order-preserving float <-> uint mapping for atomicMax on floats
+__device__ __forceinline__ unsigned int f32_ordered(float f) {
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace s2s

@@ -1,0 +1,329 @@
+// Dense projection GEMMs for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual)
+//
+// W is kept in the checkpoint's own [out_features][in_features] layout, so both MFMA
+// operands are read along K ("B^T input"): no transposes anywhere on the path.
+//
+//  * gemm_tile_kernel   : 128x128 output tile per 256-thread workgroup (2x2 waves, each
+//                         a 4x4 grid of 16x16 MFMA fragments), K staged through LDS in
+//                         128-byte rows with a 16-byte-chunk XOR swizzle so that both the
+//                         ds_write_b128 staging stores and the fragment reads are
+//                         conflict-free; the next K-slab is already in flight in registers
+//                         while the current one is multiplied.  Workgroup ids are remapped
+//                         so that each XCD's L2 sees a contiguous band of N-tiles sharing W.
+//  * gemm_skinny_kernel : M <= 64 (decode steps: one row per live session).  Weights are
+//                         streamed exactly once straight from HBM into MFMA B-fragments
+//                         (no LDS), activations come from L2; N is cut into 16-column
+//                         slabs and K into slices so that >= 256 workgroups are in flight;
+//                         K-slices are combined with f32 atomics onto the (residual)
+//                         output when split, or written directly when not.
+//
+// Element types: bf16 inputs -> v_mfma_f32_16x16x32_bf16, f32 inputs ->
+// v_mfma_f32_16x16x4_f32 (exact f32, used by the parity policy).  Accumulation is f32.
+#include "common.h"
+
+#include <algorithm>
+
+namespace s2s {
+
+template <typename T> struct MfmaTraits;
+template <> struct MfmaTraits<__hip_bfloat16> {
+    static constexpr int KPF = 32;   // K per MFMA
+    static constexpr int EPC = 8;    // elements per 16-byte chunk
+};
+template <> struct MfmaTraits<float> {
+    static constexpr int KPF = 4;
+    static constexpr int EPC = 4;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case S2S_ACT_GELU: return gelu_erf(v);
+        case S2S_ACT_SILU: return v / (1.0f + expf(-v));
+        case S2S_ACT_RELU: return fmaxf(v, 0.f);
+        default: return v;
+    }
+}
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;             // bytes of K per LDS row (64 bf16 / 32 f32)
+constexpr int TILE_BYTES = BM * ROWB; // 16 KiB per operand
+
+// XCD-aware remap: consecutive logical tiles (sharing a W band) land on one XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(
+    const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m) {
+    constexpr int EPC = MfmaTraits<T>::EPC;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
+    unsigned char* sA = lds;
+    unsigned char* sW = lds + TILE_BYTES;
+
+    const int nwg = gridDim.x;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tm = wg % tiles_m, tn = wg / tiles_m;   // M fastest: neighbours share the W band
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread
+    u32x4_t ga[4], gw[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, ch = c & 7;
+            const int k = k0 + ch * EPC;
+            u32x4_t va = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+            if (k < K) {
+                if (m0 + row < M) va = *reinterpret_cast<const u32x4_t*>(A + (long)(m0 + row) * lda + k);
+                if (n0 + row < N) vw = *reinterpret_cast<const u32x4_t*>(W + (long)(n0 + row) * K + k);
+            }
+            ga[i] = va;
+            gw[i] = vw;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, ch = c & 7;
+            const int off = row * ROWB + ((ch ^ (row & 7)) << 4);
+            *reinterpret_cast<u32x4_t*>(sA + off) = ga[i];
+            *reinterpret_cast<u32x4_t*>(sW + off) = gw[i];
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load_tile((t + 1) * BK);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm + i * 16 + l15;
+                    fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * ROWB + (((kk * 4 + lg) ^ (ra & 7)) << 4));
+                    const int rw = wn + i * 16 + l15;
+                    fw[i] = *reinterpret_cast<const bf16x8_t*>(sW + rw * ROWB + (((kk * 4 + lg) ^ (rw & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm + i * 16 + l15;
+                    fa[i] = *reinterpret_cast<const float*>(sA + ra * ROWB + ((ks ^ (ra & 7)) << 4) + lg * 4);
+                    const int rw = wn + i * 16 + l15;
+                    fw[i] = *reinterpret_cast<const float*>(sW + rw * ROWB + ((ks ^ (rw & 7)) << 4) + lg * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fw[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C fragment (i,j): row = lg*4 + r, col = l15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + j * 16 + l15;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lg * 4 + r;
+                if (m >= M) continue;
+                float v = apply_act(acc[i][j][r] + bv, act);
+                if (residual) v += residual[(long)m * ldc + n];
+                Elem<CT>::st(C + (long)m * ldc + n, v);
+            }
+    }
+}
+
+// ---- skinny (decode) GEMM --------------------------------------------------
+// grid = ceil(N/64) * ksplit, block = 256: four waves, each one 16-column slab of the same
+// K-slice (so the activation fragments of three of them are L1 hits).
+// MT = ceil(M/16) row fragments.
+template <typename T, typename CT, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(
+    const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int ksplit, int kslice) {
+    constexpr int KPF = MfmaTraits<T>::KPF;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int nb = blockIdx.x / ksplit, ks = blockIdx.x - nb * ksplit;
+    const int n = (nb * 4 + (threadIdx.x >> 6)) * 16 + l15;
+    const int kbeg = ks * kslice, kend = min(K, kbeg + kslice);
+
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const bool nvalid = n < N;
+    const T* wrow = W + (long)(nvalid ? n : 0) * K;
+    if constexpr (sizeof(T) == 2) {
+        for (int k0 = kbeg; k0 < kend; k0 += 4 * KPF) {
+            bf16x8_t fw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * KPF + lg * 8;
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (nvalid && k < kend) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + k));
+                fw[u] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * KPF + lg * 8;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int m = i * 16 + l15;
+                    u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (m < M && k < kend) v = *reinterpret_cast<const u32x4_t*>(A + (long)m * lda + k);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v), fw[u], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += 8 * KPF) {
+            float fw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * KPF + lg;
+                fw[u] = (nvalid && k < kend) ? wrow[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * KPF + lg;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int m = i * 16 + l15;
+                    const float a = (m < M && k < kend) ? A[(long)m * lda + k] : 0.f;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fw[u], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (!nvalid) return;
+    const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + lg * 4 + r;
+            if (m >= M) continue;
+            if (ksplit == 1) {
+                float v = apply_act(acc[i][r] + bv, act);
+                if (residual) v += residual[(long)m * ldc + n];
+                Elem<CT>::st(C + (long)m * ldc + n, v);
+            } else {
+                // split-K: C (f32) already holds the residual; partial sums are added onto it
+                atomicAdd(reinterpret_cast<float*>(C) + (long)m * ldc + n, acc[i][r] + bv);
+            }
+        }
+}
+
+template <typename T, typename CT>
+static int launch_gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
+                       const float* residual, void* C, long ldc, int M, int N, int K, int act,
+                       bool allow_splitk) {
+    if (M <= 64) {
+        const int MT = cdiv(M, 16);
+        const int ntiles = cdiv(N, 64);
+        int ksplit = 1;
+        // split K only where partial sums can be combined by plain addition onto C
+        const bool can_split = allow_splitk && act == S2S_ACT_NONE && sizeof(CT) == 4 &&
+                               (residual == nullptr || residual == (const float*)C);
+        constexpr int KQ = sizeof(T) == 2 ? 128 : 32;   // K consumed per loop trip
+        if (can_split) {
+            while (ntiles * ksplit < 256 && K / (ksplit * 2) >= 2 * KQ) ksplit *= 2;
+        }
+        int kslice = cdiv(cdiv(K, ksplit), KQ) * KQ;
+        ksplit = cdiv(K, kslice);
+        if (ksplit > 1 && residual == nullptr) {
+            // no residual in place: C must start from zero
+            hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
+            if (e != hipSuccess) return fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(e));
+        }
+        dim3 grid(ntiles * ksplit);
+#define S2S_SKINNY(MTV)                                                                          \
+    gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)W, bias,      \
+                                                        residual, (CT*)C, ldc, M, N, K, act,      \
+                                                        ksplit, kslice)
+        switch (MT) {
+            case 1: S2S_SKINNY(1); break;
+            case 2: S2S_SKINNY(2); break;
+            case 3: S2S_SKINNY(3); break;
+            default: S2S_SKINNY(4); break;
+        }
+#undef S2S_SKINNY
+    } else {
+        const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+        gemm_tile_kernel<T, CT><<<tiles_m * tiles_n, 256, 0, st>>>(
+            (const T*)A, lda, (const T*)W, bias, residual, (CT*)C, ldc, M, N, K, act, tiles_m);
+    }
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
+         const float* residual, void* C, long ldc, int M, int N, int K, int ab_dtype, int c_dtype,
+         int act, bool allow_splitk) {
+    S2S_REQUIRE(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    if (M == 0) return S2S_OK;
+    S2S_REQUIRE(A && W && C, "gemm: null operand");
+    const int epc = ab_dtype == S2S_BF16 ? 8 : 4;
+    S2S_REQUIRE(K % epc == 0 && lda % epc == 0, "gemm: K=%d / lda=%ld must be multiples of %d", K, lda, epc);
+    S2S_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    if (ab_dtype == S2S_BF16 && c_dtype == S2S_BF16)
+        return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
+    if (ab_dtype == S2S_BF16 && c_dtype == S2S_F32)
+        return launch_gemm<__hip_bfloat16, float>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
+    if (ab_dtype == S2S_F32 && c_dtype == S2S_F32)
+        return launch_gemm<float, float>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
+    return fail(S2S_ERR_UNSUPPORTED, "gemm: unsupported dtype combination ab=%d c=%d", ab_dtype, c_dtype);
+}
+
+}  // namespace s2s
+
+extern "C" int32_t s2s_op_gemm(void* stream, const void* A, int64_t lda, const void* W, const float* bias,
+                               const float* residual, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                               int32_t ab_dtype, int32_t c_dtype, int32_t act) {
+    return s2s::gemm((hipStream_t)stream, A, (long)lda, W, bias, residual, C, (long)ldc, M, N, K, ab_dtype,
+                     c_dtype, act, /*allow_splitk=*/false);
+}

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libs2s_mi355x.so`` (the C ABI declared in ``include/s2s_mi355x.h``).
+
+The product path has no CPU fallback: if the shared library is missing, or a call
+returns a non-zero status, this module raises.  PyTorch-ROCm tensors are used only as
+device-memory containers; ``ptr(t)`` turns one into the raw pointer the ABI takes.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import PACKAGE_DIR, REPO_ROOT
+
+LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libs2s_mi355x.so")
+HEADER_PATH = os.path.join(REPO_ROOT, "include", "s2s_mi355x.h")
+
+S2S_F32, S2S_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
+FRONTEND_WHISPER, FRONTEND_PARAKEET = 0, 1
+
+
+class NativeError(RuntimeError):
+    """A libs2s_mi355x call failed (status code + the library's message)."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int32 status unless listed in _RESTYPES)
+_SIGNATURES = {
+    "s2s_last_error": [],
+    "s2s_abi_version": [],
+    "s2s_device_count": [],
+    "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],
+    "s2s_frontend_destroy": [_vp],
+    "s2s_logmel_whisper": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
+    "s2s_logmel_parakeet": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp],
+    "s2s_op_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32],
+    "s2s_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
+    "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
+}
+_RESTYPES = {"s2s_last_error": C.c_char_p}
+
+
+def load():
+    """Load (once) and return the ctypes library; raises NativeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C speech-to-speech_amd/csrc`). There is no CPU fallback for the MI355X path."
+            )
+        try:
+            import torch  # noqa: F401  (load torch's HIP runtime first so both share one libamdhip64)
+        except Exception:  # pragma: no cover - torch is optional for symbol checks
+            pass
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _i32)
+        _lib = lib
+        return lib
+
+
+def declared_symbols() -> list[str]:
+    """Every function name the public header declares (used by the export test)."""
+    import re
+
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(s2s_[a-z0-9_]+)\s*\(", text)))
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().s2s_last_error()
+        raise NativeError(f"{what or 'libs2s_mi355x'} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Raw device/host pointer of a torch tensor (or None -> NULL)."""
+    if t is None:
+        return 0
+    return int(t.data_ptr())
+
+
+def stream_handle() -> int:
+    """hipStream_t of torch's current stream on the current device."""
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt) -> int:
+    import torch
+
+    if dt == torch.float32:
+        return S2S_F32
+    if dt == torch.bfloat16:
+        return S2S_BF16
+    raise NativeError(f"unsupported dtype {dt}")

@@ -1,0 +1,96 @@
+"""GPU parity of the primitive operators exported by the C ABI against plain float64/float32 references."""
+
+import numpy as np
+import pytest
+import torch
+
+from speech_to_speech_amd import native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gemm(A, W, bias, resid, act, c_dtype, M, N, K):
+    lib = native.load()
+    C = torch.empty((M, N), dtype=c_dtype, device=DEV)
+    native.check(lib.s2s_op_gemm(native.stream_handle(), native.ptr(A), A.stride(0), native.ptr(W), native.ptr(bias),
+                                 native.ptr(resid), native.ptr(C), C.stride(0), M, N, K, native.dtype_code(A.dtype),
+                                 native.dtype_code(c_dtype), act))
+    torch.cuda.synchronize()
+    return C
+
+
+def _ref(A, W, bias, resid, act):
+    y = A.double().cpu() @ W.double().cpu().T
+    if bias is not None:
+        y = y + bias.double().cpu()
+    if act == native.ACT_GELU:
+        y = torch.nn.functional.gelu(y)
+    elif act == native.ACT_SILU:
+        y = torch.nn.functional.silu(y)
+    elif act == native.ACT_RELU:
+        y = torch.relu(y)
+    if resid is not None:
+        y = y + resid.double().cpu()
+    return y
+
+
+SHAPES = [(128, 128, 64), (300, 200, 136), (1500, 384, 384), (64, 1280, 1280), (1, 51864, 384), (17, 100, 72),
+          (65, 130, 264)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_matches_reference(M, N, K, dt):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    # asymmetric, non-identity operands (transpose-detecting)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1 + torch.arange(N)[:, None] * 1e-4).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    for act, use_res, cdt in [(native.ACT_NONE, False, torch.float32), (native.ACT_GELU, False, dt),
+                              (native.ACT_NONE, True, torch.float32), (native.ACT_SILU, False, torch.float32)]:
+        C = _gemm(A, W, bias, resid if use_res else None, act, cdt, M, N, K)
+        ref = _ref(A, W, bias, resid if use_res else None, act)
+        err = (C.double().cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        tol = (2e-5 if cdt == torch.float32 and dt == torch.float32 else 1e-2) * max(1.0, scale)
+        if dt == torch.bfloat16 and cdt == torch.float32:
+            tol = 2e-4 * max(1.0, scale)   # bf16 products are exact in f32; only summation order differs
+        print(f"gemm M={M} N={N} K={K} {dt} act={act} res={use_res} c={cdt}: max_err={err:.3e} (scale {scale:.2f})")
+        assert err < tol
+
+
+def test_gemm_identity_detects_transposes():
+    M = N = K = 128
+    A = torch.eye(M, K).to(DEV)
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0).to(DEV)
+    C = _gemm(A, W, None, None, native.ACT_NONE, torch.float32, M, N, K)
+    assert torch.equal(C.cpu(), W.cpu().T.contiguous())
+    Ab, Wb = A.bfloat16(), W.bfloat16()
+    Cb = _gemm(Ab, Wb, None, None, native.ACT_NONE, torch.float32, M, N, K)
+    assert torch.equal(Cb.cpu(), Wb.float().cpu().T.contiguous())
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 384), (1500, 1280), (33, 1024), (4, 2048), (3, 640)])
+def test_norms_match_reference(rows, cols):
+    lib = native.load()
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.3).to(DEV)
+    gamma = torch.randn(cols, generator=g).to(DEV)
+    beta = torch.randn(cols, generator=g).to(DEV)
+    for odt in (torch.float32, torch.bfloat16):
+        y = torch.empty((rows, cols), dtype=odt, device=DEV)
+        native.check(lib.s2s_op_layernorm(native.stream_handle(), native.ptr(x), native.ptr(gamma), native.ptr(beta),
+                                          native.ptr(y), rows, cols, 1e-5, native.dtype_code(odt)))
+        ref = torch.nn.functional.layer_norm(x.double().cpu(), (cols,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+        err = (y.double().cpu() - ref).abs().max().item()
+        print(f"layernorm {rows}x{cols} {odt}: {err:.3e}")
+        assert err < (2e-5 if odt == torch.float32 else 5e-2)
+        native.check(lib.s2s_op_rmsnorm(native.stream_handle(), native.ptr(x), native.ptr(gamma), native.ptr(y), rows,
+                                        cols, 1e-6, native.dtype_code(odt)))
+        xd = x.double().cpu()
+        ref = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * gamma.double().cpu()
+        err = (y.double().cpu() - ref).abs().max().item()
+        print(f"rmsnorm {rows}x{cols} {odt}: {err:.3e}")
+        assert err < (2e-5 if odt == torch.float32 else 5e-2)
