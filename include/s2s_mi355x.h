@@ -76,6 +76,11 @@ int32_t s2s_frontend_destroy(void* frontend);
 int32_t s2s_logmel_whisper(void* frontend, void* stream, const float* pcm_dev,
                            int64_t pcm_stride, const int32_t* n_samples_dev, int32_t B,
                            void* out_dev, int32_t out_dtype);
+/* Same features in the encoder's own layout: out_dev [B][3002][n_mels] time-major with one zero
+ * row before and after each utterance (the conv stem reads it as overlapping GEMM rows). */
+int32_t s2s_logmel_whisper_tm(void* frontend, void* stream, const float* pcm_dev,
+                              int64_t pcm_stride, const int32_t* n_samples_dev, int32_t B,
+                              void* out_dev, int32_t out_dtype);
 
 /* out_dev: [B][t_max][n_mels] (time-major, zero beyond each row's valid
  * frames), n_frames_dev: int32[B] valid frames (= n_samples / 160).
@@ -105,6 +110,78 @@ int32_t s2s_op_layernorm(void* stream, const float* x, const float* gamma, const
 /* y[r,:] = x[r,:]*rsqrt(mean(x^2)+eps)*gamma */
 int32_t s2s_op_rmsnorm(void* stream, const float* x, const float* gamma, void* y, int32_t rows,
                        int32_t cols, float eps, int32_t y_dtype);
+
+/* 1-D convolution over a zero-padded time-major buffer as ONE GEMM (no im2col):
+ *   x: [B][T_in + 2*pad][Cin] with `pad` zero rows on both sides of every item,
+ *   w: [Cout][ksize][Cin] (tap-major), y: [B][y_rows][Cout], frame t written at row t + y_row0.
+ * Used for the Whisper stem (modeling_whisper.py:618-619) and the codec-decoder convolutions. */
+int32_t s2s_op_conv1d_tm(void* stream, const void* x, const void* w, const float* bias, void* y,
+                         int32_t B, int32_t T_in, int32_t Cin, int32_t Cout, int32_t ksize,
+                         int32_t stride, int32_t pad, int32_t y_rows, int32_t y_row0,
+                         int32_t ab_dtype, int32_t c_dtype, int32_t act);
+
+/* Scaled-dot-product attention over token-major buffers (f32 softmax).
+ *   q: [B][Tq][q_rs] (head h at columns h*D), k / v: [B][Tk][kv_rs] (Hkv heads, grouped-query
+ *   when H > Hkv), o: [B][Tq][H*D].  kv_len_dev: optional int32[B] valid keys.  bias: optional
+ *   f32 [B][H][Tq][2*Tk-1] relative-position term, read at column (Tk-1) - t + j (the
+ *   Transformer-XL rel-shift of modeling_parakeet.py:356-362).  causal: key j allowed iff
+ *   j <= t + (Tk - Tq); window > 0 additionally requires j > t + (Tk - Tq) - window.
+ *   use_mfma = 1 selects the bf16 flash kernel (needs H == Hkv, D in {64,128}, no causal mask
+ *   and vt_scratch_dev of B*H*D*roundup(Tk,64) elements); 0 selects the row kernel (any dtype). */
+int32_t s2s_op_attention(void* stream, const void* q, int64_t q_rs, const void* k, const void* v,
+                         int64_t kv_rs, void* o, const int32_t* kv_len_dev, const float* bias,
+                         int32_t B, int32_t H, int32_t Hkv, int32_t Tq, int32_t Tk, int32_t D,
+                         float scale, int32_t causal, int32_t window, int32_t dtype,
+                         int32_t use_mfma, void* vt_scratch_dev);
+
+/* ------------------------------------------------------------------------- *
+ * Whisper (encoder + greedy decoder) for one batch of sessions.
+ *   Replaces model.get_encoder()(feats), model.detect_language(encoder_outputs) and
+ *   model.generate(feats, max_new_tokens, num_beams=1, return_timestamps=False, task, language)
+ *   of WhisperSTTHandler (STT/whisper_stt_handler.py:166-197,243).  Arithmetic restated from
+ *   transformers/models/whisper/modeling_whisper.py and generation_whisper.py:1455-1608,
+ *   1610-1675, 1774-1812.
+ * ------------------------------------------------------------------------- */
+typedef struct s2s_whisper_config {
+    int32_t n_mels;     /* 80 (tiny.en) or 128 (large-v3) */
+    int32_t d_model;
+    int32_t n_heads;
+    int32_t enc_layers;
+    int32_t dec_layers;
+    int32_t ffn;
+    int32_t vocab;
+    int32_t max_target; /* 448 */
+    int32_t dtype;      /* S2S_BF16 (serving) or S2S_F32 (exact-f32 parity policy) */
+} s2s_whisper_config;
+
+int32_t s2s_whisper_create(const s2s_whisper_config* cfg, int32_t max_batch, void** out_model);
+int32_t s2s_whisper_destroy(void* model);
+/* Register one weight tensor (device pointer, kept by reference - the caller keeps it alive).
+ * Names and layouts are listed in speech-to-speech_amd/whisper.py (WEIGHT LAYOUT). */
+int32_t s2s_whisper_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel);
+/* Verifies that every tensor is present with the right size and allocates the workspace. */
+int32_t s2s_whisper_finalize(void* model);
+int64_t s2s_whisper_workspace_bytes(void* model);
+/* feats_dev: [B][3002][n_mels] time-major log-mel in the model dtype, rows 0 and 3001 zero
+ * (s2s_logmel_whisper layout 1).  Fills the encoder output and every layer's cross K|V. */
+int32_t s2s_whisper_encode(void* model, void* stream, const void* feats_dev, int32_t B);
+/* Copies the encoder output of the last s2s_whisper_encode into dst_dev: [B][1500][d_model], model dtype. */
+int32_t s2s_whisper_read_encoder_output(void* model, void* stream, void* dst_dev, int32_t B);
+/* Greedy decode after s2s_whisper_encode.
+ *   prompt_dev: int32 [B][P] forced decoder prefix (<sot><lang><task><notimestamps>); an entry of -1
+ *     is filled with the argmax over tokens whose prompt_fill_mask_dev byte is 0 (language
+ *     detection: mask = 1 for every non-language token).
+ *   suppress_dev / begin_suppress_dev: optional uint8 [vocab], 1 = suppressed (always / only for
+ *     the first generated token).  eos: end-of-text id.  min_steps: decode at least this many
+ *     steps before polling for "all sessions finished" (0 = poll from the start).
+ *   out_ids_dev: int32 [B][max_new_tokens + P]: generated ids first (eos excluded), then P slots
+ *     holding any filled-in prompt token (0 elsewhere); out_len_dev: int32 [B].
+ *   last_logits_dev: optional f32 [B][vocab], logits of the final executed step (tests). */
+int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t B, const int32_t* prompt_dev,
+                                  int32_t P, const uint8_t* suppress_dev, const uint8_t* begin_suppress_dev,
+                                  const uint8_t* prompt_fill_mask_dev, int32_t eos, int32_t max_new_tokens,
+                                  int32_t min_steps, int32_t* out_ids_dev, int32_t* out_len_dev,
+                                  float* last_logits_dev);
 
 #ifdef __cplusplus
 }

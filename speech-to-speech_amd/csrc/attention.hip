@@ -1,0 +1,447 @@
+// Attention kernels for gfx950.
+//
+//  * attn_rows_kernel  : one wave per query row, f32 math on any storage type.  Serves the
+//                        decode steps (one query per session against the self / cross KV
+//                        cache, grouped-query, causal and sliding-window masks) and is the
+//                        exact-f32 parity path for every attention in the models.
+//                        Scores live in LDS; pass 1 = q.K^T with each lane owning keys,
+//                        pass 2 = P.V with each lane owning output channels (coalesced V rows).
+//  * attn_mfma_kernel  : bf16 flash attention for the encoders (Whisper T=1500 d_h=64,
+//                        FastConformer d_h=128 with the Transformer-XL relative-position
+//                        term as an additive bias).  128 queries per workgroup (4 waves x 2
+//                        query fragments), K and V^T tiles of 64 keys staged through
+//                        swizzled LDS, S^T = K.Q^T ("swapped") so each lane owns one query
+//                        column: row max / sum need two cross-lane steps only and the
+//                        probabilities feed the P.V MFMA straight from registers.
+//  * transpose_v_kernel: V [tokens][H*D] -> V^T [B][H][D][Tp] (zero padded) for the above.
+#include "ops.h"
+
+namespace s2s {
+
+// ------------------------------------------------------------------------------------
+// generic row-wise attention
+// ------------------------------------------------------------------------------------
+
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kvmax = p.kv_len_const;
+    float* qs = smem + wave * (D + kvmax + 8);   // q (f32) then scores
+    float* sc = qs + D;
+    if (t >= p.Tq) return;   // whole wave exits together; no block-level barriers below
+    const int hk = h / (p.H / p.Hkv);
+    int kv = p.kv_len ? min(p.kv_len[b], kvmax) : kvmax;
+    int jlo = 0, jhi = kv;   // allowed keys [jlo, jhi)
+    if (p.causal) jhi = min(kv, t + p.causal_off + 1);
+    if (p.window > 0) jlo = max(0, t + p.causal_off - p.window + 1);
+
+    const T* q = (const T*)p.Q + (long)b * p.q_bs + (long)t * p.q_rs + (long)h * D;
+    for (int d = lane; d < D; d += 64) qs[d] = Elem<T>::ld(q + d) * p.scale;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes above are visible to the wave
+
+    const T* Kb = (const T*)p.K + (long)b * p.kv_bs + (long)hk * D;
+    const T* Vb = (const T*)p.V + (long)b * p.kv_bs + (long)hk * D;
+    const float* bias = p.bias ? p.bias + (long)b * p.bias_bs + (long)h * p.bias_hs + (long)t * p.bias_rs + (p.bias_shift - t)
+                               : nullptr;
+    float mx = -INFINITY;
+    for (int j = jlo + lane; j < jhi; j += 64) {
+        const T* kr = Kb + (long)j * p.kv_rs;
+        float s = 0.f;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = fmaf(__uint_as_float(v[e] << 16), qs[c * 8 + 2 * e], s);
+                    s = fmaf(__uint_as_float(v[e] & 0xffff0000u), qs[c * 8 + 2 * e + 1], s);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D / 4; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(kr + c * 4);
+                s = fmaf(v.x, qs[c * 4], s);
+                s = fmaf(v.y, qs[c * 4 + 1], s);
+                s = fmaf(v.z, qs[c * 4 + 2], s);
+                s = fmaf(v.w, qs[c * 4 + 3], s);
+            }
+        }
+        if (bias) s += bias[j];
+        sc[j - jlo] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = jlo + lane; j < jhi; j += 64) {
+        const float e = expf(sc[j - jlo] - mx);
+        sc[j - jlo] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    T* o = (T*)p.O + (long)b * p.o_bs + (long)t * p.o_rs + (long)h * D;
+    constexpr int PER = (D + 63) / 64;
+    float acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc[u] = 0.f;
+    const int n = jhi - jlo;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        float pv[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) pv[u4] = sc[j + u4];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int d = lane + u * 64;
+            if (d < D) {
+                float v0 = Elem<T>::ld(Vb + (long)(jlo + j) * p.kv_rs + d);
+                float v1 = Elem<T>::ld(Vb + (long)(jlo + j + 1) * p.kv_rs + d);
+                float v2 = Elem<T>::ld(Vb + (long)(jlo + j + 2) * p.kv_rs + d);
+                float v3 = Elem<T>::ld(Vb + (long)(jlo + j + 3) * p.kv_rs + d);
+                acc[u] = fmaf(pv[0], v0, acc[u]);
+                acc[u] = fmaf(pv[1], v1, acc[u]);
+                acc[u] = fmaf(pv[2], v2, acc[u]);
+                acc[u] = fmaf(pv[3], v3, acc[u]);
+            }
+        }
+    }
+    for (; j < n; ++j) {
+        const float pj = sc[j];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int d = lane + u * 64;
+            if (d < D) acc[u] = fmaf(pj, Elem<T>::ld(Vb + (long)(jlo + j) * p.kv_rs + d), acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int d = lane + u * 64;
+        if (d < D) Elem<T>::st(o + d, acc[u] * inv);
+    }
+}
+
+template <typename T>
+static int launch_attn_rows(hipStream_t st, const AttnRowsParams& p) {
+    dim3 grid(cdiv(p.Tq, 4), p.H, p.B);
+    const size_t lds = sizeof(float) * 4 * (size_t)(p.D + p.kv_len_const + 8);
+    S2S_REQUIRE(lds <= 160 * 1024, "attention: kv length %d too long for the row kernel", p.kv_len_const);
+#define S2S_ROWS(DV)                                                                                     \
+    do {                                                                                                 \
+        if (lds > 64 * 1024)                                                                             \
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)attn_rows_kernel<T, DV>,                      \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        attn_rows_kernel<T, DV><<<grid, 256, lds, st>>>(p);                                              \
+    } while (0)
+    switch (p.D) {
+        case 32: S2S_ROWS(32); break;
+        case 64: S2S_ROWS(64); break;
+        case 128: S2S_ROWS(128); break;
+        default: return fail(S2S_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32/64/128)", p.D);
+    }
+#undef S2S_ROWS
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype) {
+    S2S_REQUIRE(p.B > 0 && p.H > 0 && p.Hkv > 0 && p.H % p.Hkv == 0 && p.Tq > 0, "attention: bad shape");
+    if (p.kv_len_const <= 0) return fail(S2S_ERR_ARG, "attention: kv_len_const must be > 0");
+    return dtype == S2S_BF16 ? launch_attn_rows<__hip_bfloat16>(st, p) : launch_attn_rows<float>(st, p);
+}
+
+// ------------------------------------------------------------------------------------
+// V transpose: V rows (b, t) at V + b*v_bs + t*v_rs + h*D  ->  Vt[b][h][d][Tp]
+// grid = (Tp/64, H, B), block 256
+// ------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ V, long v_bs, long v_rs,
+                                                          T* __restrict__ Vt, int Tk, int Tp, int H) {
+    __shared__ T tile[64][D + 2];
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    for (int i = threadIdx.x; i < 64 * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        const int t = t0 + r;
+        tile[r][d] = t < Tk ? V[(long)b * v_bs + (long)t * v_rs + (long)h * D + d] : Elem<T>::zero();
+    }
+    __syncthreads();
+    T* out = Vt + ((long)(b * H + h) * D) * Tp + t0;
+    for (int i = threadIdx.x; i < 64 * D; i += 256) {
+        const int d = i >> 6, r = i & 63;
+        out[(long)d * Tp + r] = tile[r][d];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// bf16 MFMA flash attention (non-causal; key-length mask; optional additive bias)
+// ------------------------------------------------------------------------------------
+
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
+    constexpr int KT = 64;                       // keys per tile
+    constexpr int KROWB = D * 2;                 // bytes per K row in LDS
+    constexpr int KCH = KROWB / 16;              // 16-byte chunks per K row (8 or 16)
+    constexpr int K_CHUNKS = KT * KCH;           // per tile
+    constexpr int V_CHUNKS = D * 8;              // V^T tile: D rows x 128 bytes
+    constexpr int KPT = K_CHUNKS / 256, VPT = V_CHUNKS / 256;
+    constexpr int KK = D / 32;                   // k-steps of the QK^T MFMA
+    constexpr int DT = D / 16;                   // output d fragments
+    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KROWB + D * 128];
+    unsigned char* sK = lds;
+    unsigned char* sV = lds + KT * KROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int kv = p.kv_len ? min(p.kv_len[b], p.Tk) : p.Tk;
+
+    // Q fragments (B operand of S^T = K.Q^T): Q[q = l15 + 16*qf][d = kk*32 + lg*8 .. +7]
+    bf16x8_t qf[2][KK];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int q = q0 + f * 16 + l15;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (q < p.Tq)
+                v = *reinterpret_cast<const u32x4_t*>(p.Q + (long)b * p.q_bs + (long)q * p.q_rs + (long)h * D + kk * 32 + lg * 8);
+            qf[f][kk] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    f32x4_t oacc[2][DT];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[f][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+    const __hip_bfloat16* Kb = p.K + (long)b * p.k_bs + (long)h * D;
+    const __hip_bfloat16* Vb = p.Vt + ((long)(b * p.H + h) * D) * p.Tp;
+    const float* bias = p.bias ? p.bias + (long)b * p.bias_bs + (long)h * p.bias_hs : nullptr;
+
+    u32x4_t gk[KPT], gv[VPT];
+    auto load_tile = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / KCH, ch = c % KCH;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (j0 + row < kv) v = *reinterpret_cast<const u32x4_t*>(Kb + (long)(j0 + row) * p.k_rs + ch * 8);
+            gk[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, ch = c & 7;
+            gv[i] = *reinterpret_cast<const u32x4_t*>(Vb + (long)row * p.Tp + j0 + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / KCH, ch = c % KCH;
+            *reinterpret_cast<u32x4_t*>(sK + row * KROWB + ((ch ^ (row & (KCH - 1))) << 4)) = gk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, ch = c & 7;
+            *reinterpret_cast<u32x4_t*>(sV + row * 128 + ((ch ^ (row & 7)) << 4)) = gv[i];
+        }
+    };
+
+    const int ntiles = (kv + KT - 1) / KT;
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * KT;
+        if (t + 1 < ntiles) load_tile(j0 + KT);
+
+        // ---- S^T[key][q] for 4 key fragments x 2 query fragments
+        f32x4_t s[4][2];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            s[kf][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            s[kf][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int row = kf * 16 + l15;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const bf16x8_t ka = *reinterpret_cast<const bf16x8_t*>(
+                    sK + row * KROWB + (((kk * 4 + lg) ^ (row & (KCH - 1))) << 4));
+                s[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[0][kk], s[kf][0], 0, 0, 0);
+                s[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[1][kk], s[kf][1], 0, 0, 0);
+            }
+        }
+        // ---- online softmax per query column (lane-local column l15, rows = keys lg*4+r)
+        bf16x8_t pf[2][2];   // [qf][kt32]
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int q = q0 + f * 16 + l15;
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + kf * 16 + lg * 4 + r;
+                    float v = s[kf][f][r] * p.scale_log2e;
+                    if (bias && q < p.Tq && j < kv)
+                        v += bias[(long)q * p.bias_rs + (p.bias_shift - q) + j] * 1.4426950408889634f;
+                    v = j < kv ? v : -INFINITY;
+                    s[kf][f][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrun[f], tmax);
+            const float msafe = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = exp2f(mrun[f] - msafe);   // mrun = -inf -> 0
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[kf][f][r] - msafe);
+                    pv[kf][r] = e;
+                    psum += e;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            lrun[f] = lrun[f] * alpha + psum;
+            mrun[f] = mnew;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) oacc[f][dt] *= alpha;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                unsigned short e[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = f32_to_bf16_bits(pv[2 * k2][r]);
+                    e[4 + r] = f32_to_bf16_bits(pv[2 * k2 + 1][r]);
+                }
+                u32x4_t w;
+                w[0] = e[0] | ((unsigned)e[1] << 16);
+                w[1] = e[2] | ((unsigned)e[3] << 16);
+                w[2] = e[4] | ((unsigned)e[5] << 16);
+                w[3] = e[6] | ((unsigned)e[7] << 16);
+                pf[f][k2] = __builtin_bit_cast(bf16x8_t, w);
+            }
+        }
+        // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int row = dt * 16 + l15;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                // MFMA k index lg*8+e  <->  key k2*32 + (e<4 ? lg*4+e : 16+lg*4+e-4)
+                const int c0 = (k2 * 64 + lg * 8) >> 4, o0 = (lg * 8) & 15;          // bytes k2*64 + lg*8
+                const int c1 = (k2 * 64 + 32 + lg * 8) >> 4;
+                const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(sV + row * 128 + ((c0 ^ (row & 7)) << 4) + o0);
+                const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(sV + row * 128 + ((c1 ^ (row & 7)) << 4) + o0);
+                u32x4_t w;
+                w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+                const bf16x8_t va = __builtin_bit_cast(bf16x8_t, w);
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[0][k2], oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[1][k2], oacc[1][dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    // ---- write O[q][h*D + d]: lane holds d = dt*16 + lg*4 + r (4 consecutive) for q = l15
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int q = q0 + f * 16 + l15;
+        if (q >= p.Tq) continue;
+        const float inv = lrun[f] > 0.f ? 1.0f / lrun[f] : 0.f;
+        __hip_bfloat16* o = p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            u32x2_t w;
+            w[0] = f32_to_bf16_bits(oacc[f][dt][0] * inv) | ((unsigned)f32_to_bf16_bits(oacc[f][dt][1] * inv) << 16);
+            w[1] = f32_to_bf16_bits(oacc[f][dt][2] * inv) | ((unsigned)f32_to_bf16_bits(oacc[f][dt][3] * inv) << 16);
+            *reinterpret_cast<u32x2_t*>(o + dt * 16 + lg * 4) = w;
+        }
+    }
+}
+
+int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
+    S2S_REQUIRE(p.Tp % 64 == 0 && p.Tp >= p.Tk, "attention: Tp=%d must be a multiple of 64 and >= Tk=%d", p.Tp, p.Tk);
+    dim3 grid(cdiv(p.Tq, 128), p.H, p.B);
+    if (D == 64) attn_mfma_kernel<64><<<grid, 256, 0, st>>>(p);
+    else if (D == 128) attn_mfma_kernel<128><<<grid, 256, 0, st>>>(p);
+    else return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int transpose_v(hipStream_t st, const void* V, long v_bs, long v_rs, void* Vt, int B, int H, int D, int Tk,
+                int Tp, int dtype) {
+    S2S_REQUIRE(Tp % 64 == 0 && Tp >= Tk, "transpose_v: bad Tp");
+    dim3 grid(Tp / 64, H, B);
+#define S2S_TV(TT, DV) transpose_v_kernel<TT, DV><<<grid, 256, 0, st>>>((const TT*)V, v_bs, v_rs, (TT*)Vt, Tk, Tp, H)
+    if (dtype == S2S_BF16 && D == 64) S2S_TV(__hip_bfloat16, 64);
+    else if (dtype == S2S_BF16 && D == 128) S2S_TV(__hip_bfloat16, 128);
+    else return fail(S2S_ERR_UNSUPPORTED, "transpose_v: unsupported dtype/head_dim");
+#undef S2S_TV
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+}  // namespace s2s
+
+using namespace s2s;
+
+// Public op: self/cross attention over token-major buffers.
+//   q: [B][Tq][q_rs] with head h at columns h*D.. ; k, v: [B][Tk][kv_rs] likewise (Hkv heads);
+//   o: [B][Tq][H*D].  use_mfma selects the bf16 flash kernel (needs vt_scratch [B][Hkv==H][D][Tp]).
+extern "C" int32_t s2s_op_attention(void* stream, const void* q, int64_t q_rs, const void* k, const void* v,
+                                    int64_t kv_rs, void* o, const int32_t* kv_len_dev, const float* bias,
+                                    int32_t B, int32_t H, int32_t Hkv, int32_t Tq, int32_t Tk, int32_t D,
+                                    float scale, int32_t causal, int32_t window, int32_t dtype,
+                                    int32_t use_mfma, void* vt_scratch) {
+    hipStream_t st = (hipStream_t)stream;
+    if (use_mfma) {
+        S2S_REQUIRE(dtype == S2S_BF16 && H == Hkv && !causal && window <= 0 && vt_scratch, "attention: MFMA path preconditions");
+        const int Tp = cdiv(Tk, 64) * 64;
+        int rc = transpose_v(st, v, (long)Tk * kv_rs, kv_rs, vt_scratch, B, H, D, Tk, Tp, dtype);
+        if (rc) return rc;
+        AttnMfmaParams p{};
+        p.Q = (const __hip_bfloat16*)q; p.q_bs = (long)Tq * q_rs; p.q_rs = q_rs;
+        p.K = (const __hip_bfloat16*)k; p.k_bs = (long)Tk * kv_rs; p.k_rs = kv_rs;
+        p.Vt = (const __hip_bfloat16*)vt_scratch;
+        p.O = (__hip_bfloat16*)o; p.o_bs = (long)Tq * H * D; p.o_rs = (long)H * D;
+        p.bias = bias; p.bias_bs = (long)H * Tq * (2 * Tk - 1); p.bias_hs = (long)Tq * (2 * Tk - 1);
+        p.bias_rs = 2 * Tk - 1; p.bias_shift = Tk - 1;
+        p.kv_len = kv_len_dev; p.Tk = Tk; p.Tp = Tp; p.Tq = Tq; p.H = H; p.B = B;
+        p.scale_log2e = scale * 1.4426950408889634f;
+        return attn_mfma(st, p, D);
+    }
+    AttnRowsParams p{};
+    p.Q = q; p.q_bs = (long)Tq * q_rs; p.q_rs = q_rs;
+    p.K = k; p.V = v; p.kv_bs = (long)Tk * kv_rs; p.kv_rs = kv_rs;
+    p.O = o; p.o_bs = (long)Tq * H * D; p.o_rs = (long)H * D;
+    p.bias = bias; p.bias_bs = (long)H * Tq * (2 * Tk - 1); p.bias_hs = (long)Tq * (2 * Tk - 1);
+    p.bias_rs = 2 * Tk - 1; p.bias_shift = Tk - 1;
+    p.kv_len = kv_len_dev; p.kv_len_const = Tk;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Tq = Tq; p.D = D;
+    p.causal = causal; p.causal_off = Tk - Tq; p.window = window; p.scale = scale;
+    return attn_rows(st, p, dtype);
+}

@@ -60,6 +60,7 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float zero() { return 0.f; }
 };
 template <> struct Elem<__hip_bfloat16> {
     static __device__ __forceinline__ float ld(const __hip_bfloat16* p) {
@@ -67,6 +68,10 @@ template <> struct Elem<__hip_bfloat16> {
     }
     static __device__ __forceinline__ void st(__hip_bfloat16* p, float v) {
         *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
+    }
+    static __device__ __forceinline__ __hip_bfloat16 zero() {
+        unsigned short z = 0;
+        return *reinterpret_cast<__hip_bfloat16*>(&z);
     }
 };
 

@@ -19,7 +19,7 @@
 //
 // Element types: bf16 inputs -> v_mfma_f32_16x16x32_bf16, f32 inputs ->
 // v_mfma_f32_16x16x4_f32 (exact f32, used by the parity policy).  Accumulation is f32.
-#include "common.h"
+#include "ops.h"
 
 #include <algorithm>
 
@@ -56,10 +56,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Row r of A / C / residual lives at base + (r / G) * batch_stride + (r % G) * ld, so that
+// per-utterance zero-padded time-major buffers can be addressed as overlapping im2col rows
+// (1-D convolutions become GEMMs without materialising im2col) and positional tables can be
+// broadcast over the batch (r_bs = 0).
+struct RowMap {
+    long a_bs, c_bs, r_bs, ldr;
+    int G;
+};
+
 template <typename T, typename CT>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
     constexpr int EPC = MfmaTraits<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
@@ -83,16 +92,27 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 
     // staging: 1024 16-byte chunks per operand tile, 4 per thread
     u32x4_t ga[4], gw[4];
+    const T* arow[4];
+    const T* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, ch = c & 7;
+        const int m = m0 + row, n = n0 + row;
+        arow[i] = nullptr;
+        wrow[i] = nullptr;
+        if (m < M) arow[i] = A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda + ch * EPC;
+        if (n < N) wrow[i] = W + (long)n * K + ch * EPC;
+    }
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256;
-            const int row = c >> 3, ch = c & 7;
+            const int ch = (tid + i * 256) & 7;
             const int k = k0 + ch * EPC;
             u32x4_t va = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
             if (k < K) {
-                if (m0 + row < M) va = *reinterpret_cast<const u32x4_t*>(A + (long)(m0 + row) * lda + k);
-                if (n0 + row < N) vw = *reinterpret_cast<const u32x4_t*>(W + (long)(n0 + row) * K + k);
+                if (arow[i]) va = *reinterpret_cast<const u32x4_t*>(arow[i] + k0);
+                if (wrow[i]) vw = *reinterpret_cast<const u32x4_t*>(wrow[i] + k0);
             }
             ga[i] = va;
             gw[i] = vw;
@@ -169,9 +189,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + i * 16 + lg * 4 + r;
                 if (m >= M) continue;
+                const int mb = m / rm.G, mr = m % rm.G;
                 float v = apply_act(acc[i][j][r] + bv, act);
-                if (residual) v += residual[(long)m * ldc + n];
-                Elem<CT>::st(C + (long)m * ldc + n, v);
+                if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
+                Elem<CT>::st(C + (long)mb * rm.c_bs + (long)mr * ldc + n, v);
             }
     }
 }
@@ -183,7 +204,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 template <typename T, typename CT, int MT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int ksplit, int kslice) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int ksplit, int kslice,
+    RowMap rm) {
     constexpr int KPF = MfmaTraits<T>::KPF;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int nb = blockIdx.x / ksplit, ks = blockIdx.x - nb * ksplit;
@@ -196,6 +218,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 
     const bool nvalid = n < N;
     const T* wrow = W + (long)(nvalid ? n : 0) * K;
+    const T* arow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + l15;
+        arow[i] = m < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : nullptr;
+    }
     if constexpr (sizeof(T) == 2) {
         for (int k0 = kbeg; k0 < kend; k0 += 4 * KPF) {
             bf16x8_t fw[4];
@@ -211,9 +239,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
                 const int k = k0 + u * KPF + lg * 8;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int m = i * 16 + l15;
                     u32x4_t v = {0u, 0u, 0u, 0u};
-                    if (m < M && k < kend) v = *reinterpret_cast<const u32x4_t*>(A + (long)m * lda + k);
+                    if (arow[i] && k < kend) v = *reinterpret_cast<const u32x4_t*>(arow[i] + k);
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v), fw[u], acc[i], 0, 0, 0);
                 }
             }
@@ -231,8 +258,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
                 const int k = k0 + u * KPF + lg;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int m = i * 16 + l15;
-                    const float a = (m < M && k < kend) ? A[(long)m * lda + k] : 0.f;
+                    const float a = (arow[i] && k < kend) ? arow[i][k] : 0.f;
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fw[u], acc[i], 0, 0, 0);
                 }
             }
@@ -247,44 +273,52 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
         for (int r = 0; r < 4; ++r) {
             const int m = i * 16 + lg * 4 + r;
             if (m >= M) continue;
+            const int mb = m / rm.G, mr = m % rm.G;
+            CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + n;
             if (ksplit == 1) {
                 float v = apply_act(acc[i][r] + bv, act);
-                if (residual) v += residual[(long)m * ldc + n];
-                Elem<CT>::st(C + (long)m * ldc + n, v);
+                if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
+                Elem<CT>::st(cp, v);
             } else {
                 // split-K: C (f32) already holds the residual; partial sums are added onto it
-                atomicAdd(reinterpret_cast<float*>(C) + (long)m * ldc + n, acc[i][r] + bv);
+                atomicAdd(reinterpret_cast<float*>(cp), acc[i][r] + bv);
             }
         }
 }
 
 template <typename T, typename CT>
-static int launch_gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
-                       const float* residual, void* C, long ldc, int M, int N, int K, int act,
-                       bool allow_splitk) {
+static int launch_gemm(hipStream_t st, const GemmArgs& g) {
+    RowMap rm;
+    rm.G = g.G > 0 ? g.G : (g.M > 0 ? g.M : 1);
+    rm.a_bs = g.a_bs;
+    rm.c_bs = g.c_bs;
+    rm.r_bs = g.r_bs;
+    rm.ldr = g.ldr > 0 ? g.ldr : g.ldc;
+    const int M = g.M, N = g.N, K = g.K;
     if (M <= 64) {
         const int MT = cdiv(M, 16);
         const int ntiles = cdiv(N, 64);
         int ksplit = 1;
         // split K only where partial sums can be combined by plain addition onto C
-        const bool can_split = allow_splitk && act == S2S_ACT_NONE && sizeof(CT) == 4 &&
-                               (residual == nullptr || residual == (const float*)C);
+        const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
+        const bool can_split = g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 &&
+                               (g.residual == nullptr || in_place) && rm.G == M;
         constexpr int KQ = sizeof(T) == 2 ? 128 : 32;   // K consumed per loop trip
         if (can_split) {
             while (ntiles * ksplit < 256 && K / (ksplit * 2) >= 2 * KQ) ksplit *= 2;
         }
         int kslice = cdiv(cdiv(K, ksplit), KQ) * KQ;
         ksplit = cdiv(K, kslice);
-        if (ksplit > 1 && residual == nullptr) {
+        if (ksplit > 1 && g.residual == nullptr) {
             // no residual in place: C must start from zero
-            hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
+            hipError_t e = hipMemset2DAsync(g.C, g.ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
             if (e != hipSuccess) return fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(e));
         }
         dim3 grid(ntiles * ksplit);
 #define S2S_SKINNY(MTV)                                                                          \
-    gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)W, bias,      \
-                                                        residual, (CT*)C, ldc, M, N, K, act,      \
-                                                        ksplit, kslice)
+    gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
+                                                         g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
+                                                         N, K, g.act, ksplit, kslice, rm)
         switch (MT) {
             case 1: S2S_SKINNY(1); break;
             case 2: S2S_SKINNY(2); break;
@@ -295,28 +329,35 @@ static int launch_gemm(hipStream_t st, const void* A, long lda, const void* W, c
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
         gemm_tile_kernel<T, CT><<<tiles_m * tiles_n, 256, 0, st>>>(
-            (const T*)A, lda, (const T*)W, bias, residual, (CT*)C, ldc, M, N, K, act, tiles_m);
+            (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
+            tiles_m, rm);
     }
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
+int gemm_ex(hipStream_t st, const GemmArgs& g) {
+    S2S_REQUIRE(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
+    if (g.M == 0) return S2S_OK;
+    S2S_REQUIRE(g.A && g.W && g.C, "gemm: null operand");
+    const int epc = g.ab_dtype == S2S_BF16 ? 8 : 4;
+    S2S_REQUIRE(g.K % epc == 0 && g.lda % epc == 0 && g.a_bs % epc == 0,
+                "gemm: K=%d / lda=%ld / a_bs=%ld must be multiples of %d", g.K, g.lda, g.a_bs, epc);
+    S2S_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);
+    if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_F32) return launch_gemm<__hip_bfloat16, float>(st, g);
+    if (g.ab_dtype == S2S_F32 && g.c_dtype == S2S_F32) return launch_gemm<float, float>(st, g);
+    return fail(S2S_ERR_UNSUPPORTED, "gemm: unsupported dtype combination ab=%d c=%d", g.ab_dtype, g.c_dtype);
+}
+
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
          const float* residual, void* C, long ldc, int M, int N, int K, int ab_dtype, int c_dtype,
          int act, bool allow_splitk) {
-    S2S_REQUIRE(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    if (M == 0) return S2S_OK;
-    S2S_REQUIRE(A && W && C, "gemm: null operand");
-    const int epc = ab_dtype == S2S_BF16 ? 8 : 4;
-    S2S_REQUIRE(K % epc == 0 && lda % epc == 0, "gemm: K=%d / lda=%ld must be multiples of %d", K, lda, epc);
-    S2S_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: operands must be 16-byte aligned");
-    if (ab_dtype == S2S_BF16 && c_dtype == S2S_BF16)
-        return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
-    if (ab_dtype == S2S_BF16 && c_dtype == S2S_F32)
-        return launch_gemm<__hip_bfloat16, float>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
-    if (ab_dtype == S2S_F32 && c_dtype == S2S_F32)
-        return launch_gemm<float, float>(st, A, lda, W, bias, residual, C, ldc, M, N, K, act, allow_splitk);
-    return fail(S2S_ERR_UNSUPPORTED, "gemm: unsupported dtype combination ab=%d c=%d", ab_dtype, c_dtype);
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.residual = residual; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.G = 0; g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
+    g.allow_splitk = allow_splitk;
+    return gemm_ex(st, g);
 }
 
 }  // namespace s2s
@@ -326,4 +367,24 @@ extern "C" int32_t s2s_op_gemm(void* stream, const void* A, int64_t lda, const v
                                int32_t ab_dtype, int32_t c_dtype, int32_t act) {
     return s2s::gemm((hipStream_t)stream, A, (long)lda, W, bias, residual, C, (long)ldc, M, N, K, ab_dtype,
                      c_dtype, act, /*allow_splitk=*/false);
+}
+
+/* 1-D convolution over a zero-padded time-major buffer, as one GEMM (no im2col):
+ * x: [B][T_in + 2*pad][Cin] with `pad` zero rows on both sides of every item;
+ * w: [Cout][ksize][Cin]; y: [B][y_rows][Cout], output frame t written at row t + y_row0. */
+extern "C" int32_t s2s_op_conv1d_tm(void* stream, const void* x, const void* w, const float* bias, void* y,
+                                    int32_t B, int32_t T_in, int32_t Cin, int32_t Cout, int32_t ksize,
+                                    int32_t stride, int32_t pad, int32_t y_rows, int32_t y_row0,
+                                    int32_t ab_dtype, int32_t c_dtype, int32_t act) {
+    S2S_REQUIRE(B > 0 && T_in > 0 && ksize > 0 && stride > 0 && pad >= 0, "conv1d: bad arguments");
+    const int T_out = (T_in + 2 * pad - ksize) / stride + 1;
+    S2S_REQUIRE(y_row0 >= 0 && y_row0 + T_out <= y_rows, "conv1d: output rows out of range");
+    s2s::GemmArgs g{};
+    g.A = x; g.lda = (long)stride * Cin; g.a_bs = (long)(T_in + 2 * pad) * Cin;
+    g.W = w; g.bias = bias;
+    const size_t esz = c_dtype == S2S_F32 ? 4 : 2;
+    g.C = (char*)y + (size_t)y_row0 * Cout * esz; g.ldc = Cout; g.c_bs = (long)y_rows * Cout;
+    g.M = B * T_out; g.N = Cout; g.K = ksize * Cin; g.G = T_out;
+    g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
+    return s2s::gemm_ex((hipStream_t)stream, g);
 }

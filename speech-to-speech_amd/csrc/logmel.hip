@@ -17,6 +17,8 @@
 #include "common.h"
 
 #include <math.h>
+
+#include <algorithm>
 #include <vector>
 
 namespace s2s {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     const float* __restrict__ pcm, long pcm_stride, const int* __restrict__ n_samples,
     const float* __restrict__ basis, const float* __restrict__ melw,
     const float* __restrict__ window, int n_bin_tiles, int n_mel_tiles, int mel_ksteps,
-    int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax) {
+    int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax, int time_major) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* raw = smem;                       // RAW_LDS floats; later reused as the out stage
     float* win = smem + RAW_LDS;             // TAPS
@@ -190,14 +192,16 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     __syncthreads();
 
     if (KIND == S2S_FRONTEND_WHISPER) {
+        lmax = wave_max(lmax);
+        if (lane == 0) atomicMax(&wmax[b], f32_ordered(lmax));
+    }
+    if (KIND == S2S_FRONTEND_WHISPER && !time_major) {
         // out[b][mel][t]: each wave writes 64 consecutive frames of one mel row
         float* ob = out + (long)b * n_mels * n_frames;
         for (int mel = wave; mel < n_mels; mel += 4) {
             const int t = t0 + lane;
             if (t < n_frames) ob[(long)mel * n_frames + t] = stage[lane * sstride + mel];
         }
-        lmax = wave_max(lmax);
-        if (lane == 0) atomicMax(&wmax[b], f32_ordered(lmax));
     } else {
         // out[b][t][mel]: each frame row is n_mels contiguous floats
         float* ob = out + (long)b * n_frames * n_mels;
@@ -218,6 +222,26 @@ __global__ void whisper_finalize_kernel(const float* __restrict__ in, OutT* __re
         const int b = (int)(i / per_item);
         const float floor_v = f32_unordered(wmax[b]) - 8.0f;
         const float v = (fmaxf(in[i], floor_v) + 4.0f) * 0.25f;
+        Elem<OutT>::st(out + i, v);
+    }
+}
+
+// Whisper, encoder layout: out[b][r][mel], r = frame + 1, rows 0 and n_frames+1 are zero padding.
+template <typename OutT>
+__global__ void whisper_finalize_tm_kernel(const float* __restrict__ in, OutT* __restrict__ out,
+                                           const unsigned int* __restrict__ wmax, int n_frames, int n_mels,
+                                           long total) {
+    const long per_item = (long)(n_frames + 2) * n_mels;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_item);
+        const long r = i - (long)b * per_item;
+        const int row = (int)(r / n_mels);
+        float v = 0.f;
+        if (row >= 1 && row <= n_frames) {
+            const float floor_v = f32_unordered(wmax[b]) - 8.0f;
+            v = (fmaxf(in[(long)b * n_frames * n_mels + r - n_mels], floor_v) + 4.0f) * 0.25f;
+        }
         Elem<OutT>::st(out + i, v);
     }
 }
@@ -391,7 +415,7 @@ extern "C" int32_t s2s_logmel_whisper(void* frontend, void* stream, const float*
     dim3 grid(cdiv(WHISPER_FRAMES, FT), B);
     logmel_tile_kernel<S2S_FRONTEND_WHISPER><<<grid, 256, tile_lds_bytes(f), st>>>(
         pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
-        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax);
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 0);
     S2S_LAUNCH_CHECK();
     const long per_item = (long)f->n_mels * WHISPER_FRAMES;
     const long total = per_item * B;
@@ -400,6 +424,32 @@ extern "C" int32_t s2s_logmel_whisper(void* frontend, void* stream, const float*
         whisper_finalize_kernel<float><<<blocks, 256, 0, st>>>(f->scratch, (float*)out_dev, f->wmax, per_item, total);
     else
         whisper_finalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(f->scratch, (__hip_bfloat16*)out_dev, f->wmax, per_item, total);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_logmel_whisper_tm(void* frontend, void* stream, const float* pcm_dev,
+                                         int64_t pcm_stride, const int32_t* n_samples_dev, int32_t B,
+                                         void* out_dev, int32_t out_dtype) {
+    Frontend* f = (Frontend*)frontend;
+    S2S_REQUIRE(f && f->kind == S2S_FRONTEND_WHISPER, "not a Whisper front-end");
+    S2S_REQUIRE(B >= 0 && B <= f->max_batch, "batch %d exceeds max_batch %d", B, f->max_batch);
+    S2S_REQUIRE(out_dtype == S2S_F32 || out_dtype == S2S_BF16, "bad out_dtype %d", out_dtype);
+    if (B == 0) return S2S_OK;
+    S2S_REQUIRE(pcm_dev && n_samples_dev && out_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    S2S_HIP_CHECK(hipMemsetAsync(f->wmax, 0, (size_t)B * sizeof(unsigned int), st));
+    dim3 grid(cdiv(WHISPER_FRAMES, FT), B);
+    logmel_tile_kernel<S2S_FRONTEND_WHISPER><<<grid, 256, tile_lds_bytes(f), st>>>(
+        pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 1);
+    S2S_LAUNCH_CHECK();
+    const long total = (long)B * (WHISPER_FRAMES + 2) * f->n_mels;
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+    if (out_dtype == S2S_F32)
+        whisper_finalize_tm_kernel<float><<<blocks, 256, 0, st>>>(f->scratch, (float*)out_dev, f->wmax, WHISPER_FRAMES, f->n_mels, total);
+    else
+        whisper_finalize_tm_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(f->scratch, (__hip_bfloat16*)out_dev, f->wmax, WHISPER_FRAMES, f->n_mels, total);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -419,7 +469,7 @@ extern "C" int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float
     dim3 grid(cdiv(t_max, FT), B);
     logmel_tile_kernel<S2S_FRONTEND_PARAKEET><<<grid, 256, tile_lds_bytes(f), st>>>(
         pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
-        f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, f->scratch, nullptr);
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, f->scratch, nullptr, 1);
     S2S_LAUNCH_CHECK();
     parakeet_stats_kernel<<<dim3(cdiv(f->n_mels, 32), B), dim3(32, 8), 0, st>>>(
         f->scratch, n_samples_dev, t_max, f->n_mels, f->stats);

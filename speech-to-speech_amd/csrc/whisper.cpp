@@ -1,0 +1,407 @@
+// Whisper encoder / greedy decoder as a native kernel graph (C++ host, HIP kernels).
+//
+// Replaces, for one batch of sessions, what the reference obtains from
+//   model.get_encoder()(input_features), model.detect_language(encoder_outputs) and
+//   model.generate(input_features, max_new_tokens=128, num_beams=1, return_timestamps=False,
+//                  task="transcribe", language=...)
+// (reference STT/whisper_stt_handler.py:166-197,243; arithmetic restated from
+//  transformers/models/whisper/modeling_whisper.py and generation_whisper.py:1455-1608,
+//  1774-1812, 1610-1675).
+//
+// Layout in HBM (all per batch of B sessions, T = 1500 encoder frames, d = d_model):
+//   feats   [B][3002][n_mels]  time-major log-mel with one zero row either side (conv padding)
+//   y1      [B][3002][d]       conv1+GELU output, same padding convention -> conv2 reads it as
+//                              overlapping rows (no im2col)
+//   x       [B*T][d] f32       residual stream;  h/qkv/att/ffn scratch in the model dtype
+//   cross   [L][B*T][2d]       cross-attention K|V, projected once per utterance
+//   self    [L][B][Tmax][d]x2  decoder self-attention cache
+#include "ops.h"
+
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace s2s {
+
+constexpr int ENC_T = 1500;
+constexpr int FEAT_ROWS = 3002;
+
+struct Tensor {
+    const void* ptr;
+    long numel;
+};
+
+struct Whisper {
+    s2s_whisper_config cfg;
+    int max_batch;
+    int esz;   // bytes per model-dtype element
+    std::map<std::string, Tensor> w;
+    bool finalized = false;
+    // workspace
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    void *y1, *h, *qkv, *vt, *att, *ffn, *enc_out, *cross, *self_k, *self_v;
+    float *x, *xd, *logits;
+    void *hd, *qkvd, *attd, *ffnd, *qd;
+    int *cur_ids, *pos, *step, *out_ids, *out_len, *finished, *picked, *n_active;
+    int tmax;
+    int* host_flag = nullptr;   // pinned
+};
+
+static const Tensor* find(const Whisper* m, const std::string& name) {
+    auto it = m->w.find(name);
+    return it == m->w.end() ? nullptr : &it->second;
+}
+
+#define W_GET(var, name, n)                                                                      \
+    const Tensor* var##_t = find(m, name);                                                       \
+    if (!var##_t) return fail(S2S_ERR_STATE, "whisper: missing tensor %s", std::string(name).c_str()); \
+    if (var##_t->numel != (long)(n))                                                             \
+        return fail(S2S_ERR_STATE, "whisper: tensor %s has %ld elements, expected %ld",          \
+                    std::string(name).c_str(), var##_t->numel, (long)(n));                       \
+    const void* var = var##_t->ptr
+
+static std::string lname(const char* side, int l, const char* rest) {
+    return std::string(side) + "." + std::to_string(l) + "." + rest;
+}
+
+static int check_weights(const Whisper* m) {
+    const auto& c = m->cfg;
+    const long d = c.d_model;
+    { W_GET(t, "enc.conv1.w", d * 3 * c.n_mels); (void)t; }
+    { W_GET(t, "enc.conv1.b", d); (void)t; }
+    { W_GET(t, "enc.conv2.w", d * 3 * d); (void)t; }
+    { W_GET(t, "enc.conv2.b", d); (void)t; }
+    { W_GET(t, "enc.pos", (long)ENC_T * d); (void)t; }
+    { W_GET(t, "enc.ln_post.g", d); (void)t; }
+    { W_GET(t, "enc.ln_post.b", d); (void)t; }
+    for (int l = 0; l < c.enc_layers; ++l) {
+        const char* names[] = {"ln1.g", "ln1.b", "qkv.b", "o.b", "ln2.g", "ln2.b", "fc2.b"};
+        for (const char* nm : names) { W_GET(t, lname("enc", l, nm), std::string(nm) == "qkv.b" ? 3 * d : d); (void)t; }
+        { W_GET(t, lname("enc", l, "qkv.w"), 3 * d * d); (void)t; }
+        { W_GET(t, lname("enc", l, "o.w"), d * d); (void)t; }
+        { W_GET(t, lname("enc", l, "fc1.w"), (long)c.ffn * d); (void)t; }
+        { W_GET(t, lname("enc", l, "fc1.b"), c.ffn); (void)t; }
+        { W_GET(t, lname("enc", l, "fc2.w"), (long)c.ffn * d); (void)t; }
+    }
+    { W_GET(t, "dec.tok", (long)c.vocab * d); (void)t; }
+    { W_GET(t, "dec.pos", (long)c.max_target * d); (void)t; }
+    { W_GET(t, "dec.ln.g", d); (void)t; }
+    { W_GET(t, "dec.ln.b", d); (void)t; }
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const char* dn[] = {"ln1.g", "ln1.b", "o.b", "ln2.g", "ln2.b", "cq.b", "co.b", "ln3.g", "ln3.b", "fc2.b"};
+        for (const char* nm : dn) { W_GET(t, lname("dec", l, nm), d); (void)t; }
+        { W_GET(t, lname("dec", l, "qkv.w"), 3 * d * d); (void)t; }
+        { W_GET(t, lname("dec", l, "qkv.b"), 3 * d); (void)t; }
+        { W_GET(t, lname("dec", l, "o.w"), d * d); (void)t; }
+        { W_GET(t, lname("dec", l, "cq.w"), d * d); (void)t; }
+        { W_GET(t, lname("dec", l, "ckv.w"), 2 * d * d); (void)t; }
+        { W_GET(t, lname("dec", l, "ckv.b"), 2 * d); (void)t; }
+        { W_GET(t, lname("dec", l, "co.w"), d * d); (void)t; }
+        { W_GET(t, lname("dec", l, "fc1.w"), (long)c.ffn * d); (void)t; }
+        { W_GET(t, lname("dec", l, "fc1.b"), c.ffn); (void)t; }
+        { W_GET(t, lname("dec", l, "fc2.w"), (long)c.ffn * d); (void)t; }
+    }
+    return S2S_OK;
+}
+
+static const void* P(const Whisper* m, const std::string& name) { return find(m, name)->ptr; }
+static const float* PF(const Whisper* m, const std::string& name) { return (const float*)find(m, name)->ptr; }
+
+struct ArenaPlan {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+static int finalize(Whisper* m) {
+    int rc = check_weights(m);
+    if (rc) return rc;
+    const auto& c = m->cfg;
+    const size_t B = m->max_batch, d = c.d_model, e = m->esz, T = ENC_T;
+    m->tmax = c.max_target;
+    const size_t Tp = (T + 63) / 64 * 64;
+    ArenaPlan a;
+    const size_t o_y1 = a.take(B * FEAT_ROWS * d * e);
+    const size_t o_x = a.take(B * T * d * 4);
+    const size_t o_h = a.take(B * T * d * e);
+    const size_t o_qkv = a.take(B * T * 3 * d * e);
+    const size_t o_vt = a.take(B * d * Tp * e);
+    const size_t o_att = a.take(B * T * d * e);
+    const size_t o_ffn = a.take(B * T * (size_t)c.ffn * e);
+    const size_t o_enc = a.take(B * T * d * e);
+    const size_t o_cross = a.take((size_t)c.dec_layers * B * T * 2 * d * e);
+    const size_t o_sk = a.take((size_t)c.dec_layers * B * m->tmax * d * e);
+    const size_t o_sv = a.take((size_t)c.dec_layers * B * m->tmax * d * e);
+    const size_t o_xd = a.take(B * d * 4);
+    const size_t o_hd = a.take(B * d * e);
+    const size_t o_qkvd = a.take(B * 3 * d * e);
+    const size_t o_attd = a.take(B * d * e);
+    const size_t o_qd = a.take(B * d * e);
+    const size_t o_ffnd = a.take(B * (size_t)c.ffn * e);
+    const size_t o_logits = a.take(B * (size_t)c.vocab * 4);
+    const size_t o_ints = a.take((size_t)(B * (8 + m->tmax)) * 4);
+    m->arena_bytes = a.off;
+    S2S_HIP_CHECK(hipMalloc(&m->arena, m->arena_bytes));
+    S2S_HIP_CHECK(hipMemset(m->arena, 0, m->arena_bytes));
+    char* base = m->arena;
+    m->y1 = base + o_y1; m->x = (float*)(base + o_x); m->h = base + o_h; m->qkv = base + o_qkv;
+    m->vt = base + o_vt; m->att = base + o_att; m->ffn = base + o_ffn; m->enc_out = base + o_enc;
+    m->cross = base + o_cross; m->self_k = base + o_sk; m->self_v = base + o_sv;
+    m->xd = (float*)(base + o_xd); m->hd = base + o_hd; m->qkvd = base + o_qkvd; m->attd = base + o_attd;
+    m->qd = base + o_qd; m->ffnd = base + o_ffnd; m->logits = (float*)(base + o_logits);
+    int* ints = (int*)(base + o_ints);
+    m->cur_ids = ints; m->pos = ints + B; m->step = ints + 2 * B; m->out_len = ints + 3 * B;
+    m->finished = ints + 4 * B; m->picked = ints + 5 * B; m->n_active = ints + 6 * B; m->out_ids = ints + 7 * B;
+    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, 64, 0));
+    m->finalized = true;
+    return S2S_OK;
+}
+
+static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
+
+static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
+    const auto& c = m->cfg;
+    const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
+    const int M = B * ENC_T;
+    int rc;
+    // conv1 (k3 s1 p1) + GELU -> y1 rows 1..3000 ; conv2 (k3 s2 p1) + GELU + positions -> x
+    GemmArgs g{};
+    g.A = feats; g.lda = c.n_mels; g.a_bs = (long)FEAT_ROWS * c.n_mels;
+    g.W = P(m, "enc.conv1.w"); g.bias = PF(m, "enc.conv1.b");
+    g.C = at(m->y1, (size_t)d * e); g.ldc = d; g.c_bs = (long)FEAT_ROWS * d;
+    g.M = B * 3000; g.N = d; g.K = 3 * c.n_mels; g.G = 3000;
+    g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_GELU;
+    if ((rc = gemm_ex(st, g))) return rc;
+    GemmArgs g2{};
+    g2.A = m->y1; g2.lda = 2L * d; g2.a_bs = (long)FEAT_ROWS * d;
+    g2.W = P(m, "enc.conv2.w"); g2.bias = PF(m, "enc.conv2.b");
+    g2.residual = PF(m, "enc.pos"); g2.ldr = d; g2.r_bs = 0;   // sinusoid table, broadcast over the batch
+    g2.C = m->x; g2.ldc = d; g2.c_bs = (long)ENC_T * d;
+    g2.M = M; g2.N = d; g2.K = 3 * d; g2.G = ENC_T;
+    g2.ab_dtype = dt; g2.c_dtype = S2S_F32; g2.act = S2S_ACT_GELU;
+    if ((rc = gemm_ex(st, g2))) return rc;
+
+    const int Tp = (ENC_T + 63) / 64 * 64;
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < c.enc_layers; ++l) {
+        if ((rc = layernorm(st, m->x, PF(m, lname("enc", l, "ln1.g")), PF(m, lname("enc", l, "ln1.b")), m->h, M, d, 1e-5f, dt))) return rc;
+        if ((rc = gemm(st, m->h, d, P(m, lname("enc", l, "qkv.w")), PF(m, lname("enc", l, "qkv.b")), nullptr, m->qkv, 3 * d, M, 3 * d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
+        if (dt == S2S_BF16 && (D == 64 || D == 128)) {
+            if ((rc = transpose_v(st, at(m->qkv, (size_t)2 * d * e), (long)ENC_T * 3 * d, 3 * d, m->vt, B, H, D, ENC_T, Tp, dt))) return rc;
+            AttnMfmaParams p{};
+            p.Q = (const __hip_bfloat16*)m->qkv; p.q_bs = (long)ENC_T * 3 * d; p.q_rs = 3 * d;
+            p.K = (const __hip_bfloat16*)at(m->qkv, (size_t)d * e); p.k_bs = p.q_bs; p.k_rs = 3 * d;
+            p.Vt = (const __hip_bfloat16*)m->vt;
+            p.O = (__hip_bfloat16*)m->att; p.o_bs = (long)ENC_T * d; p.o_rs = d;
+            p.Tk = ENC_T; p.Tp = Tp; p.Tq = ENC_T; p.H = H; p.B = B;
+            p.scale_log2e = scale * 1.4426950408889634f;
+            if ((rc = attn_mfma(st, p, D))) return rc;
+        } else {
+            AttnRowsParams p{};
+            p.Q = m->qkv; p.q_bs = (long)ENC_T * 3 * d; p.q_rs = 3 * d;
+            p.K = at(m->qkv, (size_t)d * e); p.V = at(m->qkv, (size_t)2 * d * e); p.kv_bs = p.q_bs; p.kv_rs = 3 * d;
+            p.O = m->att; p.o_bs = (long)ENC_T * d; p.o_rs = d;
+            p.kv_len_const = ENC_T; p.B = B; p.H = H; p.Hkv = H; p.Tq = ENC_T; p.D = D; p.scale = scale;
+            if ((rc = attn_rows(st, p, dt))) return rc;
+        }
+        if ((rc = gemm(st, m->att, d, P(m, lname("enc", l, "o.w")), PF(m, lname("enc", l, "o.b")), m->x, m->x, d, M, d, d, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if ((rc = layernorm(st, m->x, PF(m, lname("enc", l, "ln2.g")), PF(m, lname("enc", l, "ln2.b")), m->h, M, d, 1e-5f, dt))) return rc;
+        if ((rc = gemm(st, m->h, d, P(m, lname("enc", l, "fc1.w")), PF(m, lname("enc", l, "fc1.b")), nullptr, m->ffn, c.ffn, M, c.ffn, d, dt, dt, S2S_ACT_GELU, false))) return rc;
+        if ((rc = gemm(st, m->ffn, c.ffn, P(m, lname("enc", l, "fc2.w")), PF(m, lname("enc", l, "fc2.b")), m->x, m->x, d, M, d, c.ffn, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+    }
+    if ((rc = layernorm(st, m->x, PF(m, "enc.ln_post.g"), PF(m, "enc.ln_post.b"), m->enc_out, M, d, 1e-5f, dt))) return rc;
+    // cross-attention K|V of every decoder layer, once per utterance
+    for (int l = 0; l < c.dec_layers; ++l) {
+        void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
+        if ((rc = gemm(st, m->enc_out, d, P(m, lname("dec", l, "ckv.w")), PF(m, lname("dec", l, "ckv.b")), nullptr, ckv, 2 * d, M, 2 * d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
+    }
+    return S2S_OK;
+}
+
+// one decoder step for B sessions: input ids in m->cur_ids, positions in m->pos
+static int decode_step(Whisper* m, hipStream_t st, int B, int kv_len, bool split_ok) {
+    const auto& c = m->cfg;
+    const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
+    const float scale = 1.0f / sqrtf((float)D);
+    int rc;
+    if ((rc = embed(st, m->cur_ids, m->pos, P(m, "dec.tok"), P(m, "dec.pos"), m->xd, B, d, 1.0f, dt))) return rc;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        void* sk = at(m->self_k, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* sv = at(m->self_v, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln1.g")), PF(m, lname("dec", l, "ln1.b")), m->hd, B, d, 1e-5f, dt))) return rc;
+        if ((rc = gemm(st, m->hd, d, P(m, lname("dec", l, "qkv.w")), PF(m, lname("dec", l, "qkv.b")), nullptr, m->qkvd, 3 * d, B, 3 * d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
+        if ((rc = kv_append(st, m->qkvd, 3 * d, d, 2 * d, sk, sv, (long)m->tmax * d, m->pos, B, d, dt))) return rc;
+        AttnRowsParams p{};
+        p.Q = m->qkvd; p.q_bs = 3 * d; p.q_rs = 3 * d;
+        p.K = sk; p.V = sv; p.kv_bs = (long)m->tmax * d; p.kv_rs = d;
+        p.O = m->attd; p.o_bs = d; p.o_rs = d;
+        p.kv_len_const = kv_len; p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
+        if ((rc = attn_rows(st, p, dt))) return rc;
+        if ((rc = gemm(st, m->attd, d, P(m, lname("dec", l, "o.w")), PF(m, lname("dec", l, "o.b")), m->xd, m->xd, d, B, d, d, dt, S2S_F32, S2S_ACT_NONE, split_ok))) return rc;
+        // cross attention
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln2.g")), PF(m, lname("dec", l, "ln2.b")), m->hd, B, d, 1e-5f, dt))) return rc;
+        if ((rc = gemm(st, m->hd, d, P(m, lname("dec", l, "cq.w")), PF(m, lname("dec", l, "cq.b")), nullptr, m->qd, d, B, d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
+        AttnRowsParams pc{};
+        pc.Q = m->qd; pc.q_bs = d; pc.q_rs = d;
+        pc.K = ckv; pc.V = at(ckv, (size_t)d * e); pc.kv_bs = (long)ENC_T * 2 * d; pc.kv_rs = 2 * d;
+        pc.O = m->attd; pc.o_bs = d; pc.o_rs = d;
+        pc.kv_len_const = ENC_T; pc.B = B; pc.H = H; pc.Hkv = H; pc.Tq = 1; pc.D = D; pc.scale = scale;
+        if ((rc = attn_rows(st, pc, dt))) return rc;
+        if ((rc = gemm(st, m->attd, d, P(m, lname("dec", l, "co.w")), PF(m, lname("dec", l, "co.b")), m->xd, m->xd, d, B, d, d, dt, S2S_F32, S2S_ACT_NONE, split_ok))) return rc;
+        // feed-forward
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln3.g")), PF(m, lname("dec", l, "ln3.b")), m->hd, B, d, 1e-5f, dt))) return rc;
+        if ((rc = gemm(st, m->hd, d, P(m, lname("dec", l, "fc1.w")), PF(m, lname("dec", l, "fc1.b")), nullptr, m->ffnd, c.ffn, B, c.ffn, d, dt, dt, S2S_ACT_GELU, false))) return rc;
+        if ((rc = gemm(st, m->ffnd, c.ffn, P(m, lname("dec", l, "fc2.w")), PF(m, lname("dec", l, "fc2.b")), m->xd, m->xd, d, B, d, c.ffn, dt, S2S_F32, S2S_ACT_NONE, split_ok))) return rc;
+    }
+    if ((rc = layernorm(st, m->xd, PF(m, "dec.ln.g"), PF(m, "dec.ln.b"), m->hd, B, d, 1e-5f, dt))) return rc;
+    // logits = h @ tok_emb^T (tied embedding)
+    if ((rc = gemm(st, m->hd, d, P(m, "dec.tok"), nullptr, nullptr, m->logits, c.vocab, B, c.vocab, d, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+    return S2S_OK;
+}
+
+// after a step: route the selected token (or the forced prompt token) to the next step's input,
+// record generated tokens, track EOS.  One thread per session.
+__global__ void whisper_advance_kernel(const int* __restrict__ picked, const int* __restrict__ prompt, int P,
+                                       int step, int B, int eos, int max_new, int* cur_ids, int* pos, int* stepv,
+                                       int* out_ids, int* out_len, int* finished, int* n_active) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    // `step` is the index of the token just consumed; the next input sits at position step+1
+    int next;
+    if (step + 1 < P) {
+        next = prompt[b * P + step + 1];
+        if (next < 0) next = picked[b];   // placeholder: take the (masked) argmax, e.g. the language token
+        if (next != prompt[b * P + step + 1]) out_ids[b * (max_new + P) + max_new + step + 1] = next;  // report the filled-in prompt token
+    } else {
+        next = picked[b];
+        const int n = out_len[b];
+        if (!finished[b]) {
+            if (next == eos) {
+                finished[b] = 1;
+            } else if (n < max_new) {
+                out_ids[b * (max_new + P) + n] = next;
+                out_len[b] = n + 1;
+            }
+        }
+        if (finished[b]) next = eos;
+    }
+    cur_ids[b] = next;
+    pos[b] = step + 1;
+    stepv[b] = step + 1;
+    if (!finished[b]) atomicAdd(n_active, 1);
+}
+
+}  // namespace s2s
+
+using namespace s2s;
+
+extern "C" int32_t s2s_whisper_create(const s2s_whisper_config* cfg, int32_t max_batch, void** out) {
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 64, "whisper_create: bad arguments (max_batch 1..64)");
+    S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "whisper_create: bad dtype");
+    S2S_REQUIRE(cfg->d_model % cfg->n_heads == 0 && cfg->d_model % 8 == 0 && cfg->n_mels % 8 == 0 && cfg->ffn % 8 == 0,
+                "whisper_create: dimensions must be multiples of 8");
+    Whisper* m = new Whisper();
+    m->cfg = *cfg;
+    m->max_batch = max_batch;
+    m->esz = cfg->dtype == S2S_F32 ? 4 : 2;
+    *out = m;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_destroy(void* model) {
+    if (!model) return S2S_OK;
+    Whisper* m = (Whisper*)model;
+    if (m->arena) (void)hipFree(m->arena);
+    if (m->host_flag) (void)hipHostFree(m->host_flag);
+    delete m;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && name && dev_ptr, "whisper_set_tensor: null argument");
+    S2S_REQUIRE(((uintptr_t)dev_ptr & 15) == 0, "whisper_set_tensor: %s is not 16-byte aligned", name);
+    m->w[name] = Tensor{dev_ptr, (long)numel};
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_finalize(void* model) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m, "whisper_finalize: null model");
+    if (m->finalized) return S2S_OK;
+    return finalize(m);
+}
+
+extern "C" int64_t s2s_whisper_workspace_bytes(void* model) {
+    Whisper* m = (Whisper*)model;
+    return m ? (int64_t)m->arena_bytes : 0;
+}
+
+extern "C" int32_t s2s_whisper_encode(void* model, void* stream, const void* feats_dev, int32_t B) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized, "whisper_encode: model not finalized");
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && feats_dev, "whisper_encode: bad batch %d", B);
+    return encode(m, (hipStream_t)stream, feats_dev, B);
+}
+
+extern "C" int32_t s2s_whisper_read_encoder_output(void* model, void* stream, void* dst_dev, int32_t B) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized && dst_dev && B > 0 && B <= m->max_batch, "whisper_read_encoder_output: bad arguments");
+    S2S_HIP_CHECK(hipMemcpyAsync(dst_dev, m->enc_out, (size_t)B * ENC_T * m->cfg.d_model * m->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t B, const int32_t* prompt_dev,
+                                             int32_t P, const uint8_t* suppress_dev, const uint8_t* begin_suppress_dev,
+                                             const uint8_t* prompt_fill_mask_dev, int32_t eos, int32_t max_new_tokens,
+                                             int32_t min_steps, int32_t* out_ids_dev, int32_t* out_len_dev,
+                                             float* last_logits_dev) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized, "whisper_decode: model not finalized");
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && prompt_dev && P >= 1 && out_ids_dev && out_len_dev, "whisper_decode: bad arguments");
+    S2S_REQUIRE(max_new_tokens >= 1 && P + max_new_tokens <= m->tmax, "whisper_decode: P + max_new_tokens = %d exceeds %d target positions", P + max_new_tokens, m->tmax);
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = m->cfg;
+    const int row = max_new_tokens + P;
+    S2S_HIP_CHECK(hipMemsetAsync(m->out_len, 0, sizeof(int) * 2 * m->max_batch, st));   // out_len + finished
+    S2S_HIP_CHECK(hipMemsetAsync(m->out_ids, 0, sizeof(int) * (size_t)B * row, st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->pos, 0, sizeof(int) * 2 * m->max_batch, st));        // pos + step
+    // first input = prompt[:,0]
+    S2S_HIP_CHECK(hipMemcpy2DAsync(m->cur_ids, sizeof(int), prompt_dev, sizeof(int) * P, sizeof(int), B, hipMemcpyDeviceToDevice, st));
+    int* n_active = m->n_active;
+    const int total_steps = P - 1 + max_new_tokens;
+    const bool split_ok = c.dtype == S2S_BF16;
+    for (int s = 0; s < total_steps; ++s) {
+        int rc = decode_step(m, st, B, s + 1, split_ok);
+        if (rc) return rc;
+        const bool in_prompt = s + 1 < P;
+        // prompt placeholders are filled from the argmax restricted by prompt_fill_mask (language detection)
+        const unsigned char* mask = in_prompt ? prompt_fill_mask_dev : suppress_dev;
+        const unsigned char* bmask = (!in_prompt && s == P - 1) ? begin_suppress_dev : nullptr;
+        rc = argmax_suppress(st, m->logits, c.vocab, B, c.vocab, mask, bmask, bmask ? m->step : nullptr, s, m->picked, nullptr);
+        if (rc) return rc;
+        S2S_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), st));
+        whisper_advance_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->picked, prompt_dev, P, s, B, eos, max_new_tokens,
+                                                          m->cur_ids, m->pos, m->step, m->out_ids, m->out_len,
+                                                          m->finished, n_active);
+        S2S_LAUNCH_CHECK();
+        if (last_logits_dev && s == total_steps - 1)
+            S2S_HIP_CHECK(hipMemcpyAsync(last_logits_dev, m->logits, sizeof(float) * (size_t)B * c.vocab, hipMemcpyDeviceToDevice, st));
+        // early exit: poll the active-session count every 8 generated tokens
+        if (!in_prompt && s + 1 >= min_steps && ((s - (P - 1)) & 7) == 7 && s + 1 < total_steps) {
+            S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+            S2S_HIP_CHECK(hipStreamSynchronize(st));
+            if (*m->host_flag == 0) break;
+        }
+    }
+    S2S_HIP_CHECK(hipMemcpyAsync(out_ids_dev, m->out_ids, sizeof(int) * (size_t)B * row, hipMemcpyDeviceToDevice, st));
+    S2S_HIP_CHECK(hipMemcpyAsync(out_len_dev, m->out_len, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    return S2S_OK;
+}

@@ -21,6 +21,13 @@ ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 FRONTEND_WHISPER, FRONTEND_PARAKEET = 0, 1
 
 
+class WhisperConfigStruct(C.Structure):
+    """Mirror of ``s2s_whisper_config``."""
+
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "d_model", "n_heads", "enc_layers", "dec_layers", "ffn", "vocab",
+                                          "max_target", "dtype")]
+
+
 class NativeError(RuntimeError):
     """A libs2s_mi355x call failed (status code + the library's message)."""
 
@@ -42,8 +49,20 @@ _SIGNATURES = {
     "s2s_op_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32],
     "s2s_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
+    "s2s_logmel_whisper_tm": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
+    "s2s_op_conv1d_tm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "s2s_op_attention": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
+                         _i32, _i32, _i32, _vp],
+    "s2s_whisper_create": [_vp, _i32, C.POINTER(_vp)],
+    "s2s_whisper_destroy": [_vp],
+    "s2s_whisper_set_tensor": [_vp, C.c_char_p, _vp, _i64],
+    "s2s_whisper_finalize": [_vp],
+    "s2s_whisper_workspace_bytes": [_vp],
+    "s2s_whisper_encode": [_vp, _vp, _vp, _i32],
+    "s2s_whisper_read_encoder_output": [_vp, _vp, _vp, _i32],
+    "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
-_RESTYPES = {"s2s_last_error": C.c_char_p}
+_RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64}
 
 
 def load():

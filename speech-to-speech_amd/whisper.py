@@ -1,0 +1,174 @@
+"""Host side of the Whisper engine (device graph: csrc/whisper.cpp).
+
+WEIGHT LAYOUT handed to ``s2s_whisper_set_tensor`` (``W`` = model dtype bf16|f32, biases / LayerNorm / the
+encoder position table always float32):
+
+  enc.conv1.w [d][3][n_mels] W   (conv1.weight permuted tap-major)     enc.conv1.b [d]
+  enc.conv2.w [d][3][d]      W                                         enc.conv2.b [d]
+  enc.pos     [1500][d] f32  (fixed sinusoids)                         enc.ln_post.{g,b}
+  enc.L.ln1.{g,b}  enc.L.qkv.w [3d][d] W = q|k|v   enc.L.qkv.b [3d] = qb|0|vb   enc.L.o.{w,b}
+  enc.L.ln2.{g,b}  enc.L.fc1.{w,b}  enc.L.fc2.{w,b}
+  dec.tok [vocab][d] W (also the logits matrix)   dec.pos [448][d] W   dec.ln.{g,b}
+  dec.L.ln1  dec.L.qkv.{w,b}  dec.L.o.{w,b}  dec.L.ln2 (encoder_attn_layer_norm)  dec.L.cq.{w,b}
+  dec.L.ckv.w [2d][d] = k|v   dec.L.ckv.b = 0|vb   dec.L.co.{w,b}   dec.L.ln3 (final_layer_norm)  dec.L.fc1  dec.L.fc2
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Sequence
+
+import numpy as np
+import torch
+
+from . import native
+from .frontend import LogMelFrontend, pack_pcm
+from .synth_weights import WhisperDims
+
+
+def convert_whisper_state_dict(sd: Mapping[str, torch.Tensor], dims: WhisperDims, dtype: torch.dtype) -> dict[str, torch.Tensor]:
+    """transformers-named float32 state dict -> engine tensors (CPU)."""
+    out: dict[str, torch.Tensor] = {}
+    d = dims.d_model
+    W = lambda t: t.to(dtype).contiguous()          # noqa: E731
+    F32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+    e = "model.encoder."
+    out["enc.conv1.w"] = W(sd[e + "conv1.weight"].permute(0, 2, 1))
+    out["enc.conv1.b"] = F32(sd[e + "conv1.bias"])
+    out["enc.conv2.w"] = W(sd[e + "conv2.weight"].permute(0, 2, 1))
+    out["enc.conv2.b"] = F32(sd[e + "conv2.bias"])
+    out["enc.pos"] = F32(sd[e + "embed_positions.weight"])
+    out["enc.ln_post.g"] = F32(sd[e + "layer_norm.weight"])
+    out["enc.ln_post.b"] = F32(sd[e + "layer_norm.bias"])
+
+    def attn_qkv(prefix):
+        w = torch.cat([sd[prefix + "q_proj.weight"], sd[prefix + "k_proj.weight"], sd[prefix + "v_proj.weight"]], 0)
+        b = torch.cat([sd[prefix + "q_proj.bias"], torch.zeros(d), sd[prefix + "v_proj.bias"]], 0)
+        return W(w), F32(b)
+
+    def ln(dst, src):
+        out[dst + ".g"] = F32(sd[src + ".weight"])
+        out[dst + ".b"] = F32(sd[src + ".bias"])
+
+    def lin(dst, src):
+        out[dst + ".w"] = W(sd[src + ".weight"])
+        out[dst + ".b"] = F32(sd[src + ".bias"])
+
+    for l in range(dims.enc_layers):
+        p, q = f"{e}layers.{l}.", f"enc.{l}."
+        ln(q + "ln1", p + "self_attn_layer_norm")
+        out[q + "qkv.w"], out[q + "qkv.b"] = attn_qkv(p + "self_attn.")
+        lin(q + "o", p + "self_attn.out_proj")
+        ln(q + "ln2", p + "final_layer_norm")
+        lin(q + "fc1", p + "fc1")
+        lin(q + "fc2", p + "fc2")
+    dd = "model.decoder."
+    out["dec.tok"] = W(sd[dd + "embed_tokens.weight"])
+    out["dec.pos"] = W(sd[dd + "embed_positions.weight"])
+    ln("dec.ln", dd + "layer_norm")
+    for l in range(dims.dec_layers):
+        p, q = f"{dd}layers.{l}.", f"dec.{l}."
+        ln(q + "ln1", p + "self_attn_layer_norm")
+        out[q + "qkv.w"], out[q + "qkv.b"] = attn_qkv(p + "self_attn.")
+        lin(q + "o", p + "self_attn.out_proj")
+        ln(q + "ln2", p + "encoder_attn_layer_norm")
+        lin(q + "cq", p + "encoder_attn.q_proj")
+        out[q + "ckv.w"] = W(torch.cat([sd[p + "encoder_attn.k_proj.weight"], sd[p + "encoder_attn.v_proj.weight"]], 0))
+        out[q + "ckv.b"] = F32(torch.cat([torch.zeros(d), sd[p + "encoder_attn.v_proj.bias"]], 0))
+        lin(q + "co", p + "encoder_attn.out_proj")
+        ln(q + "ln3", p + "final_layer_norm")
+        lin(q + "fc1", p + "fc1")
+        lin(q + "fc2", p + "fc2")
+    return out
+
+
+class WhisperEngine:
+    """One Whisper replica on one GPU: log-mel front-end + encoder + greedy decoder for batches of sessions."""
+
+    def __init__(self, dims: WhisperDims, state_dict: Mapping[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
+                 max_batch: int = 8, device: str | torch.device = "cuda:0"):
+        self.dims, self.dtype, self.max_batch = dims, dtype, int(max_batch)
+        self.device = torch.device(device)
+        self._lib = native.load()
+        cfg = native.WhisperConfigStruct(dims.n_mels, dims.d_model, dims.n_heads, dims.enc_layers, dims.dec_layers,
+                                         dims.ffn, dims.vocab, dims.max_target, native.dtype_code(dtype))
+        h = C.c_void_p()
+        native.check(self._lib.s2s_whisper_create(C.byref(cfg), self.max_batch, C.byref(h)), "s2s_whisper_create")
+        self._h = h
+        self._weights = {}
+        with torch.cuda.device(self.device):
+            for name, t in convert_whisper_state_dict(state_dict, dims, dtype).items():
+                dt = t.to(self.device)
+                self._weights[name] = dt   # keep alive: the engine holds raw pointers
+                native.check(self._lib.s2s_whisper_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
+            native.check(self._lib.s2s_whisper_finalize(h), "s2s_whisper_finalize")
+        self.frontend = LogMelFrontend("whisper", dims.n_mels, max_batch=self.max_batch, device=self.device)
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.s2s_whisper_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2s_whisper_destroy(self._h)
+            self._h = None
+            self.frontend.close()
+
+    # ---- stages ---------------------------------------------------------------------------
+    def features(self, audios: Sequence[np.ndarray]) -> torch.Tensor:
+        """float32 utterances -> encoder-layout log-mel [B][3002][n_mels] in the model dtype."""
+        pcm, ns = pack_pcm(audios, self.device, max_len=480000)
+        B = len(audios)
+        out = torch.empty((B, 3002, self.dims.n_mels), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_logmel_whisper_tm(self.frontend._handle, native.stream_handle(), native.ptr(pcm),
+                                                         pcm.stride(0), native.ptr(ns), B, native.ptr(out),
+                                                         native.dtype_code(self.dtype)), "s2s_logmel_whisper_tm")
+        return out
+
+    def encode(self, feats_tm: torch.Tensor) -> None:
+        B = feats_tm.shape[0]
+        assert feats_tm.shape[1:] == (3002, self.dims.n_mels) and feats_tm.dtype == self.dtype and feats_tm.is_contiguous()
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_encode(self._h, native.stream_handle(), native.ptr(feats_tm), B), "s2s_whisper_encode")
+        self._B = B
+
+    def encoder_output(self) -> torch.Tensor:
+        out = torch.empty((self._B, 1500, self.dims.d_model), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_read_encoder_output(self._h, native.stream_handle(), native.ptr(out), self._B))
+        return out
+
+    def _mask(self, ids: Sequence[int] | None, invert: bool = False):
+        if ids is None or len(ids) == 0:
+            return None
+        m = torch.ones(self.dims.vocab, dtype=torch.uint8) if invert else torch.zeros(self.dims.vocab, dtype=torch.uint8)
+        m[list(ids)] = 0 if invert else 1
+        return m.to(self.device)
+
+    def decode(self, prompts: Sequence[Sequence[int]], eos: int, max_new_tokens: int, suppress: Sequence[int] | None = None,
+               begin_suppress: Sequence[int] | None = None, lang_ids: Sequence[int] | None = None, min_steps: int = 0,
+               return_logits: bool = False):
+        """Greedy decode of the last encoded batch. -> (ids per session, filled prompts[, last-step logits])."""
+        B, P = len(prompts), len(prompts[0])
+        assert B == self._B
+        pr = torch.tensor(prompts, dtype=torch.int32).to(self.device)
+        out_ids = torch.zeros((B, max_new_tokens + P), dtype=torch.int32, device=self.device)
+        out_len = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        sup, bsup, fill = self._mask(suppress), self._mask(begin_suppress), self._mask(lang_ids, invert=True)
+        logits = torch.empty((B, self.dims.vocab), dtype=torch.float32, device=self.device) if return_logits else None
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_decode_greedy(self._h, native.stream_handle(), B, native.ptr(pr), P,
+                                                             native.ptr(sup), native.ptr(bsup), native.ptr(fill), int(eos),
+                                                             int(max_new_tokens), int(min_steps), native.ptr(out_ids),
+                                                             native.ptr(out_len), native.ptr(logits)), "s2s_whisper_decode_greedy")
+        ids_h, len_h = out_ids.cpu().numpy(), out_len.cpu().numpy()
+        ids = [ids_h[b, : len_h[b]].tolist() for b in range(B)]
+        filled = [[int(ids_h[b, max_new_tokens + i]) if prompts[b][i] < 0 else int(prompts[b][i]) for i in range(P)] for b in range(B)]
+        if return_logits:
+            return ids, filled, logits
+        return ids, filled
+
+    def transcribe_ids(self, audios: Sequence[np.ndarray], prompt: Sequence[int], eos: int, max_new_tokens: int = 128, **kw):
+        self.encode(self.features(audios))
+        return self.decode([list(prompt)] * len(audios), eos, max_new_tokens, **kw)

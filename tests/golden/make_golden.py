@@ -54,7 +54,61 @@ def make_logmel():
     print("logmel.npz written")
 
 
-SECTIONS = {"logmel": make_logmel}
+WHISPER_TEST = dict(eos=319, sot=300, lang_ids=[301, 302, 303, 304], transcribe=305, notimestamps=306,
+                    suppress=[1, 2, 7, 300, 301, 302, 303, 304, 305, 306], begin_suppress=[220, 319], max_new=12,
+                    seed=3, gain=2.0, pos_std=2.0)
+
+
+def make_whisper():
+    """Tiny seeded Whisper through transformers' WhisperForConditionalGeneration (CPU float32):
+    encoder output rows, language-detection ids and greedy token ids for two utterances."""
+    import torch
+    from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperForConditionalGeneration
+
+    from speech_to_speech_amd.synth_weights import WhisperDims, whisper_state_dict
+
+    dims = WhisperDims.test_tiny()
+    t = WHISPER_TEST
+    cfg = WhisperConfig(vocab_size=dims.vocab, num_mel_bins=dims.n_mels, d_model=dims.d_model,
+                        encoder_layers=dims.enc_layers, decoder_layers=dims.dec_layers,
+                        encoder_attention_heads=dims.n_heads, decoder_attention_heads=dims.n_heads,
+                        encoder_ffn_dim=dims.ffn, decoder_ffn_dim=dims.ffn, max_source_positions=1500,
+                        max_target_positions=dims.max_target, pad_token_id=t["eos"], bos_token_id=t["eos"],
+                        eos_token_id=t["eos"], decoder_start_token_id=t["sot"], suppress_tokens=t["suppress"],
+                        begin_suppress_tokens=t["begin_suppress"])
+    torch.manual_seed(0)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    sd = whisper_state_dict(dims, seed=3, gain=2.0, pos_std=2.0)
+    missing, unexpected = model.load_state_dict({**sd, "proj_out.weight": sd["model.decoder.embed_tokens.weight"]}, strict=False)
+    assert not unexpected and all("proj_out" in m for m in missing), (missing, unexpected)
+    gc = model.generation_config
+    gc.lang_to_id = {f"<|l{i}|>": v for i, v in enumerate(t["lang_ids"])}
+    gc.task_to_id = {"transcribe": t["transcribe"]}
+    gc.no_timestamps_token_id = t["notimestamps"]
+    gc.is_multilingual = True
+    gc.suppress_tokens = t["suppress"]
+    gc.begin_suppress_tokens = t["begin_suppress"]
+
+    lens = [48000, 30500]
+    audios = [synth_audio(n, 200 + i) for i, n in enumerate(lens)]
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    feats = torch.from_numpy(fe(audios, sampling_rate=16000, return_tensors="np").input_features)
+    out = {"lens": np.asarray(lens, np.int32)}
+    with torch.no_grad():
+        enc_o = model.get_encoder()(feats)
+        enc = enc_o.last_hidden_state
+        out["enc_rows"] = enc[:, ::60].numpy().astype(np.float32)          # [2, 25, d]
+        out["enc_abs_mean"] = np.float64(enc.abs().mean().item())
+        lang = model.detect_language(encoder_outputs=enc_o, generation_config=gc)
+        out["lang"] = lang.numpy().astype(np.int32)
+        ids = model.generate(feats, generation_config=gc, max_new_tokens=t["max_new"], num_beams=1, do_sample=False,
+                             return_timestamps=False, task="transcribe", language="<|l1|>")
+        out["ids_forced_l1"] = ids.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "whisper_tiny.npz"), **out)
+    print("whisper_tiny.npz written", out["lang"], out["ids_forced_l1"])
+
+
+SECTIONS = {"logmel": make_logmel, "whisper": make_whisper}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)

@@ -1,0 +1,113 @@
+"""GPU parity of the attention / conv-as-GEMM operators against float64 torch references."""
+
+import math
+
+import pytest
+import torch
+
+from speech_to_speech_amd import native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref_attention(q, k, v, H, Hkv, scale, kv_len=None, bias=None, causal=False, window=0):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    D = q.shape[2] // H
+    qh = q.double().view(B, Tq, H, D).transpose(1, 2)
+    kh = k.double().view(B, Tk, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, 1)
+    vh = v.double().view(B, Tk, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, 1)
+    s = (qh * scale) @ kh.transpose(-1, -2)
+    t = torch.arange(Tq)[:, None]
+    j = torch.arange(Tk)[None, :]
+    if bias is not None:
+        idx = (Tk - 1) - t + j
+        s = s + torch.gather(bias.double(), 3, idx.expand(B, H, Tq, Tk))
+    allowed = torch.ones(B, 1, Tq, Tk, dtype=torch.bool)
+    if kv_len is not None:
+        allowed &= (j[None, None] < kv_len.view(B, 1, 1, 1))
+    off = Tk - Tq
+    if causal:
+        allowed &= (j <= t + off)[None, None]
+    if window > 0:
+        allowed &= (j > t + off - window)[None, None]
+    s = s.masked_fill(~allowed, -math.inf)
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, H * D)
+
+
+def _run(q, k, v, H, Hkv, D, scale, kv_len=None, bias=None, causal=0, window=0, use_mfma=0):
+    lib = native.load()
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    o = torch.empty((B, Tq, H * D), dtype=q.dtype, device=DEV)
+    vt = torch.empty(B * H * D * ((Tk + 63) // 64 * 64), dtype=q.dtype, device=DEV) if use_mfma else None
+    native.check(lib.s2s_op_attention(native.stream_handle(), native.ptr(q), q.stride(1), native.ptr(k), native.ptr(v),
+                                      k.stride(1), native.ptr(o), native.ptr(kv_len), native.ptr(bias), B, H, Hkv, Tq, Tk, D,
+                                      scale, causal, window, native.dtype_code(q.dtype), use_mfma, native.ptr(vt)))
+    torch.cuda.synchronize()
+    return o
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,D,causal,window", [
+    (2, 2, 2, 70, 70, 64, 0, 0), (1, 4, 2, 1, 333, 128, 0, 0), (2, 4, 4, 37, 37, 32, 1, 0), (1, 2, 1, 50, 90, 64, 1, 24),
+    (3, 6, 6, 1, 1500, 64, 0, 0)])
+def test_row_attention(dt, B, H, Hkv, Tq, Tk, D, causal, window):
+    g = torch.Generator().manual_seed(B * 100 + Tq + Tk)
+    q = torch.randn(B, Tq, H * D, generator=g).to(dt)
+    k = torch.randn(B, Tk, Hkv * D, generator=g).to(dt)
+    v = torch.randn(B, Tk, Hkv * D, generator=g).to(dt)
+    kv_len = torch.randint(max(1, Tk // 2), Tk + 1, (B,), generator=g).to(torch.int32) if not causal else None
+    scale = D ** -0.5
+    o = _run(q.to(DEV), k.to(DEV), v.to(DEV), H, Hkv, D, scale, kv_len.to(DEV) if kv_len is not None else None, None, causal, window)
+    ref = _ref_attention(q, k, v, H, Hkv, scale, kv_len, None, bool(causal), window)
+    err = (o.double().cpu() - ref).abs().max().item()
+    print(f"row attention {dt} B{B} H{H}/{Hkv} Tq{Tq} Tk{Tk} D{D} causal{causal} w{window}: {err:.3e}")
+    assert err < (2e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("B,H,T,D,with_bias,with_len", [(1, 2, 1500, 64, False, False), (2, 3, 200, 64, False, True),
+                                                        (2, 2, 375, 128, True, True), (1, 8, 125, 128, True, False),
+                                                        (2, 2, 64, 64, False, False), (1, 1, 129, 64, False, False)])
+def test_mfma_attention(B, H, T, D, with_bias, with_len):
+    g = torch.Generator().manual_seed(T + D)
+    # fused QKV rows (stride 3*H*D), the layout the encoders produce
+    qkv = (torch.randn(B, T, 3 * H * D, generator=g) * 1.2).bfloat16().to(DEV)
+    q, k, v = qkv[:, :, : H * D], qkv[:, :, H * D : 2 * H * D], qkv[:, :, 2 * H * D :]
+    bias = (torch.randn(B, H, T, 2 * T - 1, generator=g) * 0.7).to(DEV) if with_bias else None
+    kv_len = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32).to(DEV) if with_len else None
+    scale = D ** -0.5
+    o = _run(q, k, v, H, H, D, scale, kv_len, bias, 0, 0, use_mfma=1)
+    ref = _ref_attention(q.cpu(), k.cpu(), v.cpu(), H, H, scale, kv_len.cpu() if with_len else None,
+                         bias.cpu() if with_bias else None)
+    err = (o.double().cpu() - ref).abs().max().item()
+    o2 = _run(q, k, v, H, H, D, scale, kv_len, bias, 0, 0, use_mfma=0)
+    err2 = (o2.double().cpu() - ref).abs().max().item()
+    print(f"mfma attention B{B} H{H} T{T} D{D} bias{with_bias} len{with_len}: mfma {err:.3e} rows {err2:.3e}")
+    assert err < 3e-2 and err2 < 2e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,Cin,Cout,k,stride", [(2, 300, 80, 128, 3, 1), (2, 300, 128, 64, 3, 2), (1, 97, 16, 24, 7, 1)])
+def test_conv1d_as_gemm(dt, B, T, Cin, Cout, k, stride):
+    lib = native.load()
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(T + Cin)
+    x = torch.randn(B, Cin, T, generator=g).to(dt)
+    w = (torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)).to(dt)
+    b = torch.randn(Cout, generator=g)
+    xp = torch.zeros(B, T + 2 * pad, Cin, dtype=dt)
+    xp[:, pad : pad + T] = x.permute(0, 2, 1)
+    T_out = (T + 2 * pad - k) // stride + 1
+    y = torch.zeros(B, T_out + 2, Cout, dtype=dt, device=DEV)
+    native.check(lib.s2s_op_conv1d_tm(native.stream_handle(), native.ptr(xp.to(DEV)), native.ptr(w.permute(0, 2, 1).contiguous().to(DEV)),
+                                      native.ptr(b.to(DEV)), native.ptr(y), B, T, Cin, Cout, k, stride, pad, T_out + 2, 1,
+                                      native.dtype_code(dt), native.dtype_code(dt), native.ACT_GELU))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=stride, padding=pad)).permute(0, 2, 1)
+    err = (y[:, 1 : 1 + T_out].double().cpu() - ref).abs().max().item()
+    print(f"conv1d {dt} T{T} {Cin}->{Cout} k{k} s{stride}: {err:.3e}")
+    assert err < (2e-5 if dt == torch.float32 else 3e-2)
+    assert torch.all(y[:, 0] == 0) and torch.all(y[:, -1] == 0)
