@@ -102,8 +102,9 @@ def test_conv1d_as_gemm(dt, B, T, Cin, Cout, k, stride):
     xp[:, pad : pad + T] = x.permute(0, 2, 1)
     T_out = (T + 2 * pad - k) // stride + 1
     y = torch.zeros(B, T_out + 2, Cout, dtype=dt, device=DEV)
-    native.check(lib.s2s_op_conv1d_tm(native.stream_handle(), native.ptr(xp.to(DEV)), native.ptr(w.permute(0, 2, 1).contiguous().to(DEV)),
-                                      native.ptr(b.to(DEV)), native.ptr(y), B, T, Cin, Cout, k, stride, pad, T_out + 2, 1,
+    xd, wd, bd = xp.to(DEV), w.permute(0, 2, 1).contiguous().to(DEV), b.to(DEV)   # keep alive across the async launch
+    native.check(lib.s2s_op_conv1d_tm(native.stream_handle(), native.ptr(xd), native.ptr(wd),
+                                      native.ptr(bd), native.ptr(y), B, T, Cin, Cout, k, stride, pad, T_out + 2, 1,
                                       native.dtype_code(dt), native.dtype_code(dt), native.ACT_GELU))
     torch.cuda.synchronize()
     ref = torch.nn.functional.gelu(torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=stride, padding=pad)).permute(0, 2, 1)
