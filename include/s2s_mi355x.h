@@ -49,6 +49,19 @@ int32_t s2s_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails */
 int32_t s2s_device_count(void);
 
+/* Kernel timing for bench.py's roofline line: while a category bit is enabled every launch of that
+ * kernel family is bracketed by HIP events on its own stream; s2s_prof_collect waits for them and
+ * returns (and resets) the summed device time, the algorithmic FLOPs / bytes the launches were
+ * asked to do, and their count. */
+#define S2S_PROF_GEMM_TILE 0   /* bf16/f32 MFMA tile GEMM (encoder projections, conv stems) */
+#define S2S_PROF_GEMM_SKINNY 1 /* weight-streaming decode GEMM (M <= 64) */
+#define S2S_PROF_ATTN_MFMA 2   /* flash attention */
+#define S2S_PROF_ATTN_ROWS 3   /* decode / parity attention */
+#define S2S_PROF_LOGMEL 4
+#define S2S_PROF_NCAT 8
+int32_t s2s_prof_enable(uint32_t category_mask);
+int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches);
+
 /* ------------------------------------------------------------------------- *
  * Log-mel front-ends.
  *   Whisper : replaces WhisperSTTHandler.prepare_model_inputs

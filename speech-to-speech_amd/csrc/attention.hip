@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
 template <typename T>
 static int launch_attn_rows(hipStream_t st, const AttnRowsParams& p) {
     dim3 grid(cdiv(p.Tq, 4), p.H, p.B);
+    ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.Tq * p.kv_len_const * p.D,
+                   (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_len_const * p.D * 2 + (double)p.H * p.Tq * p.D * 2));
     const size_t lds = sizeof(float) * 4 * (size_t)(p.D + p.kv_len_const + 8);
     S2S_REQUIRE(lds <= 160 * 1024, "attention: kv length %d too long for the row kernel", p.kv_len_const);
 #define S2S_ROWS(DV)                                                                                     \
@@ -385,6 +387,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
 int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
     S2S_REQUIRE(p.Tp % 64 == 0 && p.Tp >= p.Tk, "attention: Tp=%d must be a multiple of 64 and >= Tk=%d", p.Tp, p.Tk);
     dim3 grid(cdiv(p.Tq, 128), p.H, p.B);
+    ProfScope prof(st, S2S_PROF_ATTN_MFMA, 4.0 * p.B * p.H * (double)p.Tq * p.Tk * D,
+                   2.0 * p.B * p.H * ((double)p.Tq * D * 2 + (double)p.Tk * D * 2));
     if (D == 64) attn_mfma_kernel<64><<<grid, 256, 0, st>>>(p);
     else if (D == 128) attn_mfma_kernel<128><<<grid, 256, 0, st>>>(p);
     else return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);

@@ -42,6 +42,20 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::s2s::fail(S2S_ERR_ARG, __VA_ARGS__);                  \
     } while (0)
 
+// Optional per-kernel timing with HIP events on the launching stream (s2s_prof_enable / _collect).
+class ProfScope {
+  public:
+    ProfScope(hipStream_t st, int cat, double flops, double bytes);
+    ~ProfScope();
+
+  private:
+    hipStream_t st_;
+    int cat_;
+    bool on_;
+    void* start_ = nullptr;
+    void* stop_ = nullptr;
+};
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers --------------------------------------------------------

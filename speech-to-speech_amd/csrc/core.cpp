@@ -3,6 +3,10 @@
 
 #include <stdarg.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace s2s {
 
 static thread_local std::string g_last_error;
@@ -19,7 +23,73 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- in-library kernel timing (HIP events on the launching stream) -----------------------
+struct ProfCat {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    double flops = 0, bytes = 0;
+};
+static ProfCat g_prof[S2S_PROF_NCAT];
+static unsigned g_prof_mask = 0;
+static std::vector<hipEvent_t> g_event_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t take_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(hipStream_t st, int cat, double flops, double bytes) : st_(st), cat_(cat), on_(false) {
+    if (!(g_prof_mask & (1u << cat))) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    on_ = true;
+    start_ = take_event();
+    stop_ = take_event();
+    g_prof[cat].flops += flops;
+    g_prof[cat].bytes += bytes;
+    (void)hipEventRecord((hipEvent_t)start_, st);
+}
+ProfScope::~ProfScope() {
+    if (!on_) return;
+    (void)hipEventRecord((hipEvent_t)stop_, st_);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[cat_].spans.emplace_back((hipEvent_t)start_, (hipEvent_t)stop_);
+}
+
 }  // namespace s2s
+
+extern "C" int32_t s2s_prof_enable(uint32_t category_mask) {
+    std::lock_guard<std::mutex> lk(s2s::g_prof_mu);
+    s2s::g_prof_mask = category_mask;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches) {
+    S2S_REQUIRE(category >= 0 && category < S2S_PROF_NCAT, "prof_collect: bad category %d", category);
+    std::lock_guard<std::mutex> lk(s2s::g_prof_mu);
+    s2s::ProfCat& c = s2s::g_prof[category];
+    double ms = 0;
+    for (auto& sp : c.spans) {
+        S2S_HIP_CHECK(hipEventSynchronize(sp.second));
+        float t = 0;
+        S2S_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
+        ms += t;
+        s2s::g_event_pool.push_back(sp.first);
+        s2s::g_event_pool.push_back(sp.second);
+    }
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = c.flops;
+    if (bytes) *bytes = c.bytes;
+    if (launches) *launches = (int64_t)c.spans.size();
+    c.spans.clear();
+    c.flops = c.bytes = 0;
+    return S2S_OK;
+}
 
 extern "C" const char* s2s_last_error(void) { return s2s::g_last_error.c_str(); }
 extern "C" int32_t s2s_abi_version(void) { return S2S_ABI_VERSION; }

@@ -315,6 +315,8 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             if (e != hipSuccess) return fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(e));
         }
         dim3 grid(ntiles * ksplit);
+        ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K,
+                       (double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT));
 #define S2S_SKINNY(MTV)                                                                          \
     gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
                                                          g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
@@ -328,6 +330,8 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SKINNY
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+        ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K,
+                       (double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT));
         gemm_tile_kernel<T, CT><<<tiles_m * tiles_n, 256, 0, st>>>(
             (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
             tiles_m, rm);

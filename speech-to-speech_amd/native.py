@@ -42,6 +42,8 @@ _SIGNATURES = {
     "s2s_last_error": [],
     "s2s_abi_version": [],
     "s2s_device_count": [],
+    "s2s_prof_enable": [C.c_uint32],
+    "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],
     "s2s_frontend_destroy": [_vp],
     "s2s_logmel_whisper": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
@@ -99,6 +101,22 @@ def declared_symbols() -> list[str]:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(s2s_[a-z0-9_]+)\s*\(", text)))
+
+
+PROF_GEMM_TILE, PROF_GEMM_SKINNY, PROF_ATTN_MFMA, PROF_ATTN_ROWS, PROF_LOGMEL = 0, 1, 2, 3, 4
+
+
+def prof_enable(*categories: int) -> None:
+    mask = 0
+    for c in categories:
+        mask |= 1 << c
+    check(load().s2s_prof_enable(mask), "s2s_prof_enable")
+
+
+def prof_collect(category: int) -> dict:
+    ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), _i64()
+    check(load().s2s_prof_collect(category, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "s2s_prof_collect")
+    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
 
 
 def check(status: int, what: str = "") -> None:

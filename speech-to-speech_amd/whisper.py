@@ -82,11 +82,49 @@ def convert_whisper_state_dict(sd: Mapping[str, torch.Tensor], dims: WhisperDims
     return out
 
 
+def random_engine_tensors(dims: WhisperDims, dtype: torch.dtype, device: torch.device, seed: int = 0) -> dict[str, torch.Tensor]:
+    """Random-init weights generated directly on the GPU in the engine layout (bench: no checkpoints offline)."""
+    from .synth_weights import sinusoids
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    d, f = dims.d_model, dims.ffn
+    out: dict[str, torch.Tensor] = {}
+
+    def w(name, rows, cols, std=None):
+        out[name] = (torch.randn((rows, cols), generator=g, device=device, dtype=torch.float32) * (std or cols ** -0.5)).to(dtype)
+
+    def b(name, n, std=0.02):
+        out[name] = torch.randn((n,), generator=g, device=device, dtype=torch.float32) * std
+
+    def ln(name):
+        out[name + ".g"] = 1.0 + 0.05 * torch.randn((d,), generator=g, device=device)
+        out[name + ".b"] = 0.02 * torch.randn((d,), generator=g, device=device)
+
+    w("enc.conv1.w", d, 3 * dims.n_mels); b("enc.conv1.b", d)
+    w("enc.conv2.w", d, 3 * d); b("enc.conv2.b", d)
+    out["enc.pos"] = sinusoids(dims.max_source, d).to(device)
+    ln("enc.ln_post")
+    for l in range(dims.enc_layers):
+        q = f"enc.{l}."
+        ln(q + "ln1"); w(q + "qkv.w", 3 * d, d); b(q + "qkv.b", 3 * d); w(q + "o.w", d, d); b(q + "o.b", d)
+        ln(q + "ln2"); w(q + "fc1.w", f, d); b(q + "fc1.b", f); w(q + "fc2.w", d, f); b(q + "fc2.b", d)
+    w("dec.tok", dims.vocab, d, 0.3); w("dec.pos", dims.max_target, d, 0.3); ln("dec.ln")
+    for l in range(dims.dec_layers):
+        q = f"dec.{l}."
+        ln(q + "ln1"); w(q + "qkv.w", 3 * d, d); b(q + "qkv.b", 3 * d); w(q + "o.w", d, d); b(q + "o.b", d)
+        ln(q + "ln2"); w(q + "cq.w", d, d); b(q + "cq.b", d); w(q + "ckv.w", 2 * d, d); b(q + "ckv.b", 2 * d)
+        w(q + "co.w", d, d); b(q + "co.b", d)
+        ln(q + "ln3"); w(q + "fc1.w", f, d); b(q + "fc1.b", f); w(q + "fc2.w", d, f); b(q + "fc2.b", d)
+    return out
+
+
 class WhisperEngine:
     """One Whisper replica on one GPU: log-mel front-end + encoder + greedy decoder for batches of sessions."""
 
-    def __init__(self, dims: WhisperDims, state_dict: Mapping[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
-                 max_batch: int = 8, device: str | torch.device = "cuda:0"):
+    def __init__(self, dims: WhisperDims, state_dict: Mapping[str, torch.Tensor] | None, dtype: torch.dtype = torch.bfloat16,
+                 max_batch: int = 8, device: str | torch.device = "cuda:0", engine_tensors: Mapping[str, torch.Tensor] | None = None):
+        """state_dict: transformers-named float32 tensors (converted here), or engine_tensors: already in the
+        engine layout on the device (see random_engine_tensors)."""
         self.dims, self.dtype, self.max_batch = dims, dtype, int(max_batch)
         self.device = torch.device(device)
         self._lib = native.load()
@@ -97,12 +135,19 @@ class WhisperEngine:
         self._h = h
         self._weights = {}
         with torch.cuda.device(self.device):
-            for name, t in convert_whisper_state_dict(state_dict, dims, dtype).items():
+            tensors = engine_tensors if engine_tensors is not None else convert_whisper_state_dict(state_dict, dims, dtype)
+            for name, t in tensors.items():
                 dt = t.to(self.device)
                 self._weights[name] = dt   # keep alive: the engine holds raw pointers
                 native.check(self._lib.s2s_whisper_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
             native.check(self._lib.s2s_whisper_finalize(h), "s2s_whisper_finalize")
         self.frontend = LogMelFrontend("whisper", dims.n_mels, max_batch=self.max_batch, device=self.device)
+
+    @classmethod
+    def from_random(cls, dims: WhisperDims, dtype: torch.dtype = torch.bfloat16, max_batch: int = 8,
+                    device: str | torch.device = "cuda:0", seed: int = 0) -> "WhisperEngine":
+        dev = torch.device(device)
+        return cls(dims, None, dtype, max_batch, dev, engine_tensors=random_engine_tensors(dims, dtype, dev, seed))
 
     @property
     def workspace_bytes(self) -> int:

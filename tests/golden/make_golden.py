@@ -108,7 +108,48 @@ def make_whisper():
     print("whisper_tiny.npz written", out["lang"], out["ids_forced_l1"])
 
 
-SECTIONS = {"logmel": make_logmel, "whisper": make_whisper}
+def make_parakeet():
+    """Tiny seeded Parakeet-TDT through transformers' ParakeetForTDT (CPU float32): encoder rows, greedy TDT tokens + durations."""
+    import torch
+    from transformers import ParakeetForTDT, ParakeetTDTConfig
+    from transformers.models.parakeet.configuration_parakeet import ParakeetEncoderConfig
+
+    from oracle import logmel as OL   # features via the (already pinned) oracle: the HF extractor needs librosa
+    from speech_to_speech_amd.synth_weights import ParakeetDims, parakeet_state_dict
+
+    out = {}
+    dims = ParakeetDims.test_tiny()
+    for tag, seed, gain in (("a", 12, 1.5), ("b", 11, 1.5), ("stuck", 13, 2.0)):
+        sd = parakeet_state_dict(dims, seed=seed, gain=gain)
+        enc = ParakeetEncoderConfig(hidden_size=dims.d_model, num_hidden_layers=dims.layers, num_attention_heads=dims.n_heads,
+                                    intermediate_size=dims.ffn, num_mel_bins=dims.n_mels, subsampling_conv_channels=dims.sub_channels)
+        cfg = ParakeetTDTConfig(vocab_size=dims.vocab, decoder_hidden_size=dims.dec_hidden, num_decoder_layers=dims.dec_layers,
+                                blank_token_id=dims.blank, encoder_config=enc, pad_token_id=2)
+        m = ParakeetForTDT(cfg).eval()
+        sdl = dict(sd)
+        for l in range(dims.layers):
+            sdl[f"encoder.layers.{l}.conv.norm.num_batches_tracked"] = torch.tensor(0)
+        m.load_state_dict(sdl, strict=True)
+        lens = [48000, 30500]
+        audios = [synth_audio(n, 300 + i) for i, n in enumerate(lens)]
+        tmax = max(lens) // 160 + 1
+        feats = torch.from_numpy(np.stack([OL.parakeet_logmel(a, 128, t_total=tmax)[0] for a in audios]).astype(np.float32))
+        flen = torch.tensor([n // 160 for n in lens])
+        amask = torch.arange(tmax)[None, :] < flen[:, None]
+        m.generation_config.decoder_start_token_id = dims.blank
+        with torch.no_grad():
+            eo = m.get_audio_features(input_features=feats, attention_mask=amask)
+            g = m.generate(input_features=feats, attention_mask=amask, return_dict_in_generate=True)
+        out[f"{tag}_enc"] = eo.last_hidden_state.numpy()[:, ::3].astype(np.float32)
+        out[f"{tag}_enc_len"] = eo.attention_mask.sum(-1).numpy().astype(np.int32)
+        out[f"{tag}_seq"] = g.sequences.numpy().astype(np.int32)
+        out[f"{tag}_dur"] = g.durations.numpy().astype(np.int32)
+    out["lens"] = np.asarray(lens, np.int32)
+    np.savez_compressed(os.path.join(HERE, "parakeet_tiny.npz"), **out)
+    print("parakeet_tiny.npz written", {k: v.shape for k, v in out.items()})
+
+
+SECTIONS = {"logmel": make_logmel, "whisper": make_whisper, "parakeet": make_parakeet}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)
