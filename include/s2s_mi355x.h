@@ -196,6 +196,50 @@ int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t B, const in
                                   int32_t min_steps, int32_t* out_ids_dev, int32_t* out_len_dev,
                                   float* last_logits_dev);
 
+/* ------------------------------------------------------------------------- *
+ * Parakeet-TDT (FastConformer encoder + TDT greedy decode) for one batch of sessions.
+ *   Replaces nano_parakeet's model.transcribe(audio[, timestamps=True]) as called by
+ *   ParakeetTDTSTTHandler._process_nano_parakeet (STT/parakeet_tdt_handler.py:621-623) and
+ *   SmartProgressiveStreamingHandler._decode_window (STT/smart_progressive_streaming.py:82-85).
+ *   nano-parakeet (>=0.2.0) is not available offline; the arithmetic is restated from
+ *   transformers/models/parakeet/modeling_parakeet.py and generation_parakeet.py:113-122,271-294.
+ * ------------------------------------------------------------------------- */
+typedef struct s2s_parakeet_config {
+    int32_t n_mels;          /* 128 */
+    int32_t d_model;         /* 1024 */
+    int32_t n_heads;         /* 8 */
+    int32_t layers;          /* 24 */
+    int32_t ffn;             /* 4096 */
+    int32_t sub_channels;    /* 256 */
+    int32_t conv_kernel;     /* 9 */
+    int32_t vocab;           /* 8193 incl. blank (= vocab-1) */
+    int32_t dec_hidden;      /* 640 */
+    int32_t dec_layers;      /* 2 */
+    int32_t n_durations;     /* 5: {0,1,2,3,4} */
+    int32_t max_feat_frames; /* longest utterance in 10 ms feature frames (3001 = 30 s) */
+    int32_t dtype;           /* S2S_BF16 or S2S_F32 */
+} s2s_parakeet_config;
+
+int32_t s2s_parakeet_create(const s2s_parakeet_config* cfg, int32_t max_batch, void** out_model);
+int32_t s2s_parakeet_destroy(void* model);
+/* encoder frames for max_feat_frames: the relative-position tables "enc.L.R" have 2*this-1 rows */
+int32_t s2s_parakeet_max_encoder_frames(void* model);
+/* names / layouts: speech-to-speech_amd/parakeet.py (WEIGHT LAYOUT) */
+int32_t s2s_parakeet_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel);
+int32_t s2s_parakeet_finalize(void* model);
+int64_t s2s_parakeet_workspace_bytes(void* model);
+/* feats_dev: [B][T][n_mels] model dtype, zero beyond each row's n_frames_dev[b] valid frames
+ * (the output of s2s_logmel_parakeet with t_max = T). */
+int32_t s2s_parakeet_encode(void* model, void* stream, const void* feats_dev, const int32_t* n_frames_dev,
+                            int32_t B, int32_t T);
+/* encoder output of the last encode as f32 [B][T'][d_model] (+ optional valid lengths int32 [B]) */
+int32_t s2s_parakeet_read_encoder_output(void* model, void* stream, float* dst_dev, int32_t* enc_len_dev);
+/* TDT greedy decode of the last encoded batch.  max_steps <= 0 selects the reference bound
+ * (10 * T' - 1).  Outputs are int32 [B][max_steps] (steps incl. blank emissions: token id, predicted
+ * duration, encoder frame at which the step was taken) and n_steps_dev int32 [B]. */
+int32_t s2s_parakeet_tdt_greedy(void* model, void* stream, int32_t max_steps, int32_t* tokens_dev,
+                                int32_t* durations_dev, int32_t* frames_dev, int32_t* n_steps_dev);
+
 #ifdef __cplusplus
 }
 #endif

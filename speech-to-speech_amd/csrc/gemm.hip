@@ -63,6 +63,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 struct RowMap {
     long a_bs, c_bs, r_bs, ldr;
     int G;
+    long ldw;                       // row stride of W (elements)
+    int nz2;                        // blockIdx.y = z1 * nz2 + z2: batched GEMMs (e.g. one per (session, head))
+    long a_z1, a_z2, w_z1, w_z2, c_z1, c_z2;
+    float alpha;                    // C = act(acc + bias) * alpha + residual
 };
 
 template <typename T, typename CT>
@@ -75,6 +79,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
     unsigned char* sA = lds;
     unsigned char* sW = lds + TILE_BYTES;
 
+    {
+        const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
+        A += z1 * rm.a_z1 + z2 * rm.a_z2;
+        W += z1 * rm.w_z1 + z2 * rm.w_z2;
+        C += z1 * rm.c_z1 + z2 * rm.c_z2;
+        if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
+    }
     const int nwg = gridDim.x;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tm = wg % tiles_m, tn = wg / tiles_m;   // M fastest: neighbours share the W band
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
         arow[i] = nullptr;
         wrow[i] = nullptr;
         if (m < M) arow[i] = A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda + ch * EPC;
-        if (n < N) wrow[i] = W + (long)n * K + ch * EPC;
+        if (n < N) wrow[i] = W + (long)n * rm.ldw + ch * EPC;
     }
     auto load_tile = [&](int k0) {
 #pragma unroll
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                 const int m = m0 + wm + i * 16 + lg * 4 + r;
                 if (m >= M) continue;
                 const int mb = m / rm.G, mr = m % rm.G;
-                float v = apply_act(acc[i][j][r] + bv, act);
+                float v = apply_act(acc[i][j][r] + bv, act) * rm.alpha;
                 if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
                 Elem<CT>::st(C + (long)mb * rm.c_bs + (long)mr * ldc + n, v);
             }
@@ -207,6 +218,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int ksplit, int kslice,
     RowMap rm) {
     constexpr int KPF = MfmaTraits<T>::KPF;
+    {
+        const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
+        A += z1 * rm.a_z1 + z2 * rm.a_z2;
+        W += z1 * rm.w_z1 + z2 * rm.w_z2;
+        C += z1 * rm.c_z1 + z2 * rm.c_z2;
+        if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
+    }
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int nb = blockIdx.x / ksplit, ks = blockIdx.x - nb * ksplit;
     const int n = (nb * 4 + (threadIdx.x >> 6)) * 16 + l15;
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const bool nvalid = n < N;
-    const T* wrow = W + (long)(nvalid ? n : 0) * K;
+    const T* wrow = W + (long)(nvalid ? n : 0) * rm.ldw;
     const T* arow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -276,12 +294,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
             const int mb = m / rm.G, mr = m % rm.G;
             CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + n;
             if (ksplit == 1) {
-                float v = apply_act(acc[i][r] + bv, act);
+                float v = apply_act(acc[i][r] + bv, act) * rm.alpha;
                 if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
                 Elem<CT>::st(cp, v);
             } else {
                 // split-K: C (f32) already holds the residual; partial sums are added onto it
-                atomicAdd(reinterpret_cast<float*>(cp), acc[i][r] + bv);
+                atomicAdd(reinterpret_cast<float*>(cp), (acc[i][r] + bv) * rm.alpha);
             }
         }
 }
@@ -294,6 +312,12 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     rm.c_bs = g.c_bs;
     rm.r_bs = g.r_bs;
     rm.ldr = g.ldr > 0 ? g.ldr : g.ldc;
+    rm.ldw = g.ldw > 0 ? g.ldw : g.K;
+    const int nz1 = g.nz1 > 0 ? g.nz1 : 1;
+    rm.nz2 = g.nz2 > 0 ? g.nz2 : 1;
+    const int nz = nz1 * rm.nz2;
+    rm.a_z1 = g.a_z1; rm.a_z2 = g.a_z2; rm.w_z1 = g.w_z1; rm.w_z2 = g.w_z2; rm.c_z1 = g.c_z1; rm.c_z2 = g.c_z2;
+    rm.alpha = g.alpha_set ? g.alpha : 1.0f;
     const int M = g.M, N = g.N, K = g.K;
     if (M <= 64) {
         const int MT = cdiv(M, 16);
@@ -302,7 +326,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         // split K only where partial sums can be combined by plain addition onto C
         const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
         const bool can_split = g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 &&
-                               (g.residual == nullptr || in_place) && rm.G == M;
+                               (g.residual == nullptr || in_place) && rm.G == M && nz == 1;
         constexpr int KQ = sizeof(T) == 2 ? 128 : 32;   // K consumed per loop trip
         if (can_split) {
             while (ntiles * ksplit < 256 && K / (ksplit * 2) >= 2 * KQ) ksplit *= 2;
@@ -314,9 +338,9 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             hipError_t e = hipMemset2DAsync(g.C, g.ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
             if (e != hipSuccess) return fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(e));
         }
-        dim3 grid(ntiles * ksplit);
-        ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K,
-                       (double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT));
+        dim3 grid(ntiles * ksplit, nz);
+        ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz,
+                       ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
 #define S2S_SKINNY(MTV)                                                                          \
     gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
                                                          g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
@@ -330,9 +354,9 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SKINNY
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-        ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K,
-                       (double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT));
-        gemm_tile_kernel<T, CT><<<tiles_m * tiles_n, 256, 0, st>>>(
+        ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
+                       ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+        gemm_tile_kernel<T, CT><<<dim3(tiles_m * tiles_n, nz), 256, 0, st>>>(
             (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
             tiles_m, rm);
     }
@@ -348,6 +372,8 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
     S2S_REQUIRE(g.K % epc == 0 && g.lda % epc == 0 && g.a_bs % epc == 0,
                 "gemm: K=%d / lda=%ld / a_bs=%ld must be multiples of %d", g.K, g.lda, g.a_bs, epc);
     S2S_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    S2S_REQUIRE(g.ldw % epc == 0 && g.a_z1 % epc == 0 && g.a_z2 % epc == 0 && g.w_z1 % epc == 0 && g.w_z2 % epc == 0,
+                "gemm: ldw / batch strides must be multiples of %d elements", epc);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_F32) return launch_gemm<__hip_bfloat16, float>(st, g);
     if (g.ab_dtype == S2S_F32 && g.c_dtype == S2S_F32) return launch_gemm<float, float>(st, g);

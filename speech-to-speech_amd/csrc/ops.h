@@ -12,6 +12,10 @@ struct GemmArgs {
     int M, N, K, G;                              // G rows per group (<=0: one group of M rows)
     int ab_dtype, c_dtype, act;
     bool allow_splitk;
+    long ldw;                                    // row stride of W (0 -> K)
+    int nz1, nz2;                                // batched: grid.y = nz1*nz2 independent GEMMs (0 -> 1)
+    long a_z1, a_z2, w_z1, w_z2, c_z1, c_z2;     // per-batch element offsets (C strides also apply to residual)
+    float alpha; bool alpha_set;                 // C = act(acc+bias)*alpha + residual (alpha_set false -> 1)
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
@@ -57,5 +61,30 @@ int kv_append(hipStream_t st, const void* src, long src_rs, int k_off, int v_off
 int argmax_suppress(hipStream_t st, const float* logits, long ld, int B, int V, const unsigned char* mask,
                     const unsigned char* begin_mask, const int* step, int begin_step, int* out, float* out_val);
 int cast_f32(hipStream_t st, const float* in, void* out, long n, int dtype);
+
+// conformer.hip
+struct TdtState {
+    int* frame;      // [B] encoder frame pointer
+    int* finished;   // [B]
+    int* tok;        // [B] token chosen at the last step (input of the prediction network)
+    int* adv;        // [B] 1 = prediction network must advance for this row (non-blank emission)
+    int* n_steps;    // [B] steps recorded
+    int* n_active;   // [1]
+};
+int sub_conv1(hipStream_t st, const void* x, const float* w, const float* b, void* out, const int* len_in, int B, int Tin,
+              int F, int C, int dtype);
+int dwconv2d(hipStream_t st, const void* in, const float* w, const float* b, void* out, const int* len0, int halvings, int B,
+             int Tin, int Fin, int C, int dtype);
+int mask_rows(hipStream_t st, void* x, const int* len0, int halvings, int B, int Trows, long row_elems, int dtype);
+int sub_lengths(hipStream_t st, const int* len0, int halvings, int* out, int B);
+int glu_dwconv(hipStream_t st, const void* y, const float* w, const float* b, void* out, const int* len, int B, int Tn, int d,
+               int ksize, int dtype);
+int add_rowvec(hipStream_t st, const void* in, long ld_in, const float* vec, void* out, long rows, int cols, int dtype);
+int tdt_joint_in(hipStream_t st, const float* encp, const float* dec, const int* frame, void* A, int B, int Tn, int Hd, int dtype);
+int tdt_select(hipStream_t st, const float* logits, int ld, int V, int ND, int blank, const int* enc_len, const TdtState& s,
+               int* out_tok, int* out_dur, int* out_frame, int max_steps, int B);
+int lstm_in(hipStream_t st, const void* emb, const int* tok, const float* xin, const float* h, void* X, int B, int Hd, int dtype);
+int lstm_cell(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd);
+int tdt_commit(hipStream_t st, float* const* dst, const float* const* src, int n_arrays, const int* adv, int force, int B, int Hd);
 
 }  // namespace s2s

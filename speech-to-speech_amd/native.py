@@ -28,6 +28,13 @@ class WhisperConfigStruct(C.Structure):
                                           "max_target", "dtype")]
 
 
+class ParakeetConfigStruct(C.Structure):
+    """Mirror of ``s2s_parakeet_config``."""
+
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "d_model", "n_heads", "layers", "ffn", "sub_channels", "conv_kernel",
+                                          "vocab", "dec_hidden", "dec_layers", "n_durations", "max_feat_frames", "dtype")]
+
+
 class NativeError(RuntimeError):
     """A libs2s_mi355x call failed (status code + the library's message)."""
 
@@ -62,9 +69,19 @@ _SIGNATURES = {
     "s2s_whisper_workspace_bytes": [_vp],
     "s2s_whisper_encode": [_vp, _vp, _vp, _i32],
     "s2s_whisper_read_encoder_output": [_vp, _vp, _vp, _i32],
+    "s2s_parakeet_create": [_vp, _i32, C.POINTER(_vp)],
+    "s2s_parakeet_destroy": [_vp],
+    "s2s_parakeet_max_encoder_frames": [_vp],
+    "s2s_parakeet_set_tensor": [_vp, C.c_char_p, _vp, _i64],
+    "s2s_parakeet_finalize": [_vp],
+    "s2s_parakeet_workspace_bytes": [_vp],
+    "s2s_parakeet_encode": [_vp, _vp, _vp, _vp, _i32, _i32],
+    "s2s_parakeet_read_encoder_output": [_vp, _vp, _vp, _vp],
+    "s2s_parakeet_tdt_greedy": [_vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
-_RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64}
+_RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
+             "s2s_parakeet_workspace_bytes": C.c_int64}
 
 
 def load():

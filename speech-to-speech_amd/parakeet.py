@@ -1,0 +1,184 @@
+"""Host side of the Parakeet-TDT engine (device graph: csrc/parakeet.cpp, kernels csrc/conformer.hip).
+
+WEIGHT LAYOUT handed to ``s2s_parakeet_set_tensor`` (``W`` = model dtype; everything else float32):
+
+  sub.conv1.{w [C][9], b}   sub.dw2.{w [C][9], b}  sub.pw2.{w [C][C] W, b}  sub.dw3.*  sub.pw3.*
+  sub.lin.w [d][F/8 * C] W  columns re-ordered to the channels-last flatten (f*C + c) and multiplied by
+                            sqrt(d) when scale_input (exact: powers of two for d = 1024 / 256); sub.lin.b likewise
+  enc.L.ln_{ff1,att,conv,ff2,out}.{g,b}
+  enc.L.ff{1,2}.fc1.{w,b}  enc.L.ff{1,2}.fc2.{w,b}
+  enc.L.qkv.w [3d][d] W = q|k|v     enc.L.qkv.b = (q_bias + bias_u)|k_bias|v_bias
+  enc.L.vmu  [d] = bias_v - bias_u  (q+u is what the projection produces; q+v = that + vmu)
+  enc.L.R    [2*Tm-1][d] W = relative_k_proj(sinusoid table for Tm frames) * head_dim**-0.5
+  enc.L.o.{w,b}  enc.L.pw1.{w [2d][d], b}  enc.L.dw.{w [d][9], b} with eval-mode BatchNorm folded in  enc.L.pw2.{w,b}
+  dec.encp.{w,b}  dec.emb [V][Hd] W  dec.lstm.L.w [4Hd][2Hd] W = W_ih|W_hh  dec.lstm.L.b = b_ih + b_hh
+  dec.dproj.{w,b}  dec.joint.{w [V+5][Hd] W, b}
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Mapping, Sequence
+
+import numpy as np
+import torch
+
+from . import native
+from .frontend import LogMelFrontend, pack_pcm
+from .synth_weights import ParakeetDims
+
+
+def _half_up(n: int) -> int:
+    return (n - 1) // 2 + 1
+
+
+def encoder_frames(feat_frames: int) -> int:
+    return _half_up(_half_up(_half_up(feat_frames)))
+
+
+def rel_pos_table(T: int, d: int) -> torch.Tensor:
+    """[2T-1, d] interleaved sin/cos of relative positions T-1 .. -(T-1)."""
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    pos = torch.arange(T - 1, -T, -1, dtype=torch.float32)
+    fr = pos[:, None] * inv[None, :]
+    return torch.stack([fr.sin(), fr.cos()], dim=-1).reshape(2 * T - 1, d)
+
+
+def convert_parakeet_state_dict(sd: Mapping[str, torch.Tensor], dims: ParakeetDims, dtype: torch.dtype, tm_enc: int) -> dict[str, torch.Tensor]:
+    out: dict[str, torch.Tensor] = {}
+    d, C = dims.d_model, dims.sub_channels
+    D = d // dims.n_heads
+    F3 = dims.n_mels // 8
+    W = lambda t: t.to(dtype).contiguous()            # noqa: E731
+    F32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+    s = "encoder.subsampling."
+    out["sub.conv1.w"] = F32(sd[s + "layers.0.weight"].reshape(C, 9)); out["sub.conv1.b"] = F32(sd[s + "layers.0.bias"])
+    for tag, i in (("2", 2), ("3", 5)):
+        out[f"sub.dw{tag}.w"] = F32(sd[s + f"layers.{i}.weight"].reshape(C, 9)); out[f"sub.dw{tag}.b"] = F32(sd[s + f"layers.{i}.bias"])
+        out[f"sub.pw{tag}.w"] = W(sd[s + f"layers.{i + 1}.weight"].reshape(C, C)); out[f"sub.pw{tag}.b"] = F32(sd[s + f"layers.{i + 1}.bias"])
+    scale = math.sqrt(d) if dims.scale_input else 1.0
+    lw = sd[s + "linear.weight"].reshape(d, C, F3).permute(0, 2, 1).reshape(d, F3 * C) * scale
+    out["sub.lin.w"] = W(lw); out["sub.lin.b"] = F32(sd[s + "linear.bias"] * scale)
+    pos = rel_pos_table(tm_enc, d)
+
+    def ln(dst, src):
+        out[dst + ".g"] = F32(sd[src + ".weight"]); out[dst + ".b"] = F32(sd[src + ".bias"])
+
+    def lin(dst, src):
+        out[dst + ".w"] = W(sd[src + ".weight"]); out[dst + ".b"] = F32(sd[src + ".bias"])
+
+    for l in range(dims.layers):
+        p, q = f"encoder.layers.{l}.", f"enc.{l}."
+        for a, b in (("ln_ff1", "norm_feed_forward1"), ("ln_att", "norm_self_att"), ("ln_conv", "norm_conv"),
+                     ("ln_ff2", "norm_feed_forward2"), ("ln_out", "norm_out")):
+            ln(q + a, p + b)
+        for a, b in (("ff1", "feed_forward1"), ("ff2", "feed_forward2")):
+            lin(q + a + ".fc1", p + b + ".linear1"); lin(q + a + ".fc2", p + b + ".linear2")
+        at = p + "self_attn."
+        u, v = sd[at + "bias_u"].reshape(d), sd[at + "bias_v"].reshape(d)
+        out[q + "qkv.w"] = W(torch.cat([sd[at + "q_proj.weight"], sd[at + "k_proj.weight"], sd[at + "v_proj.weight"]], 0))
+        out[q + "qkv.b"] = F32(torch.cat([sd[at + "q_proj.bias"] + u, sd[at + "k_proj.bias"], sd[at + "v_proj.bias"]], 0))
+        out[q + "vmu"] = F32(v - u)
+        out[q + "R"] = W((pos @ sd[at + "relative_k_proj.weight"].T) * D ** -0.5)
+        lin(q + "o", at + "o_proj")
+        cv = p + "conv."
+        out[q + "pw1.w"] = W(sd[cv + "pointwise_conv1.weight"].reshape(2 * d, d)); out[q + "pw1.b"] = F32(sd[cv + "pointwise_conv1.bias"])
+        bn_s = sd[cv + "norm.weight"] / torch.sqrt(sd[cv + "norm.running_var"] + 1e-5)
+        bn_t = sd[cv + "norm.bias"] - sd[cv + "norm.running_mean"] * bn_s
+        out[q + "dw.w"] = F32(sd[cv + "depthwise_conv.weight"].reshape(d, dims.conv_kernel) * bn_s[:, None])
+        out[q + "dw.b"] = F32(sd[cv + "depthwise_conv.bias"] * bn_s + bn_t)
+        out[q + "pw2.w"] = W(sd[cv + "pointwise_conv2.weight"].reshape(d, d)); out[q + "pw2.b"] = F32(sd[cv + "pointwise_conv2.bias"])
+    lin("dec.encp", "encoder_projector")
+    out["dec.emb"] = W(sd["decoder.embedding.weight"])
+    for l in range(dims.dec_layers):
+        out[f"dec.lstm.{l}.w"] = W(torch.cat([sd[f"decoder.lstm.weight_ih_l{l}"], sd[f"decoder.lstm.weight_hh_l{l}"]], 1))
+        out[f"dec.lstm.{l}.b"] = F32(sd[f"decoder.lstm.bias_ih_l{l}"] + sd[f"decoder.lstm.bias_hh_l{l}"])
+    lin("dec.dproj", "decoder.decoder_projector")
+    lin("dec.joint", "joint.head")
+    return out
+
+
+class ParakeetEngine:
+    """One Parakeet-TDT replica on one GPU: log-mel + FastConformer encoder + TDT greedy decode for session batches."""
+
+    def __init__(self, dims: ParakeetDims, state_dict: Mapping[str, torch.Tensor] | None, dtype: torch.dtype = torch.bfloat16,
+                 max_batch: int = 8, max_seconds: float = 30.0, device: str | torch.device = "cuda:0",
+                 engine_tensors: Mapping[str, torch.Tensor] | None = None):
+        self.dims, self.dtype, self.max_batch = dims, dtype, int(max_batch)
+        self.device = torch.device(device)
+        self.max_feat_frames = int(max_seconds * 100) + 1
+        self._lib = native.load()
+        cfg = native.ParakeetConfigStruct(dims.n_mels, dims.d_model, dims.n_heads, dims.layers, dims.ffn, dims.sub_channels,
+                                          dims.conv_kernel, dims.vocab, dims.dec_hidden, dims.dec_layers, dims.n_durations,
+                                          self.max_feat_frames, native.dtype_code(dtype))
+        h = C.c_void_p()
+        native.check(self._lib.s2s_parakeet_create(C.byref(cfg), self.max_batch, C.byref(h)), "s2s_parakeet_create")
+        self._h = h
+        self.tm_enc = int(self._lib.s2s_parakeet_max_encoder_frames(h))
+        self._weights = {}
+        with torch.cuda.device(self.device):
+            tensors = engine_tensors if engine_tensors is not None else convert_parakeet_state_dict(state_dict, dims, dtype, self.tm_enc)
+            for name, t in tensors.items():
+                dt = t.to(self.device)
+                self._weights[name] = dt
+                native.check(self._lib.s2s_parakeet_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
+            native.check(self._lib.s2s_parakeet_finalize(h), "s2s_parakeet_finalize")
+        self.frontend = LogMelFrontend("parakeet", dims.n_mels, max_batch=self.max_batch, device=self.device)
+        self._B = 0
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.s2s_parakeet_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2s_parakeet_destroy(self._h)
+            self._h = None
+            self.frontend.close()
+
+    def features(self, audios: Sequence[np.ndarray]):
+        """-> (feats [B][T][n_mels] model dtype, n_frames int32 [B], T)."""
+        pcm, ns = pack_pcm(audios, self.device)
+        T = max(8, max(len(a) for a in audios) // 160 + 1)
+        feats, nf = self.frontend.parakeet(pcm, ns, T, out_dtype=self.dtype)
+        return feats, nf, T
+
+    def encode(self, feats: torch.Tensor, n_frames: torch.Tensor) -> None:
+        B, T, _ = feats.shape
+        assert feats.dtype == self.dtype and feats.is_contiguous()
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_parakeet_encode(self._h, native.stream_handle(), native.ptr(feats), native.ptr(n_frames), B, T),
+                         "s2s_parakeet_encode")
+        self._B, self._T = B, encoder_frames(T)
+
+    def encoder_output(self):
+        out = torch.empty((self._B, self._T, self.dims.d_model), dtype=torch.float32, device=self.device)
+        lens = torch.empty((self._B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_parakeet_read_encoder_output(self._h, native.stream_handle(), native.ptr(out), native.ptr(lens)))
+        return out, lens
+
+    def tdt_greedy(self, max_steps: int = 0):
+        """-> per session (tokens incl. blanks, durations, frame index of each step)."""
+        ms = max_steps if max_steps > 0 else 10 * self._T - 1
+        toks = torch.zeros((self._B, ms), dtype=torch.int32, device=self.device)
+        durs = torch.zeros_like(toks)
+        frames = torch.zeros_like(toks)
+        n = torch.zeros((self._B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_parakeet_tdt_greedy(self._h, native.stream_handle(), ms, native.ptr(toks), native.ptr(durs),
+                                                           native.ptr(frames), native.ptr(n)), "s2s_parakeet_tdt_greedy")
+        n_h, t_h, d_h, f_h = n.cpu().numpy(), toks.cpu().numpy(), durs.cpu().numpy(), frames.cpu().numpy()
+        return ([t_h[b, : n_h[b]].tolist() for b in range(self._B)], [d_h[b, : n_h[b]].tolist() for b in range(self._B)],
+                [f_h[b, : n_h[b]].tolist() for b in range(self._B)])
+
+    def transcribe_ids(self, audios: Sequence[np.ndarray]):
+        """-> per session (non-blank token ids, start frame of each token [x 80 ms])."""
+        feats, nf, _ = self.features(audios)
+        self.encode(feats, nf)
+        toks, durs, frames = self.tdt_greedy()
+        blank = self.dims.blank
+        ids = [[t for t in tk if t != blank] for tk in toks]
+        starts = [[f for t, f in zip(tk, fr) if t != blank] for tk, fr in zip(toks, frames)]
+        return ids, starts
