@@ -149,7 +149,63 @@ def make_parakeet():
     print("parakeet_tiny.npz written", {k: v.shape for k, v in out.items()})
 
 
-SECTIONS = {"logmel": make_logmel, "whisper": make_whisper, "parakeet": make_parakeet}
+def make_qwen3_tts():
+    """Sibling modules of Qwen3-TTS in transformers (CPU float32) on the tiny seeded checkpoint:
+    Code2Wav waveform, code-predictor greedy codes, dense Qwen3 decoder stack hidden states."""
+    import torch
+    from transformers import Qwen3Config, Qwen3Model
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import (Qwen3OmniMoeCode2WavConfig,
+                                                                                Qwen3OmniMoeTalkerCodePredictorConfig)
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import (
+        Qwen3OmniMoeCode2Wav, Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration)
+
+    from speech_to_speech_amd.synth_weights import Qwen3TTSDims, qwen3_tts_state_dict
+
+    dims = Qwen3TTSDims.test_tiny()
+    sd = qwen3_tts_state_dict(dims, seed=5)
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    # code2wav
+    c = Qwen3OmniMoeCode2WavConfig(codebook_size=dims.codebook, hidden_size=dims.c_hidden, num_attention_heads=dims.c_heads,
+                                   num_key_value_heads=dims.c_heads, intermediate_size=dims.c_ffn, num_hidden_layers=dims.c_layers,
+                                   num_quantizers=dims.n_groups, upsample_rates=list(dims.upsample_rates),
+                                   upsampling_ratios=list(dims.upsampling_ratios), decoder_dim=dims.c_decoder_dim,
+                                   sliding_window=dims.c_window)
+    m = Qwen3OmniMoeCode2Wav(c).eval()
+    m.load_state_dict({k[len("code2wav."):]: v for k, v in sd.items() if k.startswith("code2wav.")}, strict=True)
+    codes = torch.randint(0, dims.codebook, (2, dims.n_groups, 20), generator=g)
+    with torch.no_grad():
+        out["c2w_codes"] = codes.numpy().astype(np.int32)
+        out["c2w_wav"] = m(codes).numpy().astype(np.float32)
+    # code predictor
+    pc = Qwen3OmniMoeTalkerCodePredictorConfig(vocab_size=dims.codebook, hidden_size=dims.p_hidden, intermediate_size=dims.p_ffn,
+                                               num_hidden_layers=dims.p_layers, num_attention_heads=dims.p_heads,
+                                               num_key_value_heads=dims.p_kv_heads, head_dim=dims.p_head_dim,
+                                               num_code_groups=dims.n_groups, rms_norm_eps=dims.eps)
+    pm = Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration(pc).eval()
+    pm.load_state_dict({k[len("code_predictor."):]: v for k, v in sd.items() if k.startswith("code_predictor.")}, strict=True)
+    ph, e0 = torch.randn(3, dims.p_hidden, generator=g), torch.randn(3, dims.p_hidden, generator=g)
+    with torch.no_grad():
+        r = pm.generate(inputs_embeds=torch.stack([ph, e0], 1), max_new_tokens=dims.n_groups - 1, do_sample=False,
+                        return_dict_in_generate=True)
+    out["cp_hidden"], out["cp_e0"], out["cp_codes"] = ph.numpy(), e0.numpy(), r.sequences.numpy().astype(np.int32)
+    # talker backbone = dense Qwen3 decoder
+    qc = Qwen3Config(vocab_size=dims.codec_vocab, hidden_size=dims.t_hidden, intermediate_size=dims.t_ffn, num_hidden_layers=dims.t_layers,
+                     num_attention_heads=dims.t_heads, num_key_value_heads=dims.t_kv_heads, head_dim=dims.t_head_dim, rms_norm_eps=dims.eps,
+                     rope_parameters={"rope_theta": dims.t_theta, "rope_type": "default"}, attention_bias=False, tie_word_embeddings=False)
+    qm = Qwen3Model(qc).eval()
+    sub = {k[len("talker.model."):]: v for k, v in sd.items() if k.startswith("talker.model.") and "codec_embedding" not in k}
+    sub["embed_tokens.weight"] = sd["talker.model.codec_embedding.weight"]
+    qm.load_state_dict(sub, strict=True)
+    x = torch.randn(2, 9, dims.t_hidden, generator=g)
+    with torch.no_grad():
+        out["talker_in"] = x.numpy()
+        out["talker_hidden"] = qm(inputs_embeds=x).last_hidden_state.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "qwen3_tts_tiny.npz"), **out)
+    print("qwen3_tts_tiny.npz written", {k: v.shape for k, v in out.items()}, float(np.abs(out["c2w_wav"]).mean()))
+
+
+SECTIONS = {"logmel": make_logmel, "whisper": make_whisper, "parakeet": make_parakeet, "qwen3_tts": make_qwen3_tts}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)
