@@ -240,6 +240,61 @@ int32_t s2s_parakeet_read_encoder_output(void* model, void* stream, float* dst_d
 int32_t s2s_parakeet_tdt_greedy(void* model, void* stream, int32_t max_steps, int32_t* tokens_dev,
                                 int32_t* durations_dev, int32_t* frames_dev, int32_t* n_steps_dev);
 
+/* ------------------------------------------------------------------------- *
+ * Qwen3-TTS: talker + code predictor (codec frames) and codec decoder (waveform), one batch of sessions.
+ *   Replaces FasterQwen3TTS.generate_custom_voice_streaming / generate_voice_clone_streaming /
+ *   generate_voice_design_streaming as consumed by Qwen3TTSHandler._stream
+ *   (TTS/qwen3_tts_handler.py:695-749, 910-1003): prompt -> 12.5 Hz frames of n_groups codes -> 24 kHz PCM,
+ *   streamed every `chunk_size` frames.  faster-qwen3-tts / qwentts.cpp are not available offline; the
+ *   arithmetic is restated from transformers' qwen3_omni_moe talker / code predictor / Code2Wav and qwen3.
+ * ------------------------------------------------------------------------- */
+typedef struct s2s_tts_config {
+    int32_t t_hidden, t_layers, t_heads, t_kv_heads, t_head_dim, t_ffn;   /* talker (dense Qwen3 decoder) */
+    int32_t codec_vocab, codec_eos;
+    int32_t p_hidden, p_layers, p_heads, p_kv_heads, p_head_dim, p_ffn;   /* code predictor */
+    int32_t n_groups, codebook;
+    int32_t c_hidden, c_layers, c_heads, c_ffn, c_window, c_decoder_dim;  /* codec decoder */
+    int32_t n_dec_blocks;    /* decoder blocks in use (<= 4) */
+    int32_t up_rate[4];      /* decoder-block upsampling (8,5,4,3) */
+    int32_t up_ratio[2];     /* pre-decoder upsamplers (2,2) */
+    int32_t total_upsample;  /* 1920 samples per frame */
+    int32_t max_prompt;      /* longest prefill (tokens) */
+    int32_t max_frames;      /* codec-frame budget per utterance */
+    int32_t max_pos;         /* talker KV-cache positions >= max_prompt + max_frames */
+    int32_t max_codec_frames;/* longest codec_decode call (context + new frames) */
+    float eps, c_eps;        /* RMSNorm eps of talker/predictor and of the codec transformer */
+    int32_t dtype;
+} s2s_tts_config;
+
+int32_t s2s_tts_create(const s2s_tts_config* cfg, int32_t max_batch, void** out_model);
+int32_t s2s_tts_destroy(void* model);
+/* names / layouts: speech-to-speech_amd/tts.py (WEIGHT LAYOUT) */
+int32_t s2s_tts_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel);
+int32_t s2s_tts_finalize(void* model);
+int64_t s2s_tts_workspace_bytes(void* model);
+/* Prefill the talker: prompt_embeds_dev f32 [B][Tp][t_hidden] (right-padded), prompt_len_dev int32 [B]. */
+int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev,
+                        int32_t B, int32_t Tp);
+/* Generate n_frames more frames (greedy).  codes_dev int32 [B][n_frames][n_groups] receives the frames of THIS call
+ * (-1 after a session's eos), n_frames_dev int32 [B] the valid frames so far; eos is suppressed until a session has
+ * min_total_frames frames; *all_done_host (optional, forces a stream sync) = 1 when every session has ended. */
+int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
+                         int32_t* n_frames_dev, int32_t* all_done_host);
+/* Codec decoder: codes_dev int32 [B][F][n_groups] (the first ctx frames are left context) -> wav_dev f32
+ * [B][n_samples], n_samples = s2s_codec_samples(F) - ctx * total_upsample, values clamped to [-1, 1]. */
+int32_t s2s_codec_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, int32_t ctx,
+                         float* wav_dev, int32_t n_samples);
+int64_t s2s_codec_samples(void* model, int32_t F);
+/* Post-processing of Qwen3TTSHandler._stream (TTS/qwen3_tts_handler.py:612-613,674-680): per-chunk
+ * scipy.signal.resample_poly(x, up=2, down=3) then clip(x*32768).astype(int16).
+ *   pcm24_dev f32 [B][in_stride], n_in_dev optional int32 [B] (else in_stride samples), fir_dev f32 [taps] the
+ *   host-designed polyphase prototype (already multiplied by `up`), delay = (taps-1)/2.
+ *   out16_dev int16 / outf_dev f32 (either may be NULL) [B][out_stride]; n_out_max outputs computed per row
+ *   (rows shorter than that are zero-filled past ceil(2n/3)). */
+int32_t s2s_resample_24k16k_int16(void* stream, const float* pcm24_dev, int64_t in_stride, const int32_t* n_in_dev,
+                                  const float* fir_dev, int32_t taps, int32_t delay, int16_t* out16_dev, float* outf_dev,
+                                  int64_t out_stride, int32_t n_out_max, int32_t B);
+
 #ifdef __cplusplus
 }
 #endif

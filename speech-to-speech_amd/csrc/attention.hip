@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     const int hk = h / (p.H / p.Hkv);
     int kv = p.kv_len ? min(p.kv_len[b], kvmax) : kvmax;
     int jlo = 0, jhi = kv;   // allowed keys [jlo, jhi)
-    if (p.causal) jhi = min(kv, t + p.causal_off + 1);
-    if (p.window > 0) jlo = max(0, t + p.causal_off - p.window + 1);
+    const int coff = p.causal_off_arr ? p.causal_off_arr[b] : p.causal_off;
+    if (p.causal) jhi = min(kv, t + coff + 1);
+    if (p.window > 0) jlo = max(0, t + coff - p.window + 1);
 
     const T* q = (const T*)p.Q + (long)b * p.q_bs + (long)t * p.q_rs + (long)h * D;
     for (int d = lane; d < D; d += 64) qs[d] = Elem<T>::ld(q + d) * p.scale;

@@ -67,6 +67,8 @@ struct RowMap {
     int nz2;                        // blockIdx.y = z1 * nz2 + z2: batched GEMMs (e.g. one per (session, head))
     long a_z1, a_z2, w_z1, w_z2, c_z1, c_z2;
     float alpha;                    // C = act(acc + bias) * alpha + residual
+    int tap_len;                    // > 0: K index k of A lives at row + (k / tap_len) * tap_stride + k % tap_len
+    long tap_stride;                //      (dilated 1-D convolution taps over a time-major buffer)
 };
 
 template <typename T, typename CT>
@@ -122,7 +124,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
             const int k = k0 + ch * EPC;
             u32x4_t va = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
             if (k < K) {
-                if (arow[i]) va = *reinterpret_cast<const u32x4_t*>(arow[i] + k0);
+                if (arow[i]) {
+                    long ao = k0;
+                    if (rm.tap_len > 0) {
+                        const int tap = k / rm.tap_len;
+                        ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len) - ch * EPC;
+                    }
+                    va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                }
                 if (wrow[i]) vw = *reinterpret_cast<const u32x4_t*>(wrow[i] + k0);
             }
             ga[i] = va;
@@ -258,7 +267,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     u32x4_t v = {0u, 0u, 0u, 0u};
-                    if (arow[i] && k < kend) v = *reinterpret_cast<const u32x4_t*>(arow[i] + k);
+                    if (arow[i] && k < kend) {
+                        long ao = k;
+                        if (rm.tap_len > 0) {
+                            const int tap = k / rm.tap_len;
+                            ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
+                        }
+                        v = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                    }
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v), fw[u], acc[i], 0, 0, 0);
                 }
             }
@@ -276,7 +292,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
                 const int k = k0 + u * KPF + lg;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const float a = (arow[i] && k < kend) ? arow[i][k] : 0.f;
+                    float a = 0.f;
+                    if (arow[i] && k < kend) {
+                        long ao = k;
+                        if (rm.tap_len > 0) {
+                            const int tap = k / rm.tap_len;
+                            ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
+                        }
+                        a = arow[i][ao];
+                    }
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fw[u], acc[i], 0, 0, 0);
                 }
             }
@@ -318,6 +342,8 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     const int nz = nz1 * rm.nz2;
     rm.a_z1 = g.a_z1; rm.a_z2 = g.a_z2; rm.w_z1 = g.w_z1; rm.w_z2 = g.w_z2; rm.c_z1 = g.c_z1; rm.c_z2 = g.c_z2;
     rm.alpha = g.alpha_set ? g.alpha : 1.0f;
+    rm.tap_len = g.tap_len;
+    rm.tap_stride = g.tap_stride;
     const int M = g.M, N = g.N, K = g.K;
     if (M <= 64) {
         const int MT = cdiv(M, 16);
@@ -372,6 +398,7 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
     S2S_REQUIRE(g.K % epc == 0 && g.lda % epc == 0 && g.a_bs % epc == 0,
                 "gemm: K=%d / lda=%ld / a_bs=%ld must be multiples of %d", g.K, g.lda, g.a_bs, epc);
     S2S_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    S2S_REQUIRE(g.tap_len % epc == 0 && g.tap_stride % epc == 0, "gemm: tap_len / tap_stride must be multiples of %d", epc);
     S2S_REQUIRE(g.ldw % epc == 0 && g.a_z1 % epc == 0 && g.a_z2 % epc == 0 && g.w_z1 % epc == 0 && g.w_z2 % epc == 0,
                 "gemm: ldw / batch strides must be multiples of %d elements", epc);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);

@@ -16,6 +16,7 @@ struct GemmArgs {
     int nz1, nz2;                                // batched: grid.y = nz1*nz2 independent GEMMs (0 -> 1)
     long a_z1, a_z2, w_z1, w_z2, c_z1, c_z2;     // per-batch element offsets (C strides also apply to residual)
     float alpha; bool alpha_set;                 // C = act(acc+bias)*alpha + residual (alpha_set false -> 1)
+    int tap_len; long tap_stride;                // dilated conv taps: A index k -> (k/tap_len)*tap_stride + k%tap_len
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
@@ -37,6 +38,7 @@ struct AttnRowsParams {
     int B, H, Hkv, Tq, D;
     int causal;          // 1: key j allowed iff j <= t + causal_off
     int causal_off;
+    const int* causal_off_arr;   // optional int32[B]: per-session offset (tokens already in the cache) instead of causal_off
     int window;          // >0: additionally j > t + causal_off - window
     float scale;
 };

@@ -1,0 +1,633 @@
+// Qwen3-TTS as a native kernel graph: talker (dense Qwen3 decoder) + code predictor (per-frame 15-step
+// residual-code loop) + codec decoder (sliding-window transformer, causal transposed convolutions, ConvNeXt,
+// SnakeBeta residual units), for one batch of sessions.
+//
+// Replaces FasterQwen3TTS.generate_*_streaming(...) as driven by the reference's Qwen3TTSHandler
+// (TTS/qwen3_tts_handler.py:910-1003).  The package behind it (faster-qwen3-tts -> qwentts.cpp) is not available
+// offline; the arithmetic is restated from the sibling architecture in transformers
+// (models/qwen3_omni_moe/modeling_qwen3_omni_moe.py:2250-2620, 3100-3177, 3180-3697; models/qwen3/modeling_qwen3.py).
+//
+// HBM layout: residual streams f32; projections / caches in the model dtype; KV caches [L][B][max_pos][Hk*D];
+// codec activations time-major [B][LPAD + T][C] with LPAD zero rows in front of every item so that every causal
+// (dilated) convolution and transposed convolution is ONE GEMM over overlapping rows (no im2col).
+#include "ops.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace s2s {
+
+int rope_qknorm(hipStream_t st, void* qkv, int rows, int T_len, int H, int Hk, int D, const float* qw, const float* kw, float eps,
+                const float* cosT, const float* sinT, const int* pos0, int dtype);
+int kv_append_rows(hipStream_t st, const void* src, long src_rs, int k_off, int v_off, void* kc, void* vc, long c_bs,
+                   const int* pos0, int B, int T_len, int n, int dtype);
+int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dtype);
+int add_int(hipStream_t st, int* p, int v, int n);
+int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
+                 int dim, int accumulate, const void* addvec, int dtype);
+int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* h, long rows, int Q, int cb, int dim, int dtype);
+int snake(hipStream_t st, const void* x, void* y, const float* a, const float* invb, int B, int Tn, int C, int lpad_in, int lpad_out, int dtype);
+int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias, const float* g, const float* be, void* y, int B,
+               int Tn, int C, int lpad, float eps, int dtype);
+int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, int skip, int n, int dtype);
+int add_f32_into_padded(hipStream_t st, void* x, const float* y, int B, int Tn, int C, int lpad, int dtype);
+int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
+
+constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
+
+struct TTensor { const void* ptr; long numel; };
+
+struct StackCfg {
+    int hidden, layers, heads, kv_heads, head_dim, ffn, qk_norm, window, max_pos;
+    float eps;
+};
+
+struct Stack {
+    StackCfg c;
+    std::string prefix;      // weight name prefix, e.g. "talker."
+    void *kc = nullptr, *vc = nullptr;          // [L][B][max_pos][Hk*D]
+    const float *cosT = nullptr, *sinT = nullptr;
+};
+
+struct Tts {
+    s2s_tts_config cfg;
+    int max_batch, esz;
+    std::map<std::string, TTensor> w;
+    bool finalized = false;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    Stack talker, pred, codec;
+    // shared scratch (sized for the largest use)
+    void *h, *qkv, *att, *gu, *act;
+    float *x;          // talker residual rows [B*Tmax_prompt][E]
+    float *xp;         // predictor residual rows [B*2][P]
+    float *hn;         // talker normed last hidden (f32) [B][E]
+    void *hn_t;        // same in model dtype
+    float *logits;     // [B][max(codec_vocab, codebook)]
+    float *xnext;      // next talker input [B][E]
+    float *pin;        // predictor input before in_proj [B*2][E]
+    void *pin_t;
+    int *pos_t, *pos_p, *code0, *codes_frame, *finished, *n_frames, *n_active, *step;
+    int *codes_out;    // [B][max_frames][G]
+    unsigned char* sup_mask;   // [codec_vocab] built-in suppress mask (codec specials except eos)
+    int frames_done = 0, cur_B = 0, prompt_max = 0;
+    // codec decoder buffers
+    float* cx;  void *ca, *cb_, *cc;   // residual stream + ping-pong activations
+    int* host_flag = nullptr;
+};
+
+static const TTensor* tf(const Tts* m, const std::string& n) {
+    auto it = m->w.find(n);
+    return it == m->w.end() ? nullptr : &it->second;
+}
+static const void* TP(const Tts* m, const std::string& n) { const TTensor* t = tf(m, n); return t ? t->ptr : nullptr; }
+static const float* TPF(const Tts* m, const std::string& n) { return (const float*)TP(m, n); }
+
+static int need(const Tts* m, const std::string& n, long numel) {
+    const TTensor* t = tf(m, n);
+    if (!t) return fail(S2S_ERR_STATE, "tts: missing tensor %s", n.c_str());
+    if (t->numel != numel) return fail(S2S_ERR_STATE, "tts: tensor %s has %ld elements, expected %ld", n.c_str(), t->numel, numel);
+    return S2S_OK;
+}
+
+static int check_stack(const Tts* m, const Stack& s) {
+    const auto& c = s.c;
+    const long qkv_n = (long)(c.heads + 2 * c.kv_heads) * c.head_dim;
+    int rc;
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = s.prefix + std::to_string(l) + ".";
+        if ((rc = need(m, p + "ln1", c.hidden))) return rc;
+        if ((rc = need(m, p + "qkv.w", qkv_n * c.hidden))) return rc;
+        if (c.qk_norm) {
+            if ((rc = need(m, p + "qnorm", c.head_dim))) return rc;
+            if ((rc = need(m, p + "knorm", c.head_dim))) return rc;
+        }
+        if ((rc = need(m, p + "o.w", (long)c.hidden * c.heads * c.head_dim))) return rc;
+        if ((rc = need(m, p + "ln2", c.hidden))) return rc;
+        if ((rc = need(m, p + "gu.w", 2L * c.ffn * c.hidden))) return rc;
+        if ((rc = need(m, p + "down.w", (long)c.hidden * c.ffn))) return rc;
+    }
+    if ((rc = need(m, s.prefix + "rope.cos", (long)c.max_pos * c.head_dim / 2))) return rc;
+    if ((rc = need(m, s.prefix + "rope.sin", (long)c.max_pos * c.head_dim / 2))) return rc;
+    return S2S_OK;
+}
+
+struct Plan {
+    size_t off = 0;
+    size_t take(size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; }
+};
+
+static long codec_len(const s2s_tts_config& c, long F, int stage) {
+    // stage 0: after the two x2 upsamplers; stage i (1..4): after decoder block i
+    long T = F;
+    for (int i = 0; i < 2; ++i) T *= c.up_ratio[i];
+    for (int i = 0; i < stage; ++i) T = (T - 1) * c.up_rate[i];
+    return T;
+}
+
+static int finalize(Tts* m) {
+    const auto& c = m->cfg;
+    int rc;
+    m->talker.c = StackCfg{c.t_hidden, c.t_layers, c.t_heads, c.t_kv_heads, c.t_head_dim, c.t_ffn, 1, 0, c.max_pos, c.eps};
+    m->talker.prefix = "talker.";
+    m->pred.c = StackCfg{c.p_hidden, c.p_layers, c.p_heads, c.p_kv_heads, c.p_head_dim, c.p_ffn, 1, 0, c.n_groups + 1, c.eps};
+    m->pred.prefix = "pred.";
+    m->codec.c = StackCfg{c.c_hidden, c.c_layers, c.c_heads, c.c_heads, c.c_hidden / c.c_heads, c.c_ffn, 0, c.c_window, c.max_codec_frames, c.c_eps};
+    m->codec.prefix = "codec.";
+    for (Stack* s : {&m->talker, &m->pred, &m->codec}) {
+        if ((rc = check_stack(m, *s))) return rc;
+        s->cosT = TPF(m, s->prefix + "rope.cos");
+        s->sinT = TPF(m, s->prefix + "rope.sin");
+    }
+    const long E = c.t_hidden, P = c.p_hidden, G = c.n_groups, CB = c.codebook, H = c.c_hidden;
+    if ((rc = need(m, "talker.norm", E)) || (rc = need(m, "talker.emb", (long)c.codec_vocab * E)) || (rc = need(m, "talker.head.w", (long)c.codec_vocab * E)) ||
+        (rc = need(m, "talker.pad_embed", E)) || (rc = need(m, "pred.norm", P)))
+        return rc;
+    if (P != E && ((rc = need(m, "pred.in_proj.w", P * E)) || (rc = need(m, "pred.in_proj.b", P)))) return rc;
+    for (int g = 0; g < G - 1; ++g) {
+        if ((rc = need(m, "pred.emb." + std::to_string(g), CB * E)) || (rc = need(m, "pred.head." + std::to_string(g) + ".w", CB * P))) return rc;
+    }
+    if ((rc = need(m, "codec.emb", CB * G * H)) || (rc = need(m, "codec.norm", H))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        const std::string q = "codec.up." + std::to_string(i) + ".";
+        const long r = c.up_ratio[i];
+        if ((rc = need(m, q + "tconv.w", r * H * H)) || (rc = need(m, q + "tconv.b", r * H)) || (rc = need(m, q + "dw.w", H * 7)) || (rc = need(m, q + "dw.b", H)) ||
+            (rc = need(m, q + "ln.g", H)) || (rc = need(m, q + "ln.b", H)) || (rc = need(m, q + "pw1.w", 4 * H * H)) || (rc = need(m, q + "pw1.b", 4 * H)) ||
+            (rc = need(m, q + "pw2.w", 4 * H * H)) || (rc = need(m, q + "pw2.b", H)))
+            return rc;
+    }
+    const long Dd = c.c_decoder_dim;
+    if ((rc = need(m, "codec.dec.in.w", Dd * 7 * H)) || (rc = need(m, "codec.dec.in.b", Dd))) return rc;
+    for (int i = 0; i < c.n_dec_blocks; ++i) {
+        const long cin = Dd >> i, cout = Dd >> (i + 1), r = c.up_rate[i];
+        const std::string q = "codec.dec." + std::to_string(i) + ".";
+        if ((rc = need(m, q + "snake.a", cin)) || (rc = need(m, q + "snake.ib", cin)) || (rc = need(m, q + "tconv.w", r * cout * 2 * cin)) || (rc = need(m, q + "tconv.b", r * cout))) return rc;
+        for (int j = 0; j < 3; ++j) {
+            const std::string u = q + "ru" + std::to_string(j) + ".";
+            if ((rc = need(m, u + "s1.a", cout)) || (rc = need(m, u + "s1.ib", cout)) || (rc = need(m, u + "c1.w", cout * 7 * cout)) || (rc = need(m, u + "c1.b", cout)) ||
+                (rc = need(m, u + "s2.a", cout)) || (rc = need(m, u + "s2.ib", cout)) || (rc = need(m, u + "c2.w", cout * cout)) || (rc = need(m, u + "c2.b", cout)))
+                return rc;
+        }
+    }
+    const long co = Dd >> c.n_dec_blocks;
+    if ((rc = need(m, "codec.dec.out.a", co)) || (rc = need(m, "codec.dec.out.ib", co)) || (rc = need(m, "codec.dec.out.w", 7 * co)) || (rc = need(m, "codec.dec.out.b", 1))) return rc;
+
+    // ---- workspace
+    const size_t B = m->max_batch, e = m->esz;
+    const size_t Tp = c.max_prompt, F = c.max_codec_frames;
+    auto stack_scratch_rows = std::max<size_t>(B * Tp, B * F);
+    size_t wid_qkv = 0, wid_ffn = 0, wid_hid = 0, wid_att = 0;
+    for (Stack* s : {&m->talker, &m->pred, &m->codec}) {
+        wid_qkv = std::max<size_t>(wid_qkv, (size_t)(s->c.heads + 2 * s->c.kv_heads) * s->c.head_dim);
+        wid_ffn = std::max<size_t>(wid_ffn, s->c.ffn);
+        wid_hid = std::max<size_t>(wid_hid, s->c.hidden);
+        wid_att = std::max<size_t>(wid_att, (size_t)s->c.heads * s->c.head_dim);
+    }
+    Plan a;
+    std::vector<size_t> o;
+    auto T = [&](size_t b) { o.push_back(a.take(b)); };
+    T(stack_scratch_rows * wid_hid * e);       // 0 h
+    T(stack_scratch_rows * wid_qkv * e);       // 1 qkv
+    T(stack_scratch_rows * wid_att * e);       // 2 att
+    T(stack_scratch_rows * 2 * wid_ffn * e);   // 3 gu
+    T(stack_scratch_rows * wid_ffn * e);       // 4 act
+    T(B * Tp * E * 4);                         // 5 x
+    T(B * 2 * P * 4);                          // 6 xp
+    T(B * E * 4);                              // 7 hn
+    T(B * E * e);                              // 8 hn_t
+    T(B * (size_t)std::max(c.codec_vocab, c.codebook) * 4);   // 9 logits
+    T(B * E * 4);                              // 10 xnext
+    T(B * 2 * E * 4);                          // 11 pin
+    T(B * 2 * E * e);                          // 12 pin_t
+    T((8 * B + 16) * 4);                       // 13 ints
+    T(B * (size_t)c.max_frames * G * 4);       // 14 codes_out
+    T((size_t)c.codec_vocab);                  // 15 sup_mask
+    for (Stack* s : {&m->talker, &m->pred, &m->codec}) {   // 16..21 caches
+        const size_t per = (size_t)s->c.layers * B * s->c.max_pos * s->c.kv_heads * s->c.head_dim * e;
+        T(per); T(per);
+    }
+    // codec conv stack: the widest stage decides (rows * channels)
+    size_t act_elems = 0;
+    {
+        size_t r0 = codec_len(c, F, 0);
+        act_elems = std::max<size_t>(act_elems, (LPAD + r0) * (size_t)std::max<long>(4 * H, Dd));
+        for (int i = 1; i <= c.n_dec_blocks; ++i) act_elems = std::max<size_t>(act_elems, (LPAD + codec_len(c, F, i)) * (size_t)(Dd >> i));
+        act_elems = std::max<size_t>(act_elems, (LPAD + codec_len(c, F, c.n_dec_blocks)) * 8);   // final 1-channel conv output
+    }
+    T(B * F * 4 * H * 4);                      // 22 cx (f32 residual for the pre-transformer / unused later)
+    T(B * act_elems * e);                      // 23 ca
+    T(B * act_elems * e);                      // 24 cb
+    T(B * act_elems * e);                      // 25 cc
+    m->arena_bytes = a.off;
+    S2S_HIP_CHECK(hipMalloc(&m->arena, m->arena_bytes));
+    S2S_HIP_CHECK(hipMemset(m->arena, 0, m->arena_bytes));
+    char* b0 = m->arena;
+    m->h = b0 + o[0]; m->qkv = b0 + o[1]; m->att = b0 + o[2]; m->gu = b0 + o[3]; m->act = b0 + o[4];
+    m->x = (float*)(b0 + o[5]); m->xp = (float*)(b0 + o[6]); m->hn = (float*)(b0 + o[7]); m->hn_t = b0 + o[8];
+    m->logits = (float*)(b0 + o[9]); m->xnext = (float*)(b0 + o[10]); m->pin = (float*)(b0 + o[11]); m->pin_t = b0 + o[12];
+    int* ints = (int*)(b0 + o[13]);
+    m->pos_t = ints; m->pos_p = ints + B; m->code0 = ints + 2 * B; m->finished = ints + 3 * B; m->n_frames = ints + 4 * B;
+    m->codes_frame = ints + 5 * B;   // unused tail
+    m->n_active = ints + 7 * B; m->step = ints + 7 * B + 4;
+    m->codes_out = (int*)(b0 + o[14]);
+    m->sup_mask = (unsigned char*)(b0 + o[15]);
+    m->talker.kc = b0 + o[16]; m->talker.vc = b0 + o[17];
+    m->pred.kc = b0 + o[18]; m->pred.vc = b0 + o[19];
+    m->codec.kc = b0 + o[20]; m->codec.vc = b0 + o[21];
+    m->cx = (float*)(b0 + o[22]); m->ca = b0 + o[23]; m->cb_ = b0 + o[24]; m->cc = b0 + o[25];
+    // suppress mask: every codec special token except eos can never be emitted as codebook-0
+    std::vector<unsigned char> sup(c.codec_vocab, 0);
+    for (int i = c.codebook; i < c.codec_vocab; ++i) sup[i] = (i == c.codec_eos) ? 0 : 1;
+    S2S_HIP_CHECK(hipMemcpy(m->sup_mask, sup.data(), sup.size(), hipMemcpyHostToDevice));
+    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, 64, 0));
+    m->finalized = true;
+    return S2S_OK;
+}
+
+static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
+static inline const void* at(const void* p, size_t bytes) { return (const char*)p + bytes; }
+
+// One pass of a decoder stack over T_len new tokens per session.  x: f32 residual rows [B*T_len][hidden].
+// pos0: device int32[B] = tokens already cached per session (nullptr -> 0).  kv_cap: host upper bound of pos0 + T_len.
+static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int T_len, const int* pos0, int kv_cap, const int* kv_len_dev) {
+    const auto& c = s.c;
+    const int dt = m->cfg.dtype, e = m->esz;
+    const int H = c.heads, Hk = c.kv_heads, D = c.head_dim, hid = c.hidden;
+    const int nq = (H + 2 * Hk) * D, M = B * T_len;
+    const size_t cache_layer = (size_t)m->max_batch * c.max_pos * Hk * D * e;
+    int rc;
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = s.prefix + std::to_string(l) + ".";
+        if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
+        if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+        if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
+                              c.eps, s.cosT, s.sinT, pos0, dt))) return rc;
+        void* kc = at(s.kc, l * cache_layer);
+        void* vc = at(s.vc, l * cache_layer);
+        if ((rc = kv_append_rows(st, m->qkv, nq, H * D, (H + Hk) * D, kc, vc, (long)c.max_pos * Hk * D, pos0, B, T_len, Hk * D, dt))) return rc;
+        AttnRowsParams a{};
+        a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
+        a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
+        a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
+        a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
+        a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+        if ((rc = attn_rows(st, a, dt))) return rc;
+        if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
+        if ((rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
+        if ((rc = gemm(st, m->h, hid, TP(m, p + "gu.w"), nullptr, nullptr, m->gu, 2 * c.ffn, M, 2 * c.ffn, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+        if ((rc = swiglu(st, m->gu, m->act, M, c.ffn, dt))) return rc;
+        if ((rc = gemm(st, m->act, c.ffn, TP(m, p + "down.w"), nullptr, x, x, hid, M, hid, c.ffn, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
+    }
+    return S2S_OK;
+}
+
+// kv_len[b] = pos0[b] + T  (valid keys after appending)
+__global__ void kvlen_kernel(const int* pos0, int T, int* out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = (pos0 ? pos0[b] : 0) + T;
+}
+
+// copy the last valid prompt row of every session: dst[b] = x[b*Tp + len[b]-1]
+__global__ void last_row_kernel(const float* __restrict__ x, const int* __restrict__ len, int Tp, int dim, float* __restrict__ dst) {
+    const int b = blockIdx.x;
+    const float* r = x + ((long)b * Tp + max(len[b] - 1, 0)) * dim;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) dst[(long)b * dim + i] = r[i];
+}
+
+// after the talker head: code0 = argmax (already in code0), handle eos / frame bookkeeping
+__global__ void tts_frame_begin_kernel(const int* __restrict__ code0, int eos, int* finished, int* n_frames, int* codes_out, int max_frames,
+                                       int G, int frame, int B, int* n_active) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int f = finished[b];
+    if (!f && code0[b] == eos) f = 1;
+    finished[b] = f;
+    codes_out[((long)b * max_frames + frame) * G] = f ? -1 : code0[b];
+    if (!f) {
+        n_frames[b] = frame + 1;
+        atomicAdd(n_active, 1);
+    }
+}
+
+__global__ void tts_store_code_kernel(const int* __restrict__ picked, const int* __restrict__ finished, int* codes_out, int max_frames, int G,
+                                      int frame, int g, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    codes_out[((long)b * max_frames + frame) * G + g] = finished[b] ? -1 : picked[b];
+}
+
+// pin rows: [b][0] = talker normed hidden, [b][1] = talker embedding of code0 (both f32, dim E)
+__global__ void pred_input_kernel(const float* __restrict__ hn, const float* __restrict__ e0, float* __restrict__ pin, int E) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < E; i += blockDim.x) {
+        pin[((long)b * 2) * E + i] = hn[(long)b * E + i];
+        pin[((long)b * 2 + 1) * E + i] = e0[(long)b * E + i];
+    }
+}
+
+static int talker_head(Tts* m, hipStream_t st, int B, const float* hidden_rows, int min_frames_left) {
+    const auto& c = m->cfg;
+    const int dt = c.dtype, E = c.t_hidden;
+    int rc;
+    if ((rc = rmsnorm(st, hidden_rows, TPF(m, "talker.norm"), m->hn, B, E, c.eps, S2S_F32))) return rc;
+    if ((rc = cast_f32(st, m->hn, m->hn_t, (long)B * E, dt))) return rc;
+    if ((rc = gemm(st, m->hn_t, E, TP(m, "talker.head.w"), nullptr, nullptr, m->logits, c.codec_vocab, B, c.codec_vocab, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+    // min_frames: eos suppressed through the begin-mask slot (a mask that only has the eos byte set)
+    const unsigned char* eos_mask = (const unsigned char*)TP(m, "talker.eos_mask");
+    return argmax_suppress(st, m->logits, c.codec_vocab, B, c.codec_vocab, m->sup_mask, min_frames_left > 0 ? eos_mask : nullptr,
+                           min_frames_left > 0 ? m->step : nullptr, 0, m->code0, nullptr);
+}
+
+// run the code predictor for the current frame and build the next talker input in m->xnext
+static int predictor_frame(Tts* m, hipStream_t st, int B, int frame) {
+    const auto& c = m->cfg;
+    const int dt = c.dtype, E = c.t_hidden, P = c.p_hidden, G = c.n_groups, CB = c.codebook;
+    int rc;
+    // xnext = talker embedding of code0 + tts_pad_embed; the residual groups' embeddings are accumulated below
+    if ((rc = gather_embed(st, TP(m, "talker.emb"), m->code0, 1, 0, m->xnext, E, B, E, 0, TP(m, "talker.pad_embed"), dt))) return rc;
+    // predictor prefill rows per session: [normed talker hidden, talker embedding of code0]
+    S2S_HIP_CHECK(hipMemcpy2DAsync(m->pin, sizeof(float) * 2 * E, m->hn, sizeof(float) * E, sizeof(float) * E, B, hipMemcpyDeviceToDevice, st));
+    if ((rc = gather_embed(st, TP(m, "talker.emb"), m->code0, 1, 0, m->pin + E, 2L * E, B, E, 0, nullptr, dt))) return rc;
+    S2S_HIP_CHECK(hipMemsetAsync(m->pos_p, 0, sizeof(int) * m->max_batch, st));
+    for (int g = 0; g < G - 1; ++g) {
+        const int T_len = g == 0 ? 2 : 1;
+        const int M = B * T_len;
+        if (g > 0) {
+            // input = predictor embedding g-1 of the code just drawn
+            if ((rc = gather_embed(st, TP(m, "pred.emb." + std::to_string(g - 1)), m->codes_frame, 1, 0, m->pin, E, B, E, 0, nullptr, dt))) return rc;
+        }
+        if (P != E) {
+            if ((rc = cast_f32(st, m->pin, m->pin_t, (long)M * E, dt))) return rc;
+            if ((rc = gemm(st, m->pin_t, E, TP(m, "pred.in_proj.w"), TPF(m, "pred.in_proj.b"), nullptr, m->xp, P, M, P, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        } else {
+            S2S_HIP_CHECK(hipMemcpyAsync(m->xp, m->pin, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, st));
+        }
+        if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, m->pos_p, g + 2, nullptr))) return rc;
+        if ((rc = add_int(st, m->pos_p, T_len, B))) return rc;
+        const float* last = m->xp;
+        if (T_len == 2) {   // compact the second row of every session
+            S2S_HIP_CHECK(hipMemcpy2DAsync(m->pin, sizeof(float) * P, m->xp + P, sizeof(float) * 2 * P, sizeof(float) * P, B, hipMemcpyDeviceToDevice, st));
+            last = m->pin;
+        }
+        if ((rc = rmsnorm(st, last, TPF(m, "pred.norm"), m->h, B, P, c.eps, dt))) return rc;
+        if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if ((rc = argmax_suppress(st, m->logits, CB, B, CB, nullptr, nullptr, nullptr, 0, m->codes_frame, nullptr))) return rc;
+        tts_store_code_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->codes_frame, m->finished, m->codes_out, c.max_frames, G, frame, g + 1, B);
+        S2S_LAUNCH_CHECK();
+        if ((rc = gather_embed(st, TP(m, "pred.emb." + std::to_string(g)), m->codes_frame, 1, 0, m->xnext, E, B, E, 1, nullptr, dt))) return rc;
+    }
+    return S2S_OK;
+}
+
+}  // namespace s2s
+
+using namespace s2s;
+
+extern "C" int32_t s2s_tts_create(const s2s_tts_config* cfg, int32_t max_batch, void** out) {
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 64, "tts_create: bad arguments (max_batch 1..64)");
+    S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "tts_create: bad dtype");
+    S2S_REQUIRE(cfg->t_hidden % 8 == 0 && cfg->p_hidden % 8 == 0 && cfg->c_hidden % 8 == 0 && cfg->t_ffn % 8 == 0 && cfg->p_ffn % 8 == 0 &&
+                    cfg->c_ffn % 8 == 0 && cfg->n_dec_blocks >= 1 && cfg->n_dec_blocks <= 4 && (cfg->c_decoder_dim >> cfg->n_dec_blocks) % 8 == 0,
+                "tts_create: dimensions must be multiples of 8 (decoder_dim / 2^n_dec_blocks too)");
+    S2S_REQUIRE(cfg->max_prompt >= 2 && cfg->max_frames >= 1 && cfg->max_pos >= cfg->max_prompt + cfg->max_frames, "tts_create: max_pos too small");
+    Tts* m = new Tts();
+    m->cfg = *cfg;
+    m->max_batch = max_batch;
+    m->esz = cfg->dtype == S2S_F32 ? 4 : 2;
+    *out = m;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_tts_destroy(void* model) {
+    if (!model) return S2S_OK;
+    Tts* m = (Tts*)model;
+    if (m->arena) (void)hipFree(m->arena);
+    if (m->host_flag) (void)hipHostFree(m->host_flag);
+    delete m;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_tts_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && name && dev_ptr, "tts_set_tensor: null argument");
+    S2S_REQUIRE(((uintptr_t)dev_ptr & 15) == 0, "tts_set_tensor: %s is not 16-byte aligned", name);
+    m->w[name] = TTensor{dev_ptr, (long)numel};
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_tts_finalize(void* model) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m, "tts_finalize: null model");
+    if (m->finalized) return S2S_OK;
+    int rc = need(m, "talker.eos_mask", m->cfg.codec_vocab);
+    if (rc) return rc;
+    return finalize(m);
+}
+
+extern "C" int64_t s2s_tts_workspace_bytes(void* model) {
+    Tts* m = (Tts*)model;
+    return m ? (int64_t)m->arena_bytes : 0;
+}
+
+// Prefill: prompt_embeds_dev f32 [B][Tp][E] (right-padded), prompt_len_dev int32 [B].
+extern "C" int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev,
+                                   int32_t B, int32_t Tp) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "tts_prefill: model not finalized");
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && Tp >= 1 && Tp <= m->cfg.max_prompt && prompt_embeds_dev && prompt_len_dev, "tts_prefill: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = m->cfg.t_hidden;
+    int rc;
+    S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)B * Tp * E, hipMemcpyDeviceToDevice, st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (8 * (size_t)m->max_batch + 16), st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->codes_out, 0xff, sizeof(int) * (size_t)m->max_batch * m->cfg.max_frames * m->cfg.n_groups, st));
+    // padded rows beyond a session's prompt are cached too but never attended: kv_len = prompt_len
+    if ((rc = stack_forward(m, st, m->talker, m->x, B, Tp, nullptr, Tp, prompt_len_dev))) return rc;
+    S2S_HIP_CHECK(hipMemcpyAsync(m->pos_t, prompt_len_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    last_row_kernel<<<B, 256, 0, st>>>(m->x, prompt_len_dev, Tp, E, m->xnext);
+    S2S_LAUNCH_CHECK();
+    m->cur_B = B;
+    m->prompt_max = Tp;
+    m->frames_done = 0;
+    return S2S_OK;
+}
+
+// Generate up to n_frames more codec frames for the prefilled batch (greedy).  Returns codes of the frames
+// produced by THIS call in codes_dev int32 [B][n_frames][G] (-1 after a session's end) and the total number of
+// valid frames so far per session in n_frames_dev.  min_total_frames: eos is suppressed until a session has that
+// many frames.  all_done_host (optional): set to 1 when every session has emitted eos.
+extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
+                                    int32_t* n_frames_dev, int32_t* all_done_host) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && m->cur_B > 0, "tts_generate: prefill first");
+    const auto& c = m->cfg;
+    S2S_REQUIRE(n_frames >= 1 && m->frames_done + n_frames <= c.max_frames, "tts_generate: frame budget %d exceeded", c.max_frames);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = m->cur_B, E = c.t_hidden, G = c.n_groups;
+    int rc;
+    const int f0 = m->frames_done;
+    for (int f = f0; f < f0 + n_frames; ++f) {
+        // hidden of the last processed position is in xnext (prefill) or in x (previous frame's talker step)
+        const float* hidden = f == 0 ? m->xnext : m->x;
+        if (f == 0) {
+            S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
+            hidden = m->x;
+        }
+        if ((rc = talker_head(m, st, B, hidden, min_total_frames - f))) return rc;
+        S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
+        tts_frame_begin_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->code0, c.codec_eos, m->finished, m->n_frames, m->codes_out, c.max_frames, G, f, B, m->n_active);
+        S2S_LAUNCH_CHECK();
+        if ((rc = predictor_frame(m, st, B, f))) return rc;
+        // talker step on the summed embeddings
+        S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
+        if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->prompt_max + f + 1, nullptr))) return rc;
+        if ((rc = add_int(st, m->pos_t, 1, B))) return rc;
+    }
+    m->frames_done = f0 + n_frames;
+    if (codes_dev)
+        S2S_HIP_CHECK(hipMemcpy2DAsync(codes_dev, sizeof(int) * n_frames * G, m->codes_out + (size_t)f0 * G, sizeof(int) * c.max_frames * G,
+                                       sizeof(int) * n_frames * G, B, hipMemcpyDeviceToDevice, st));
+    if (n_frames_dev) S2S_HIP_CHECK(hipMemcpyAsync(n_frames_dev, m->n_frames, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    if (all_done_host) {
+        S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        S2S_HIP_CHECK(hipStreamSynchronize(st));
+        *all_done_host = *m->host_flag == 0 ? 1 : 0;
+    }
+    return S2S_OK;
+}
+
+// ---- codec decoder ----------------------------------------------------------------------------------------
+namespace s2s {
+
+// causal conv (kernel k, dilation d) as one GEMM over the padded time-major buffer: in [B][LPAD+T][Cin] -> out rows
+static int conv_gemm(Tts* m, hipStream_t st, const void* in, int T, int Cin, int k, int dil, const std::string& w, const std::string& b,
+                     void* out, int out_lpad, int Cout, const float* residual_in_out_layout, int act, int c_dtype) {
+    GemmArgs g{};
+    const int e = m->esz;
+    g.A = at(in, (size_t)(LPAD - (k - 1) * dil) * Cin * e); g.lda = Cin; g.a_bs = (long)(LPAD + T) * Cin;
+    g.W = TP(m, w); g.bias = TPF(m, b);
+    const size_t ce = c_dtype == S2S_F32 ? 4 : e;
+    g.C = at(out, (size_t)out_lpad * Cout * ce); g.ldc = Cout; g.c_bs = (long)(out_lpad + T) * Cout;
+    g.residual = residual_in_out_layout; g.ldr = Cout; g.r_bs = g.c_bs;
+    g.M = m->cur_B * T; g.N = Cout; g.K = k * Cin; g.G = T;
+    g.ab_dtype = m->cfg.dtype; g.c_dtype = c_dtype; g.act = act;
+    if (k > 1) { g.tap_len = Cin; g.tap_stride = (long)dil * Cin; }
+    return gemm_ex(st, g);
+}
+
+}  // namespace s2s
+
+// codes_dev int32 [B][F][G] frame-major (ctx frames of left context first); wav_dev f32 [B][n_samples] receives the
+// samples after the first ctx*total_upsample ones; n_samples = codec_samples(F) - ctx*total_upsample.
+extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, int32_t ctx,
+                                    float* wav_dev, int32_t n_samples) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "codec_decode: model not finalized");
+    const auto& c = m->cfg;
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && F >= 1 && F <= c.max_codec_frames && ctx >= 0 && ctx < F && codes_dev && wav_dev, "codec_decode: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = c.dtype, e = m->esz, H = c.c_hidden, G = c.n_groups;
+    const int saveB = m->cur_B;
+    m->cur_B = B;
+    int rc;
+    auto done = [&](int r) { m->cur_B = saveB; return r; };
+    // code embeddings -> sliding-window transformer
+    if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
+    if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, nullptr, F, nullptr))) return done(rc);
+    // final norm -> ca [B][LPAD+F][H]
+    {
+        // rmsnorm writes contiguous rows; place them behind the LPAD rows of every item with a strided copy
+        if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
+        S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,
+                                       hipMemcpyDeviceToDevice, st));
+    }
+    int T = F;
+    void *cur = m->ca, *alt = m->cb_, *tmp = m->cc;
+    for (int i = 0; i < 2; ++i) {
+        const std::string q = "codec.up." + std::to_string(i) + ".";
+        const int r = c.up_ratio[i];
+        // transposed conv kernel == stride: out[t*r + j] = x[t] . W[j]  -> GEMM N = r*H, rows land time-major
+        GemmArgs g{};
+        g.A = at(cur, (size_t)LPAD * H * e); g.lda = H; g.a_bs = (long)(LPAD + T) * H;
+        g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
+        g.C = at(alt, (size_t)LPAD * H * e); g.ldc = (long)r * H; g.c_bs = (long)(LPAD + T * r) * H;
+        g.M = B * T; g.N = r * H; g.K = H; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+        if ((rc = gemm_ex(st, g))) return done(rc);
+        T *= r;
+        std::swap(cur, alt);
+        // ConvNeXt: dwconv7 + LN -> pw1 GELU -> pw2 (gamma folded) + residual
+        if ((rc = dwconv7_ln(st, cur, TPF(m, q + "dw.w"), TPF(m, q + "dw.b"), TPF(m, q + "ln.g"), TPF(m, q + "ln.b"), alt, B, T, H, LPAD, 1e-6f, dt))) return done(rc);
+        if ((rc = gemm(st, alt, H, TP(m, q + "pw1.w"), TPF(m, q + "pw1.b"), nullptr, tmp, 4 * H, B * T, 4 * H, H, dt, dt, S2S_ACT_GELU, false))) return done(rc);
+        {
+            // residual lives in the padded model-dtype buffer: out = x + pw2(...).  The GEMM residual input is f32 only,
+            // so the sum is formed by a dedicated add below.
+            GemmArgs g2{};
+            g2.A = tmp; g2.lda = 4 * H; g2.a_bs = (long)T * 4 * H;
+            g2.W = TP(m, q + "pw2.w"); g2.bias = TPF(m, q + "pw2.b");
+            g2.C = m->cx; g2.ldc = H; g2.c_bs = (long)T * H;
+            g2.M = B * T; g2.N = H; g2.K = 4 * H; g2.G = T; g2.ab_dtype = dt; g2.c_dtype = S2S_F32; g2.act = S2S_ACT_NONE;
+            if ((rc = gemm_ex(st, g2))) return done(rc);
+            // cur (padded, model dtype) += cx (f32, unpadded)
+            if ((rc = add_f32_into_padded(st, cur, m->cx, B, T, H, LPAD, dt))) return done(rc);
+        }
+    }
+    // decoder.0: causal conv k7 H -> Dd
+    int C = c.c_decoder_dim;
+    if ((rc = conv_gemm(m, st, cur, T, H, 7, 1, "codec.dec.in.w", "codec.dec.in.b", alt, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+    std::swap(cur, alt);
+    for (int i = 0; i < c.n_dec_blocks; ++i) {
+        const std::string q = "codec.dec." + std::to_string(i) + ".";
+        const int r = c.up_rate[i], Co = C >> 1;
+        if ((rc = snake(st, cur, alt, TPF(m, q + "snake.a"), TPF(m, q + "snake.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+        // transposed conv k=2r, s=r, trimmed r on both sides: out[(t-1)*r + j] = x[t-1].W[j+r] + x[t].W[j], t = 1..T-1
+        {
+            GemmArgs g{};
+            g.A = at(alt, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;   // row t' = t-1 reads [x[t'] | x[t'+1]]
+            g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
+            g.C = at(tmp, (size_t)LPAD * Co * e); g.ldc = (long)r * Co; g.c_bs = (long)(LPAD + (T - 1) * r) * Co;
+            g.M = B * (T - 1); g.N = r * Co; g.K = 2 * C; g.G = T - 1; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+            if ((rc = gemm_ex(st, g))) return done(rc);
+        }
+        T = (T - 1) * r;
+        C = Co;
+        // x = tmp ; three residual units (dilations 1, 3, 9)
+        void* xbuf = tmp;
+        void* y1 = cur;
+        void* y2 = alt;
+        for (int j = 0; j < 3; ++j) {
+            const std::string u = q + "ru" + std::to_string(j) + ".";
+            const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
+            if ((rc = snake(st, xbuf, y1, TPF(m, u + "s1.a"), TPF(m, u + "s1.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+            if ((rc = conv_gemm(m, st, y1, T, C, 7, dil, u + "c1.w", u + "c1.b", y2, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+            if ((rc = snake(st, y2, y1, TPF(m, u + "s2.a"), TPF(m, u + "s2.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+            // 1x1 conv -> f32 scratch, then x += it
+            {
+                GemmArgs g{};
+                g.A = at(y1, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+                g.W = TP(m, u + "c2.w"); g.bias = TPF(m, u + "c2.b");
+                g.C = y2; g.ldc = C; g.c_bs = (long)T * C;     // unpadded model-dtype scratch
+                g.M = B * T; g.N = C; g.K = C; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+                if ((rc = gemm_ex(st, g))) return done(rc);
+                if ((rc = add_into_padded(st, xbuf, y2, B, T, C, LPAD, dt))) return done(rc);
+            }
+        }
+        // rotate buffers so that `cur` holds x
+        void* a0 = cur; void* a1 = alt;
+        cur = xbuf; alt = a0; tmp = a1;
+    }
+    // output: snake -> conv k7 C -> 1 (weights padded to 8 output channels), clamp
+    if ((rc = snake(st, cur, alt, TPF(m, "codec.dec.out.a"), TPF(m, "codec.dec.out.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+    if ((rc = conv_gemm(m, st, alt, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", tmp, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+    const long total = T;
+    const long skip = (long)ctx * c.total_upsample;
+    S2S_REQUIRE(n_samples == total - skip, "codec_decode: n_samples %d != %ld", n_samples, total - skip);
+    if ((rc = wav_out(st, tmp, wav_dev, B, T, LPAD, (int)skip, n_samples, dt))) return done(rc);
+    return done(S2S_OK);
+}
+
+extern "C" int64_t s2s_codec_samples(void* model, int32_t F) {
+    Tts* m = (Tts*)model;
+    if (!m) return 0;
+    return s2s::codec_len(m->cfg, F, m->cfg.n_dec_blocks);
+}

@@ -1,0 +1,320 @@
+// Kernels for the Qwen3-TTS path: decoder-stack helpers (RoPE + per-head q/k RMSNorm, KV append, SwiGLU),
+// code-embedding gathers for the talker / code-predictor loop, and the codec-decoder elementwise pieces
+// (SnakeBeta, causal depthwise conv + LayerNorm of the ConvNeXt block, clamp) plus the 24 kHz -> 16 kHz
+// polyphase resampler with int16 conversion of the reference's _stream() post-processing.
+#include "ops.h"
+
+#include <algorithm>
+
+namespace s2s {
+
+#define S2S_DT(TT_, ...)                                                    \
+    do {                                                                    \
+        if (dtype == S2S_BF16) { using TT_ = __hip_bfloat16; __VA_ARGS__; } \
+        else { using TT_ = float; __VA_ARGS__; }                            \
+    } while (0)
+
+// In-place on fused projection rows [rows][(H + 2*Hk) * D]: per head of q and k: optional RMSNorm over D
+// (weight qw / kw), then rotary embedding at position pos0[b] + t (row = b*T + t).  One wave per (row, head).
+// cos/sin: f32 [max_pos][D/2].  grid = (ceil((H+Hk)/4), rows), block 256.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_qknorm_kernel(T* __restrict__ qkv, int T_len, int H, int Hk, int D,
+                                                          const float* __restrict__ qw, const float* __restrict__ kw, float eps,
+                                                          const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                          const int* __restrict__ pos0) {
+    const int head = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (head >= H + Hk) return;
+    const int row = blockIdx.y, lane = threadIdx.x & 63;
+    const int b = row / T_len, t = row - b * T_len;
+    const int pos = (pos0 ? pos0[b] : 0) + t;
+    T* x = qkv + (long)row * (H + 2 * Hk) * D + (long)head * D;
+    const float* w = head < H ? qw : kw;
+    const int half = D >> 1;
+    float a = 0.f, c = 0.f;
+    if (lane < half) {
+        a = Elem<T>::ld(x + lane);
+        c = Elem<T>::ld(x + lane + half);
+    }
+    if (w) {
+        const float ss = wave_sum(a * a + c * c);
+        const float r = rsqrtf(ss / (float)D + eps);
+        if (lane < half) {
+            a = a * r * w[lane];
+            c = c * r * w[lane + half];
+        }
+    }
+    if (lane < half) {
+        const float cs = cosT[(long)pos * half + lane], sn = sinT[(long)pos * half + lane];
+        Elem<T>::st(x + lane, a * cs - c * sn);
+        Elem<T>::st(x + lane + half, c * cs + a * sn);
+    }
+}
+
+int rope_qknorm(hipStream_t st, void* qkv, int rows, int T_len, int H, int Hk, int D, const float* qw, const float* kw, float eps,
+                const float* cosT, const float* sinT, const int* pos0, int dtype) {
+    S2S_REQUIRE(D <= 128 && D % 2 == 0, "rope: head_dim %d unsupported", D);
+    dim3 grid(cdiv(H + Hk, 4), rows);
+    S2S_DT(TT, (rope_qknorm_kernel<TT><<<grid, 256, 0, st>>>((TT*)qkv, T_len, H, Hk, D, qw, kw, eps, cosT, sinT, pos0)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// cache[b][pos0[b] + t][:] = src row (b*T + t) columns [k_off, k_off + n) / [v_off, v_off + n)
+template <typename T>
+__global__ void kv_append_rows_kernel(const T* __restrict__ src, long src_rs, int k_off, int v_off, T* __restrict__ kc,
+                                      T* __restrict__ vc, long c_bs, const int* __restrict__ pos0, int T_len, int n) {
+    const int row = blockIdx.x;
+    const int b = row / T_len, t = row - b * T_len;
+    const long p = (pos0 ? pos0[b] : 0) + t;
+    const T* s = src + (long)row * src_rs;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        kc[(long)b * c_bs + p * n + i] = s[k_off + i];
+        vc[(long)b * c_bs + p * n + i] = s[v_off + i];
+    }
+}
+
+int kv_append_rows(hipStream_t st, const void* src, long src_rs, int k_off, int v_off, void* kc, void* vc, long c_bs,
+                   const int* pos0, int B, int T_len, int n, int dtype) {
+    S2S_DT(TT, (kv_append_rows_kernel<TT><<<B * T_len, 256, 0, st>>>((const TT*)src, src_rs, k_off, v_off, (TT*)kc, (TT*)vc, c_bs, pos0, T_len, n)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// out[r][c] = silu(gu[r][c]) * gu[r][ffn + c]
+template <typename T>
+__global__ void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, long rows, int ffn) {
+    const long total = rows * ffn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ffn;
+        const int c = (int)(i - r * ffn);
+        const float g = Elem<T>::ld(gu + r * 2 * ffn + c), u = Elem<T>::ld(gu + r * 2 * ffn + ffn + c);
+        Elem<T>::st(out + i, g / (1.0f + expf(-g)) * u);
+    }
+}
+
+int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dtype) {
+    const int blocks = (int)std::min<long>(cdiv(rows * ffn, 256), 4096);
+    S2S_DT(TT, (swiglu_kernel<TT><<<blocks, 256, 0, st>>>((const TT*)gu, (TT*)out, rows, ffn)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+__global__ void add_int_kernel(int* p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+int add_int(hipStream_t st, int* p, int v, int n) {
+    add_int_kernel<<<cdiv(n, 64), 64, 0, st>>>(p, v, n);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// dst[b][:] (f32, += when accumulate) = table[ids[b*id_stride] + id_offset][:]  (+ addvec)
+template <typename T>
+__global__ void gather_embed_kernel(const T* __restrict__ table, const int* __restrict__ ids, int id_stride, int id_offset,
+                                    float* __restrict__ dst, long dst_rs, int dim, int accumulate, const T* __restrict__ addvec) {
+    const int b = blockIdx.x;
+    const long id = (long)ids[(long)b * id_stride] + id_offset;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        float v = id >= 0 ? Elem<T>::ld(table + id * dim + i) : 0.f;
+        if (addvec) v += Elem<T>::ld(addvec + i);
+        if (accumulate) v += dst[(long)b * dst_rs + i];
+        dst[(long)b * dst_rs + i] = v;
+    }
+}
+
+int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
+                 int dim, int accumulate, const void* addvec, int dtype) {
+    if (B == 0) return S2S_OK;
+    S2S_DT(TT, (gather_embed_kernel<TT><<<B, 256, 0, st>>>((const TT*)table, ids, id_stride, id_offset, dst, dst_rs, dim, accumulate, (const TT*)addvec)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// h[b][t][:] = mean_q table[q*cb + codes[b][t][q]][:]   (codes frame-major [B][F][Q]; negative codes count as 0)
+template <typename T>
+__global__ void code_embed_mean_kernel(const T* __restrict__ table, const int* __restrict__ codes, float* __restrict__ h, int Q,
+                                       int cb, int dim) {
+    const long row = blockIdx.x;
+    const int* c = codes + row * Q;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < Q; ++q) s += Elem<T>::ld(table + ((long)q * cb + max(c[q], 0)) * dim + i);
+        h[row * dim + i] = s / (float)Q;
+    }
+}
+
+int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* h, long rows, int Q, int cb, int dim, int dtype) {
+    S2S_DT(TT, (code_embed_mean_kernel<TT><<<(unsigned)rows, 256, 0, st>>>((const TT*)table, codes, h, Q, cb, dim)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// ---- codec decoder elementwise -------------------------------------------------------------------------
+// Activation buffers are time-major with `lpad` zero rows in front of every item: [B][lpad + T][C].
+// SnakeBeta: y = x + sin^2(x * a) * invb, a = exp(alpha), invb = 1 / (exp(beta) + 1e-9)   (per channel)
+template <typename T>
+__global__ void snake_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ a, const float* __restrict__ invb,
+                             int Tn, int C, int lpad_in, int lpad_out) {
+    const int b = blockIdx.y;
+    const long total = (long)Tn * C;
+    const T* xb = x + ((long)b * (lpad_in + Tn) + lpad_in) * C;
+    T* yb = y + ((long)b * (lpad_out + Tn) + lpad_out) * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float v = Elem<T>::ld(xb + i);
+        const float s = sinf(v * a[c]);
+        Elem<T>::st(yb + i, v + s * s * invb[c]);
+    }
+}
+
+int snake(hipStream_t st, const void* x, void* y, const float* a, const float* invb, int B, int Tn, int C, int lpad_in, int lpad_out,
+          int dtype) {
+    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
+    S2S_DT(TT, (snake_kernel<TT><<<grid, 256, 0, st>>>((const TT*)x, (TT*)y, a, invb, Tn, C, lpad_in, lpad_out)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// ConvNeXt head: causal depthwise conv k7 over time (channels-last) followed by LayerNorm over channels.
+// x [B][lpad+T][C] -> y [B][T][C] (no padding, GEMM input).  One wave per output row; C <= 2048.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ g, const float* __restrict__ be, T* __restrict__ y,
+                                                         int Tn, int C, int lpad, float eps) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Tn) return;
+    const T* xb = x + ((long)b * (lpad + Tn) + lpad + t) * C;
+    constexpr int PER = 32;
+    float v[PER];
+    float s = 0.f;
+    const int n = (C + 63) / 64;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        v[u] = 0.f;
+        if (u < n) {
+            const int c = lane + u * 64;
+            if (c < C) {
+                float acc = bias[c];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) acc = fmaf(w[c * 7 + k], Elem<T>::ld(xb + (long)(k - 6) * C + c), acc);
+                v[u] = acc;
+                s += acc;
+            }
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (u < n && lane + u * 64 < C) {
+            const float d = v[u] - mean;
+            q += d * d;
+        }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    T* yb = y + ((long)b * Tn + t) * C;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (u < n) {
+            const int c = lane + u * 64;
+            if (c < C) Elem<T>::st(yb + c, (v[u] - mean) * rstd * g[c] + be[c]);
+        }
+}
+
+int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias, const float* g, const float* be, void* y, int B,
+               int Tn, int C, int lpad, float eps, int dtype) {
+    S2S_REQUIRE(C <= 2048 && lpad >= 6, "convnext: C=%d lpad=%d unsupported", C, lpad);
+    dim3 grid(cdiv(Tn, 4), B);
+    S2S_DT(TT, (dwconv7_ln_kernel<TT><<<grid, 256, 0, st>>>((const TT*)x, w, bias, g, be, (TT*)y, Tn, C, lpad, eps)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// x[b][lpad + t][c] += y[b][t][c]   (y unpadded, f32 or model dtype)
+template <typename T, typename Y>
+__global__ void add_into_padded_kernel(T* __restrict__ x, const Y* __restrict__ y, int Tn, int C, int lpad) {
+    const int b = blockIdx.y;
+    const long total = (long)Tn * C;
+    T* xb = x + ((long)b * (lpad + Tn) + lpad) * C;
+    const Y* yb = y + (long)b * total;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        Elem<T>::st(xb + i, Elem<T>::ld(xb + i) + Elem<Y>::ld(yb + i));
+}
+
+int add_f32_into_padded(hipStream_t st, void* x, const float* y, int B, int Tn, int C, int lpad, int dtype) {
+    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
+    S2S_DT(TT, (add_into_padded_kernel<TT, float><<<grid, 256, 0, st>>>((TT*)x, y, Tn, C, lpad)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype) {
+    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
+    S2S_DT(TT, (add_into_padded_kernel<TT, TT><<<grid, 256, 0, st>>>((TT*)x, (const TT*)y, Tn, C, lpad)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// wav[b][i] = clamp(x[b][lpad + skip + i][0], -1, 1) for i < n
+template <typename T>
+__global__ void wav_out_kernel(const T* __restrict__ x, float* __restrict__ wav, int Tn, int lpad, int skip, int n) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        wav[(long)b * n + i] = fminf(fmaxf(Elem<T>::ld(x + (long)b * (lpad + Tn) + lpad + skip + i), -1.f), 1.f);
+}
+
+int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, int skip, int n, int dtype) {
+    if (n <= 0) return S2S_OK;
+    dim3 grid(std::min(cdiv(n, 256), 1024), B);
+    S2S_DT(TT, (wav_out_kernel<TT><<<grid, 256, 0, st>>>((const TT*)x, wav, Tn, lpad, skip, n)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// ---- 24 kHz -> 16 kHz: scipy.signal.resample_poly(x, up=2, down=3) per chunk, then clip(x*32768) -> int16 ---
+// y[m] = sum_k h[k] * xup[3m + off - k], xup[2i] = x[i]; h (taps, host-designed) includes the gain `up`.
+__global__ void resample_2_3_int16_kernel(const float* __restrict__ x, long x_bs, const int* __restrict__ n_in, const float* __restrict__ h,
+                                          int taps, int off, short* __restrict__ y16, float* __restrict__ yf, long y_bs, int n_out_max) {
+    const int b = blockIdx.y;
+    const int n = n_in ? n_in[b] : (int)x_bs;
+    const int n_out = (2 * n + 2) / 3;   // ceil(2n/3)
+    const float* xb = x + (long)b * x_bs;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n_out_max; m += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        if (m < n_out) {
+            const int c = 3 * m + off;
+            // k runs over taps with (c - k) even and 0 <= (c-k)/2 < n
+            for (int k = (c & 1); k < taps; k += 2) {
+                const int i = (c - k) >> 1;
+                if (c - k >= 0 && i < n) acc = fmaf(h[k], xb[i], acc);
+            }
+        }
+        if (yf) yf[(long)b * y_bs + m] = acc;
+        if (y16) {
+            const float s = fminf(fmaxf(acc * 32768.0f, -32768.0f), 32767.0f);
+            y16[(long)b * y_bs + m] = (short)s;   // truncation toward zero == numpy astype(int16)
+        }
+    }
+}
+
+int resample_2_3_int16(hipStream_t st, const float* x, long x_bs, const int* n_in, const float* h, int taps, int off, short* y16,
+                       float* yf, long y_bs, int n_out_max, int B) {
+    if (B == 0 || n_out_max <= 0) return S2S_OK;
+    dim3 grid(std::min(cdiv(n_out_max, 256), 1024), B);
+    resample_2_3_int16_kernel<<<grid, 256, 0, st>>>(x, x_bs, n_in, h, taps, off, y16, yf, y_bs, n_out_max);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+}  // namespace s2s
+
+extern "C" int32_t s2s_resample_24k16k_int16(void* stream, const float* pcm24_dev, int64_t in_stride, const int32_t* n_in_dev,
+                                             const float* fir_dev, int32_t taps, int32_t delay, int16_t* out16_dev, float* outf_dev,
+                                             int64_t out_stride, int32_t n_out_max, int32_t B) {
+    S2S_REQUIRE(pcm24_dev && fir_dev && (out16_dev || outf_dev) && taps > 0, "resample: null argument");
+    return s2s::resample_2_3_int16((hipStream_t)stream, pcm24_dev, (long)in_stride, n_in_dev, fir_dev, taps, delay, (short*)out16_dev,
+                                   outf_dev, (long)out_stride, n_out_max, B);
+}

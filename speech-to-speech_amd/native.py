@@ -35,6 +35,18 @@ class ParakeetConfigStruct(C.Structure):
                                           "vocab", "dec_hidden", "dec_layers", "n_durations", "max_feat_frames", "dtype")]
 
 
+class TTSConfigStruct(C.Structure):
+    """Mirror of ``s2s_tts_config``."""
+
+    _fields_ = ([(n, C.c_int32) for n in ("t_hidden", "t_layers", "t_heads", "t_kv_heads", "t_head_dim", "t_ffn", "codec_vocab",
+                                           "codec_eos", "p_hidden", "p_layers", "p_heads", "p_kv_heads", "p_head_dim", "p_ffn",
+                                           "n_groups", "codebook", "c_hidden", "c_layers", "c_heads", "c_ffn", "c_window",
+                                           "c_decoder_dim", "n_dec_blocks")]
+                + [("up_rate", C.c_int32 * 4), ("up_ratio", C.c_int32 * 2)]
+                + [(n, C.c_int32) for n in ("total_upsample", "max_prompt", "max_frames", "max_pos", "max_codec_frames")]
+                + [("eps", C.c_float), ("c_eps", C.c_float), ("dtype", C.c_int32)])
+
+
 class NativeError(RuntimeError):
     """A libs2s_mi355x call failed (status code + the library's message)."""
 
@@ -78,10 +90,21 @@ _SIGNATURES = {
     "s2s_parakeet_encode": [_vp, _vp, _vp, _vp, _i32, _i32],
     "s2s_parakeet_read_encoder_output": [_vp, _vp, _vp, _vp],
     "s2s_parakeet_tdt_greedy": [_vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "s2s_tts_create": [_vp, _i32, C.POINTER(_vp)],
+    "s2s_tts_destroy": [_vp],
+    "s2s_tts_set_tensor": [_vp, C.c_char_p, _vp, _i64],
+    "s2s_tts_finalize": [_vp],
+    "s2s_tts_workspace_bytes": [_vp],
+    "s2s_tts_prefill": [_vp, _vp, _vp, _vp, _i32, _i32],
+    "s2s_tts_generate": [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
+    "s2s_codec_decode": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32],
+    "s2s_codec_samples": [_vp, _i32],
+    "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
-             "s2s_parakeet_workspace_bytes": C.c_int64}
+             "s2s_parakeet_workspace_bytes": C.c_int64, "s2s_tts_workspace_bytes": C.c_int64,
+             "s2s_codec_samples": C.c_int64}
 
 
 def load():

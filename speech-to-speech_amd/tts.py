@@ -1,0 +1,319 @@
+"""Host side of the Qwen3-TTS engine (device graph: csrc/tts.cpp, kernels csrc/tts.hip).
+
+WEIGHT LAYOUT handed to ``s2s_tts_set_tensor`` (``W`` = model dtype; norms / biases / tables float32):
+
+  decoder stacks, prefix in {talker, pred, codec}, layer L:
+    <p>.L.ln1 [hid]   <p>.L.qkv.w [(H+2Hk)*D][hid] W = q|k|v   <p>.L.qnorm / .knorm [D] (talker, pred)
+    <p>.L.o.w [hid][H*D] W   <p>.L.ln2 [hid]   <p>.L.gu.w [2*ffn][hid] W = gate|up   <p>.L.down.w [hid][ffn] W
+    (codec: the LayerScale vectors are folded into the rows of o.w and down.w)
+    <p>.rope.cos / .rope.sin  [max_pos][D/2]
+  talker.norm  talker.emb [codec_vocab][E] W  talker.head.w [codec_vocab][E] W  talker.pad_embed [E] W
+  talker.eos_mask uint8 [codec_vocab]
+  pred.norm  pred.in_proj.{w [P][E] W, b} (only when P != E)  pred.emb.g [codebook][E] W  pred.head.g.w [codebook][P] W
+  codec.emb [codebook*G][H] W   codec.norm [H]
+  codec.up.i: tconv.w [r*H][H] W (row j*H+o = W[:, o, j])  tconv.b [r*H]  dw.w [H][7]  dw.b  ln.{g,b}
+              pw1.{w [4H][H] W, b}  pw2.{w [H][4H] W, b} with gamma folded in
+  codec.dec.in.{w [Dd][7*H] W tap-major, b}
+  codec.dec.i: snake.{a = exp(alpha), ib = 1/(exp(beta)+1e-9)}  tconv.w [r*Co][2*C] W (row j*Co+o = [W[:,o,j+r] | W[:,o,j]])
+               tconv.b [r*Co]   ruJ.{s1.a, s1.ib, c1.w [Co][7*Co] W tap-major, c1.b, s2.a, s2.ib, c2.w [Co][Co] W, c2.b}
+  codec.dec.out.{a, ib, w [1][7*co] W, b [1]}
+
+Prompt layout: the real Qwen3-TTS chat template / speaker table / language tags live in the unavailable qwen_tts
+package (SURVEY.md 8a'); prompts are therefore assembled from explicit (text-side, codec-side) embedding rows behind
+``TTSPrompt`` and exercised with synthetic prompts.  ``non_streaming_mode=True`` semantics: the whole text is prefilled,
+every generated frame adds ``tts_pad_embed``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterator, Mapping, Sequence
+
+import numpy as np
+import torch
+
+from . import native
+from .synth_weights import Qwen3TTSDims
+
+PIPELINE_SR = 16000
+CODEC_SR = 24000
+BLOCKSIZE = 512
+
+
+def rope_cos_sin(max_pos: int, head_dim: int, theta: float):
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous(), fr.sin().contiguous()
+
+
+def _stack(out, sd, src, dst, layers, dtype, layer_scale=False, qk_norm=True):
+    W = lambda t: t.to(dtype).contiguous()            # noqa: E731
+    F32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+    for l in range(layers):
+        p, q = f"{src}layers.{l}.", f"{dst}{l}."
+        out[q + "ln1"] = F32(sd[p + "input_layernorm.weight"])
+        out[q + "qkv.w"] = W(torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0))
+        if qk_norm:
+            out[q + "qnorm"] = F32(sd[p + "self_attn.q_norm.weight"])
+            out[q + "knorm"] = F32(sd[p + "self_attn.k_norm.weight"])
+        ow, dw = sd[p + "self_attn.o_proj.weight"], sd[p + "mlp.down_proj.weight"]
+        if layer_scale:
+            ow = ow * sd[p + "self_attn_layer_scale.scale"][:, None]
+            dw = dw * sd[p + "mlp_layer_scale.scale"][:, None]
+        out[q + "o.w"] = W(ow)
+        out[q + "ln2"] = F32(sd[p + "post_attention_layernorm.weight"])
+        out[q + "gu.w"] = W(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0))
+        out[q + "down.w"] = W(dw)
+
+
+def convert_tts_state_dict(sd: Mapping[str, torch.Tensor], dims: Qwen3TTSDims, dtype: torch.dtype, max_pos: int,
+                           max_codec_frames: int, pad_embed: torch.Tensor) -> dict[str, torch.Tensor]:
+    out: dict[str, torch.Tensor] = {}
+    W = lambda t: t.to(dtype).contiguous()            # noqa: E731
+    F32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+    _stack(out, sd, "talker.model.", "talker.", dims.t_layers, dtype)
+    _stack(out, sd, "code_predictor.model.", "pred.", dims.p_layers, dtype)
+    _stack(out, sd, "code2wav.pre_transformer.", "codec.", dims.c_layers, dtype, layer_scale=True, qk_norm=False)
+    for pre, n, hd, th in (("talker.", max_pos, dims.t_head_dim, dims.t_theta), ("pred.", dims.n_groups + 1, dims.p_head_dim, dims.p_theta),
+                           ("codec.", max_codec_frames, dims.c_hidden // dims.c_heads, dims.c_theta)):
+        out[pre + "rope.cos"], out[pre + "rope.sin"] = rope_cos_sin(n, hd, th)
+    out["talker.norm"] = F32(sd["talker.model.norm.weight"])
+    out["talker.emb"] = W(sd["talker.model.codec_embedding.weight"])
+    out["talker.head.w"] = W(sd["talker.codec_head.weight"])
+    out["talker.pad_embed"] = W(pad_embed)
+    eos = torch.zeros(dims.codec_vocab, dtype=torch.uint8)
+    eos[dims.codec_eos] = 1
+    out["talker.eos_mask"] = eos
+    out["pred.norm"] = F32(sd["code_predictor.model.norm.weight"])
+    if dims.p_hidden != dims.t_hidden:
+        out["pred.in_proj.w"] = W(sd["code_predictor.in_proj.weight"])
+        out["pred.in_proj.b"] = F32(sd["code_predictor.in_proj.bias"])
+    for g in range(dims.n_groups - 1):
+        out[f"pred.emb.{g}"] = W(sd[f"code_predictor.model.codec_embedding.{g}.weight"])
+        out[f"pred.head.{g}.w"] = W(sd[f"code_predictor.lm_head.{g}.weight"])
+    c = "code2wav."
+    H = dims.c_hidden
+    out["codec.emb"] = W(sd[c + "code_embedding.weight"])
+    out["codec.norm"] = F32(sd[c + "pre_transformer.norm.weight"])
+    for i, r in enumerate(dims.upsampling_ratios):
+        s, q = f"{c}upsample.{i}.", f"codec.up.{i}."
+        tw = sd[s + "0.conv.weight"]                              # [Cin][Cout][r]
+        out[q + "tconv.w"] = W(tw.permute(2, 1, 0).reshape(r * H, H))
+        out[q + "tconv.b"] = F32(sd[s + "0.conv.bias"].repeat(r))
+        out[q + "dw.w"] = F32(sd[s + "1.dwconv.conv.weight"].reshape(H, 7)); out[q + "dw.b"] = F32(sd[s + "1.dwconv.conv.bias"])
+        out[q + "ln.g"] = F32(sd[s + "1.norm.weight"]); out[q + "ln.b"] = F32(sd[s + "1.norm.bias"])
+        out[q + "pw1.w"] = W(sd[s + "1.pwconv1.weight"]); out[q + "pw1.b"] = F32(sd[s + "1.pwconv1.bias"])
+        gam = sd[s + "1.gamma"]
+        out[q + "pw2.w"] = W(sd[s + "1.pwconv2.weight"] * gam[:, None]); out[q + "pw2.b"] = F32(sd[s + "1.pwconv2.bias"] * gam)
+    d = c + "decoder."
+
+    def conv_w(w):   # [Cout][Cin][k] -> [Cout][k*Cin] tap-major
+        return W(w.permute(0, 2, 1).reshape(w.shape[0], -1))
+
+    def snake(dst, a, b):
+        out[dst + ".a"] = F32(torch.exp(sd[a])); out[dst + ".ib"] = F32(1.0 / (torch.exp(sd[b]) + 1e-9))
+
+    out["codec.dec.in.w"] = conv_w(sd[d + "0.conv.weight"]); out["codec.dec.in.b"] = F32(sd[d + "0.conv.bias"])
+    for i, r in enumerate(dims.upsample_rates):
+        s, q = f"{d}{i + 1}.block.", f"codec.dec.{i}."
+        snake(q + "snake", s + "0.alpha", s + "0.beta")
+        tw = sd[s + "1.conv.weight"]                              # [Cin][Cout][2r]
+        cin, cout = tw.shape[0], tw.shape[1]
+        early, late = tw[:, :, r:], tw[:, :, :r]                  # tap on x[t-1] / on x[t]
+        wcat = torch.cat([early.permute(2, 1, 0), late.permute(2, 1, 0)], dim=2)   # [r][Cout][2*Cin]
+        out[q + "tconv.w"] = W(wcat.reshape(r * cout, 2 * cin))
+        out[q + "tconv.b"] = F32(sd[s + "1.conv.bias"].repeat(r))
+        for j in range(3):
+            u, v = f"{s}{j + 2}.", f"{q}ru{j}."
+            snake(v + "s1", u + "act1.alpha", u + "act1.beta")
+            out[v + "c1.w"] = conv_w(sd[u + "conv1.conv.weight"]); out[v + "c1.b"] = F32(sd[u + "conv1.conv.bias"])
+            snake(v + "s2", u + "act2.alpha", u + "act2.beta")
+            out[v + "c2.w"] = W(sd[u + "conv2.conv.weight"].reshape(cout, cout)); out[v + "c2.b"] = F32(sd[u + "conv2.conv.bias"])
+    n = len(dims.upsample_rates) + 1
+    snake("codec.dec.out", f"{d}{n}.alpha", f"{d}{n}.beta")
+    out["codec.dec.out.w"] = conv_w(sd[f"{d}{n + 1}.conv.weight"]); out["codec.dec.out.b"] = F32(sd[f"{d}{n + 1}.conv.bias"])
+    return out
+
+
+def resample_fir_2_3(dtype=np.float32) -> np.ndarray:
+    """The prototype low-pass scipy.signal.resample_poly(x, 2, 3) designs (firwin(61, 1/3, kaiser 5.0) * up)."""
+    from scipy.signal import firwin
+
+    half_len = 10 * 3
+    return (firwin(2 * half_len + 1, 1.0 / 3.0, window=("kaiser", 5.0)) * 2.0).astype(dtype)
+
+
+@dataclass
+class TTSPrompt:
+    """Prefill rows of one utterance: float32 [P, t_hidden] (text-side + codec-side embeddings already summed)."""
+
+    embeds: np.ndarray
+
+
+class AudioBlocker:
+    """The reference's per-utterance output shaping (Qwen3TTSHandler._stream, TTS/qwen3_tts_handler.py:716-742):
+    drop the leading silence (|x| <= 0.01*32768) keeping 40 ms of pre-roll, re-block to 512 samples, pad the tail."""
+
+    def __init__(self, blocksize: int = BLOCKSIZE):
+        self.blocksize = blocksize
+        self.found_speech = False
+        self.leftover = np.array([], dtype=np.int16)
+
+    def push(self, chunk16: np.ndarray) -> Iterator[np.ndarray]:
+        if not self.found_speech:
+            threshold = int(32768 * 0.01)
+            above = np.abs(chunk16) > threshold
+            if not np.any(above):
+                return
+            start_idx = max(0, int(np.argmax(above)) - int(PIPELINE_SR * 0.040))
+            chunk16 = chunk16[start_idx:]
+            self.found_speech = True
+        chunk16 = np.concatenate([self.leftover, chunk16])
+        n = (len(chunk16) // self.blocksize) * self.blocksize
+        for i in range(0, n, self.blocksize):
+            yield chunk16[i : i + self.blocksize]
+        self.leftover = chunk16[n:]
+
+    def flush(self) -> Iterator[np.ndarray]:
+        if len(self.leftover) > 0:
+            yield np.pad(self.leftover, (0, self.blocksize - len(self.leftover)))
+            self.leftover = np.array([], dtype=np.int16)
+
+
+class TTSEngine:
+    """One Qwen3-TTS replica on one GPU: batched talker/code-predictor frame loop, chunked codec decode, resample."""
+
+    def __init__(self, dims: Qwen3TTSDims, state_dict: Mapping[str, torch.Tensor] | None, dtype: torch.dtype = torch.bfloat16,
+                 max_batch: int = 8, max_prompt: int = 128, max_frames: int = 1536, max_codec_frames: int = 33,
+                 pad_embed: torch.Tensor | None = None, device: str | torch.device = "cuda:0",
+                 engine_tensors: Mapping[str, torch.Tensor] | None = None):
+        self.dims, self.dtype, self.max_batch = dims, dtype, int(max_batch)
+        self.device = torch.device(device)
+        self.max_prompt, self.max_frames, self.max_codec_frames = int(max_prompt), int(max_frames), int(max_codec_frames)
+        self.max_pos = self.max_prompt + self.max_frames
+        self._lib = native.load()
+        cfg = native.TTSConfigStruct()
+        for k in ("t_hidden", "t_layers", "t_heads", "t_kv_heads", "t_head_dim", "t_ffn", "codec_vocab", "codec_eos", "p_hidden", "p_layers",
+                  "p_heads", "p_kv_heads", "p_head_dim", "p_ffn", "n_groups", "codebook", "c_hidden", "c_layers", "c_heads", "c_ffn", "c_window"):
+            setattr(cfg, k, int(getattr(dims, k)))
+        cfg.c_decoder_dim = dims.c_decoder_dim
+        cfg.n_dec_blocks = len(dims.upsample_rates)
+        for i, r in enumerate(dims.upsample_rates):
+            cfg.up_rate[i] = int(r)
+        for i, r in enumerate(dims.upsampling_ratios):
+            cfg.up_ratio[i] = int(r)
+        cfg.total_upsample = dims.total_upsample
+        cfg.max_prompt, cfg.max_frames, cfg.max_pos, cfg.max_codec_frames = self.max_prompt, self.max_frames, self.max_pos, self.max_codec_frames
+        cfg.eps, cfg.c_eps, cfg.dtype = dims.eps, dims.c_eps, native.dtype_code(dtype)
+        h = C.c_void_p()
+        native.check(self._lib.s2s_tts_create(C.byref(cfg), self.max_batch, C.byref(h)), "s2s_tts_create")
+        self._h = h
+        if pad_embed is None:
+            pad_embed = torch.zeros(dims.t_hidden)
+        self._weights = {}
+        with torch.cuda.device(self.device):
+            tensors = engine_tensors if engine_tensors is not None else convert_tts_state_dict(
+                state_dict, dims, dtype, self.max_pos, self.max_codec_frames, pad_embed)
+            for name, t in tensors.items():
+                dt = t.to(self.device)
+                self._weights[name] = dt
+                native.check(self._lib.s2s_tts_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
+            native.check(self._lib.s2s_tts_finalize(h), "s2s_tts_finalize")
+            self._fir = torch.from_numpy(resample_fir_2_3()).to(self.device)
+        self._B = 0
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.s2s_tts_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2s_tts_destroy(self._h)
+            self._h = None
+
+    # ---- stages --------------------------------------------------------------------------------------
+    def prefill(self, prompts: Sequence[TTSPrompt]) -> None:
+        B = len(prompts)
+        lens = [p.embeds.shape[0] for p in prompts]
+        Tp = max(lens)
+        host = torch.zeros((B, Tp, self.dims.t_hidden), dtype=torch.float32)
+        for i, p in enumerate(prompts):
+            host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(p.embeds, dtype=np.float32))
+        emb = host.to(self.device)
+        ln = torch.tensor(lens, dtype=torch.int32).to(self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_prefill(self._h, native.stream_handle(), native.ptr(emb), native.ptr(ln), B, Tp), "s2s_tts_prefill")
+        self._B = B
+        self._keep = (emb, ln)
+
+    def generate(self, n_frames: int, min_total_frames: int = 0, check_done: bool = True):
+        """-> (codes int32 [B][n_frames][G] on the GPU, valid frames so far per session (numpy), all_done)."""
+        B, G = self._B, self.dims.n_groups
+        codes = torch.empty((B, n_frames, G), dtype=torch.int32, device=self.device)
+        nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
+        done = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_generate(self._h, native.stream_handle(), n_frames, int(min_total_frames), native.ptr(codes),
+                                                    native.ptr(nfr), C.byref(done) if check_done else None), "s2s_tts_generate")
+        return codes, nfr, bool(done.value)
+
+    def codec_samples(self, F: int) -> int:
+        return int(self._lib.s2s_codec_samples(self._h, F))
+
+    def codec_decode(self, codes: torch.Tensor, ctx: int = 0) -> torch.Tensor:
+        """codes int32 [B][F][G] (first ctx frames = left context) -> float32 [B][n] 24 kHz samples of the new frames."""
+        B, F, _ = codes.shape
+        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        n = self.codec_samples(F) - ctx * self.dims.total_upsample
+        wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_codec_decode(self._h, native.stream_handle(), native.ptr(codes), B, F, ctx, native.ptr(wav), n), "s2s_codec_decode")
+        return wav
+
+    def resample_int16(self, wav24: torch.Tensor, n_valid: torch.Tensor | None = None, want_float: bool = False):
+        """Per-row scipy.signal.resample_poly(x, 2, 3) then clip(x*32768).astype(int16) -> int16 [B][ceil(2n/3)]."""
+        B, n = wav24.shape
+        n_out = (2 * n + 2) // 3
+        out16 = torch.empty((B, n_out), dtype=torch.int16, device=self.device)
+        outf = torch.empty((B, n_out), dtype=torch.float32, device=self.device) if want_float else None
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_resample_24k16k_int16(native.stream_handle(), native.ptr(wav24), wav24.stride(0), native.ptr(n_valid),
+                                                            native.ptr(self._fir), self._fir.numel(), (self._fir.numel() - 1) // 2,
+                                                            native.ptr(out16), native.ptr(outf), n_out, n_out, B), "s2s_resample_24k16k_int16")
+        return (out16, outf) if want_float else out16
+
+    # ---- utterance-level streaming (what the handler consumes) ------------------------------------------
+    def stream(self, prompts: Sequence[TTSPrompt], max_new_tokens: Sequence[int], chunk_size: int = 8, ctx_frames: int = 25,
+               min_frames: int = 0) -> Iterator[list[np.ndarray | None]]:
+        """Yields, every `chunk_size` frames, one int16 16 kHz numpy chunk per session (None once a session ended)."""
+        B = len(prompts)
+        self.prefill(prompts)
+        budget = max(max_new_tokens)
+        history = torch.empty((B, 0, self.dims.n_groups), dtype=torch.int32, device=self.device)
+        produced = 0
+        while produced < budget:
+            n = min(chunk_size, budget - produced)
+            codes, nfr, all_done = self.generate(n, min_total_frames=min_frames)
+            nfr_h = nfr.cpu().numpy()
+            history = torch.cat([history, codes], 1)
+            ctx = min(ctx_frames, produced)
+            window = history[:, produced - ctx : produced + n].contiguous()
+            wav = self.codec_decode(window.clamp(min=0), ctx)
+            pcm16 = self.resample_int16(wav).cpu().numpy()
+            out: list[np.ndarray | None] = []
+            for b in range(B):
+                valid = int(min(nfr_h[b], max_new_tokens[b])) - produced
+                if valid <= 0:
+                    out.append(None)
+                    continue
+                if valid >= n:
+                    out.append(pcm16[b])
+                else:
+                    # the utterance ended inside this chunk: keep only the samples of its valid frames
+                    keep = (2 * (self.codec_samples(ctx + valid) - ctx * self.dims.total_upsample) + 2) // 3
+                    out.append(pcm16[b][:keep])
+            produced += n
+            yield out
+            if all_done:
+                break
