@@ -532,6 +532,11 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
     m->cur_B = B;
     int rc;
     auto done = [&](int r) { m->cur_B = saveB; return r; };
+    // a buffer is reused with a different [T][C] geometry at every stage: re-establish its LPAD zero rows first
+    auto prep = [&](void* buf, int Tn, int Cn) -> int {
+        hipError_t er = hipMemset2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, 0, (size_t)LPAD * Cn * e, B, st);
+        return er == hipSuccess ? S2S_OK : fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(er));
+    };
     // code embeddings -> sliding-window transformer
     if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
     if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, nullptr, F, nullptr))) return done(rc);
@@ -539,6 +544,7 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
     {
         // rmsnorm writes contiguous rows; place them behind the LPAD rows of every item with a strided copy
         if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
+        if ((rc = prep(m->ca, F, H))) return done(rc);
         S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,
                                        hipMemcpyDeviceToDevice, st));
     }
@@ -553,6 +559,7 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
         g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
         g.C = at(alt, (size_t)LPAD * H * e); g.ldc = (long)r * H; g.c_bs = (long)(LPAD + T * r) * H;
         g.M = B * T; g.N = r * H; g.K = H; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+        if ((rc = prep(alt, T * r, H))) return done(rc);
         if ((rc = gemm_ex(st, g))) return done(rc);
         T *= r;
         std::swap(cur, alt);
@@ -574,12 +581,15 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
     }
     // decoder.0: causal conv k7 H -> Dd
     int C = c.c_decoder_dim;
+    if ((rc = prep(alt, T, C))) return done(rc);
     if ((rc = conv_gemm(m, st, cur, T, H, 7, 1, "codec.dec.in.w", "codec.dec.in.b", alt, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
     std::swap(cur, alt);
     for (int i = 0; i < c.n_dec_blocks; ++i) {
         const std::string q = "codec.dec." + std::to_string(i) + ".";
         const int r = c.up_rate[i], Co = C >> 1;
+        if ((rc = prep(alt, T, C))) return done(rc);
         if ((rc = snake(st, cur, alt, TPF(m, q + "snake.a"), TPF(m, q + "snake.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+        if ((rc = prep(tmp, (T - 1) * r, Co))) return done(rc);
         // transposed conv k=2r, s=r, trimmed r on both sides: out[(t-1)*r + j] = x[t-1].W[j+r] + x[t].W[j], t = 1..T-1
         {
             GemmArgs g{};
@@ -595,6 +605,7 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
         void* xbuf = tmp;
         void* y1 = cur;
         void* y2 = alt;
+        if ((rc = prep(y1, T, C)) || (rc = prep(y2, T, C))) return done(rc);
         for (int j = 0; j < 3; ++j) {
             const std::string u = q + "ru" + std::to_string(j) + ".";
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
@@ -617,6 +628,7 @@ extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* co
         cur = xbuf; alt = a0; tmp = a1;
     }
     // output: snake -> conv k7 C -> 1 (weights padded to 8 output channels), clamp
+    if ((rc = prep(alt, T, C)) || (rc = prep(tmp, T, 1))) return done(rc);
     if ((rc = snake(st, cur, alt, TPF(m, "codec.dec.out.a"), TPF(m, "codec.dec.out.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
     if ((rc = conv_gemm(m, st, alt, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", tmp, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
     const long total = T;

@@ -286,11 +286,12 @@ __global__ void resample_2_3_int16_kernel(const float* __restrict__ x, long x_bs
         float acc = 0.f;
         if (m < n_out) {
             const int c = 3 * m + off;
-            // k runs over taps with (c - k) even and 0 <= (c-k)/2 < n
-            for (int k = (c & 1); k < taps; k += 2) {
-                const int i = (c - k) >> 1;
-                if (c - k >= 0 && i < n) acc = fmaf(h[k], xb[i], acc);
-            }
+            // taps k = c - 2i with 0 <= k < taps; accumulate oldest sample first with separately rounded multiply
+            // and add - the order and rounding of scipy's upfirdn (float32), so the int16 truncation matches it
+            int i_lo = c - taps + 1;
+            i_lo = i_lo <= 0 ? 0 : (i_lo + 1) >> 1;
+            const int i_hi = min(c >> 1, n - 1);
+            for (int i = i_lo; i <= i_hi; ++i) acc = __fadd_rn(acc, __fmul_rn(xb[i], h[c - 2 * i]));
         }
         if (yf) yf[(long)b * y_bs + m] = acc;
         if (y16) {
