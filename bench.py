@@ -28,6 +28,23 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md:42
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md:35
 
 
+def shard_sessions(per_gpu: int, rank: int) -> list[int]:
+    """Global session ids served by this rank's pool: rank r owns [r*per_gpu, (r+1)*per_gpu) - weak scaling, no exchange."""
+    return list(range(rank * per_gpu, (rank + 1) * per_gpu))
+
+
+def reduce_step_time(dt: float, device) -> float:
+    """The contract's cross-rank step: MAX over ranks of the timed region (the only collective in the job)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +175,7 @@ def main():
     B = args.sessions
     eng = WhisperEngine.from_random(dims, torch.bfloat16, max_batch=B, device=dev, seed=rank)
     n = int(args.utt_seconds * 16000)
-    audios = [synth_audio(n, rank * B + i) for i in range(B)]
+    audios = [synth_audio(n, sid) for sid in shard_sessions(B, rank)]
     pcm, ns = pack_pcm(audios, dev)            # inputs resident in HBM before the timed region
     lib = native.load()
     prompt = [[1, 2, 3, 4]] * B
@@ -200,12 +217,7 @@ def main():
         print(f"[breakdown] gemm_tile: {prof['ms'] / args.steps:.3f} ms/step over {prof['launches'] // args.steps} launches", file=sys.stderr)
     native.prof_enable()
     assert all(len(x) == args.decode_tokens for x in ids)
-    if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = reduce_step_time(dt, dev)
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3

@@ -1,0 +1,149 @@
+"""``--tts mi355x-qwen3``: drop-in for the reference's Qwen3TTSHandler (TTS/qwen3_tts_handler.py) on the MI355X session
+pool.  Kept from the reference contract (tests/test_qwen3_tts_handler_backend.py:505-735, 915-964):
+  * ``EndOfResponse`` -> ``AUDIO_RESPONSE_DONE``; never touches ``should_listen``;
+  * output = int16 numpy blocks of ``blocksize`` (512) samples @ 16 kHz, leading silence trimmed with 40 ms pre-roll,
+    tail zero-padded;
+  * the cancel generation captured at the start of the utterance is checked between chunks;
+  * the frame budget estimator (words / chars / CJK chars / punctuation -> seconds -> 12.5 Hz * 1.35 margin,
+    >= 360, multiple of the chunk size, <= cap) and the coalescing of already-queued TTSInputs of the same response."""
+
+from __future__ import annotations
+
+import logging
+import math
+import re
+import unicodedata
+from time import perf_counter
+from typing import Any, Iterator, Optional
+
+import numpy as np
+import torch
+
+from ..boundary import AUDIO_RESPONSE_DONE, BaseHandler, EndOfResponse, TTSInput
+from ..checkpoints import TTS_DIMS, load_safetensors_dir, parse_model_name
+from ..session_pool import SessionPool
+from ..text import ByteTextFrontend
+from ..tts import AudioBlocker, TTSPrompt
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_MAX_NEW_TOKENS = 1536
+MIN_UTTERANCE_TOKENS = 360
+TOKENS_PER_SECOND = 12.5
+WORDS_PER_SECOND, CHARS_PER_SECOND, CJK_CHARS_PER_SECOND = 2.6, 14.0, 5.5
+SAFETY_MARGIN, BASE_PROMPT_SECONDS, PUNCTUATION_PAUSE_SECONDS = 1.35, 1.0, 0.5
+CJK_PATTERN = re.compile(r"[぀-ヿ㐀-䶿一-鿿가-힯豈-﫿\U00020000-\U0002fa1f]")
+
+
+def estimate_max_new_tokens(text: Optional[str], chunk_size: int = 8, cap: int = DEFAULT_MAX_NEW_TOKENS) -> int:
+    """Codec-frame budget for one utterance (reference _estimate_max_new_tokens, TTS/qwen3_tts_handler.py:615-658)."""
+    text = (text or "").strip()
+    chunk_size, cap = max(1, int(chunk_size)), max(1, int(cap))
+    if not text:
+        return min(cap, MIN_UTTERANCE_TOKENS)
+    words = len(re.findall(r"\w+", text, flags=re.UNICODE))
+    chars = len(re.sub(r"\s+", "", text))
+    cjk = len(CJK_PATTERN.findall(text))
+    seconds = max(words / WORDS_PER_SECOND if words else 0.0, chars / CHARS_PER_SECOND if chars else 0.0,
+                  cjk / CJK_CHARS_PER_SECOND if cjk else 0.0)
+    seconds += sum(unicodedata.category(ch).startswith("P") for ch in text) * PUNCTUATION_PAUSE_SECONDS + BASE_PROMPT_SECONDS
+    tokens = math.ceil(seconds * TOKENS_PER_SECOND * SAFETY_MARGIN)
+    aligned = max(chunk_size, math.ceil(tokens / chunk_size) * chunk_size)
+    return min(cap, max(MIN_UTTERANCE_TOKENS, aligned))
+
+
+def build_tts_engine(model_name: str, device: str, dtype: str, max_batch: int, max_new_tokens: int, ctx_frames: int, chunk_size: int):
+    from ..synth_weights import _normal, qwen3_tts_state_dict
+    from ..tts import TTSEngine
+
+    kind, key, seed = parse_model_name(model_name)
+    if kind != "synthetic":
+        raise NotImplementedError("loading a real Qwen3-TTS checkpoint needs its (unavailable offline) config / prompt layout; "
+                                  "see DESIGN.md 'Qwen3-TTS assumptions'")
+    dims = TTS_DIMS[key]()
+    sd = qwen3_tts_state_dict(dims, seed=seed or 5)
+    pad = _normal(seed or 5, "tts_pad_embed", (dims.t_hidden,), 0.5)
+    eng = TTSEngine(dims, sd, dtype=getattr(torch, dtype), max_batch=max_batch, max_prompt=128, max_frames=max_new_tokens,
+                    max_codec_frames=ctx_frames + chunk_size, pad_embed=pad, device=device)
+    eng.text_frontend = ByteTextFrontend(_normal(seed or 5, "text_table", (258, dims.t_hidden), 1.0).numpy())
+    return eng
+
+
+class MI355XQwen3TTSHandler(BaseHandler):
+    def setup(self, should_listen: Any = None, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", dtype: str = "bfloat16",
+              speaker: str | None = None, language: str | None = "auto", instruct: str | None = None, streaming_chunk_size: int = 8,
+              max_new_tokens: int = DEFAULT_MAX_NEW_TOKENS, blocksize: int = 512, max_batch: int = 64, batch_window_ms: float = 4.0,
+              codec_context_frames: int = 25, cancel_scope: Any = None, speculative_turns: Any = None, gen_kwargs: dict | None = None,
+              pool: SessionPool | None = None, **_ignored: Any) -> None:
+        self.should_listen = should_listen          # owned by the reference runtime; never touched here
+        self.cancel_scope, self.speculative_turns = cancel_scope, speculative_turns
+        self.streaming_chunk_size, self.max_new_tokens, self.blocksize = int(streaming_chunk_size), int(max_new_tokens), int(blocksize)
+        self.speaker, self.language, self.instruct = speaker, language, instruct
+        self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms,
+                                                  tts_chunk_size=self.streaming_chunk_size, tts_ctx_frames=codec_context_frames)
+        self.pool.ensure_engine("tts", lambda: build_tts_engine(model_name, device, dtype, max_batch, self.max_new_tokens, codec_context_frames,
+                                                               self.streaming_chunk_size))
+
+    def _estimate_max_new_tokens(self, text: Optional[str]) -> int:
+        return estimate_max_new_tokens(text, self.streaming_chunk_size, self.max_new_tokens)
+
+    def _coalesce_pending_tts_input(self, current: Any) -> tuple[str, Optional[str]]:
+        """Merge already-queued TTSInputs of the same response into one synthesis call (reference :751-810)."""
+        q = self.queue_in
+        text, lang = current.text, current.language_code
+        if not hasattr(q, "mutex") or not hasattr(q, "queue"):
+            return text, lang
+        parts = [text.strip()] if text and text.strip() else []
+        with q.mutex:
+            while q.queue:
+                nxt = q.queue[0]
+                same = (isinstance(nxt, TTSInput) and nxt.response_key == current.response_key and nxt.cancel_generation == current.cancel_generation
+                        and nxt.turn_id == current.turn_id and nxt.prefetch_transaction is None)
+                if not same:
+                    break
+                q.queue.popleft()
+                if nxt.text and nxt.text.strip():
+                    parts.append(nxt.text.strip())
+                lang = nxt.language_code or lang
+        return " ".join(parts), lang
+
+    def _build_prompt(self, text: str) -> TTSPrompt:
+        eng = self.pool.engine("tts")
+        return TTSPrompt(eng.text_frontend.embed(text, eng.max_prompt))
+
+    def process(self, tts_input: Any) -> Iterator[Any]:
+        if isinstance(tts_input, EndOfResponse):
+            yield AUDIO_RESPONSE_DONE
+            return
+        if self.speculative_turns is not None and tts_input.turn_id is not None and hasattr(self.speculative_turns, "commit"):
+            if not self.speculative_turns.commit(tts_input.turn_id, tts_input.turn_revision):
+                return
+        text, _lang = self._coalesce_pending_tts_input(tts_input)
+        if not text or not text.strip():
+            return
+        gen = self.cancel_scope.generation if self.cancel_scope is not None else None
+        start = perf_counter()
+        try:
+            chunks, cancel = self.pool.synthesize(self._build_prompt(text), self._estimate_max_new_tokens(text))
+            blocker = AudioBlocker(self.blocksize)
+            first, total = True, 0
+            for chunk in chunks:
+                if gen is not None and self.cancel_scope.is_stale(gen):
+                    cancel.set()
+                    logger.info("TTS generation cancelled (interruption)")
+                    return
+                if first:
+                    logger.info("MI355X Qwen3-TTS TTFA: %.3fs", perf_counter() - start)
+                    if tts_input.speech_stopped_at_s is not None:
+                        logger.info("Last speech detected to first speech out: %.3fs", perf_counter() - tts_input.speech_stopped_at_s)
+                    first = False
+                for block in blocker.push(np.asarray(chunk, dtype=np.int16)):
+                    total += len(block)
+                    yield block
+            for block in blocker.flush():
+                total += len(block)
+                yield block
+            dt = perf_counter() - start
+            logger.info("MI355X Qwen3-TTS generated %.2fs audio in %.2fs (RTF: %.2f)", total / 16000, dt, (total / 16000) / dt if dt > 0 else 0)
+        except Exception as e:  # noqa: BLE001  (reference policy: generation failure -> no audio, thread keeps running)
+            logger.error("Qwen3-TTS generation failed: %s", e, exc_info=True)

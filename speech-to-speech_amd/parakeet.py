@@ -173,6 +173,12 @@ class ParakeetEngine:
         return ([t_h[b, : n_h[b]].tolist() for b in range(self._B)], [d_h[b, : n_h[b]].tolist() for b in range(self._B)],
                 [f_h[b, : n_h[b]].tolist() for b in range(self._B)])
 
+    def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
+        """SessionPool entry point: {"ids": non-blank token ids, "starts_s": start time of each token in seconds}."""
+        max_len = (self.max_feat_frames - 1) * 160
+        ids, starts = self.transcribe_ids([a[:max_len] if len(a) >= 1280 else np.pad(a, (0, 1280 - len(a))) for a in audios])
+        return [{"ids": i, "starts_s": [f * 0.08 for f in st]} for i, st in zip(ids, starts)]
+
     def transcribe_ids(self, audios: Sequence[np.ndarray]):
         """-> per session (non-blank token ids, start frame of each token [x 80 ms])."""
         feats, nf, _ = self.features(audios)

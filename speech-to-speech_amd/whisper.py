@@ -214,6 +214,21 @@ class WhisperEngine:
             return ids, filled, logits
         return ids, filled
 
+    def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
+        """SessionPool entry point: one dict per request {"ids": [...], "language": code | None}.
+        options per request: language (code | "auto" | None), max_new_tokens, vocab (text.WhisperVocab)."""
+        vocab = options[0]["vocab"]
+        max_new = max(int(o.get("max_new_tokens", 128)) for o in options)
+        prompts = [vocab.prompt(o.get("language")) for o in options]
+        self.encode(self.features(audios))
+        ids, filled = self.decode(prompts, vocab.eot, max_new, suppress=vocab.suppress, begin_suppress=vocab.begin_suppress,
+                                  lang_ids=list(vocab.lang_to_id.values()))
+        out = []
+        for i, o in enumerate(options):
+            n = int(o.get("max_new_tokens", 128))
+            out.append({"ids": ids[i][:n], "language": vocab.id_to_lang(filled[i][1])})
+        return out
+
     def transcribe_ids(self, audios: Sequence[np.ndarray], prompt: Sequence[int], eos: int, max_new_tokens: int = 128, **kw):
         self.encode(self.features(audios))
         return self.decode([list(prompt)] * len(audios), eos, max_new_tokens, **kw)

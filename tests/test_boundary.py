@@ -1,0 +1,198 @@
+"""Boundary-conformance tests (CPU, fake engines): the MI355X handlers honour the reference's handler contract
+(tests/test_backend_registry.py, test_stt_stale_filter.py, test_qwen3_tts_handler_backend.py:505-735,
+915-964, test_tts_input_coalescing.py) and the session pool batches concurrent pipeline units."""
+
+import importlib
+import sys
+import threading
+import time
+from queue import Queue
+from threading import Event
+
+import numpy as np
+import pytest
+
+from speech_to_speech_amd.boundary import (AUDIO_RESPONSE_DONE, PIPELINE_END, SESSION_END, AudioOutput, CancelScope, EndOfResponse,
+                                           PartialTranscription, Transcription, TTSInput, VADAudio)
+from speech_to_speech_amd.boundary import registry
+from speech_to_speech_amd.handlers.qwen3_tts import MI355XQwen3TTSHandler, estimate_max_new_tokens
+from speech_to_speech_amd.session_pool import SessionPool
+from speech_to_speech_amd.text import IdTextCodec, WhisperVocab
+
+
+class FakeSTTEngine:
+    def __init__(self):
+        self.batches = []
+
+    def transcribe_batch(self, audios, options):
+        self.batches.append(len(audios))
+        time.sleep(0.01)
+        return [{"ids": [len(a) % 97, 5], "language": "de", "starts_s": [0.0, 0.08]} for a in audios]
+
+    def close(self):
+        pass
+
+
+class FakeTTSEngine:
+    max_prompt = 64
+
+    class text_frontend:  # noqa: N801
+        @staticmethod
+        def embed(text, n):
+            return np.zeros((min(n, len(text) + 2), 8), np.float32)
+
+    def stream(self, prompts, max_new_tokens, chunk_size=8, ctx_frames=25, min_frames=0):
+        for k in range(3):
+            time.sleep(0.005)
+            yield [np.full(700, 3000 + k, np.int16) for _ in prompts]
+
+    def close(self):
+        pass
+
+
+@pytest.fixture
+def pool():
+    p = SessionPool("fake:0", max_batch=8, batch_window_ms=20.0)
+    p._engines.update(whisper=FakeSTTEngine(), parakeet=FakeSTTEngine(), tts=FakeTTSEngine())
+    yield p
+    p.shutdown()
+
+
+def _whisper(pool, language="en"):
+    from speech_to_speech_amd.handlers.whisper import MI355XWhisperSTTHandler
+
+    h = object.__new__(MI355XWhisperSTTHandler)
+    h.stop_event, h.queue_in, h.queue_out = Event(), Queue(), Queue()
+    h.gen_kwargs, h.start_language, h.last_language = {}, language, None if language == "auto" else language
+    h.vocab, h.tokenizer, h.pool, h._times = WhisperVocab(), IdTextCodec(), pool, []
+    return h
+
+
+def test_stt_final_yields_exactly_one_transcription_with_turn_fields(pool):
+    h = _whisper(pool)
+    va = VADAudio(audio=np.zeros(1600, np.float32), mode="final", turn_id="t1", turn_revision=3)
+    out = list(h.process(va))
+    assert len(out) == 1 and isinstance(out[0], Transcription)
+    assert (out[0].turn_id, out[0].turn_revision, out[0].speech_stopped_at_s) == ("t1", 3, va.created_at_s)
+    assert out[0].language_code == "en" and out[0].text == "t48 t5"
+
+
+def test_stt_auto_language_reports_detected_code_with_suffix_and_partial_is_tagged(pool):
+    h = _whisper(pool, language="auto")
+    out = list(h.process(VADAudio(audio=np.zeros(800, np.float32), mode="final")))
+    assert out[0].language_code == "de-auto"
+    part = list(h.process(VADAudio(audio=np.zeros(800, np.float32), mode="progressive", turn_id="a", turn_revision=1)))
+    assert len(part) == 1 and isinstance(part[0], PartialTranscription) and part[0].turn_id == "a"
+
+
+def test_parakeet_failure_degrades_to_empty_transcript(pool):
+    from speech_to_speech_amd.handlers.parakeet import MI355XParakeetSTTHandler
+
+    class Broken(FakeSTTEngine):
+        def transcribe_batch(self, audios, options):
+            raise RuntimeError("device lost")
+
+    pool._engines["parakeet"] = Broken()
+    h = object.__new__(MI355XParakeetSTTHandler)
+    h.language, h.tokenizer, h.pool = "en", IdTextCodec(), pool
+    out = list(h.process(VADAudio(audio=np.zeros(1600, np.float32), mode="final", turn_id="x", turn_revision=0)))
+    assert len(out) == 1 and out[0].text == "" and out[0].turn_id == "x"
+
+
+def test_pool_batches_concurrent_pipeline_units(pool):
+    h = [_whisper(pool) for _ in range(6)]
+    res = [None] * 6
+
+    def run(i):
+        res[i] = list(h[i].process(VADAudio(audio=np.zeros(100 + i, np.float32), mode="final", turn_id=str(i), turn_revision=0)))
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(r and r[0].turn_id == str(i) for i, r in enumerate(res))
+    assert max(pool.engine("whisper").batches) >= 2 and sum(pool.engine("whisper").batches) == 6   # batched, nothing lost
+    assert [r[0].text for r in res] == [f"t{(100 + i) % 97} t5" for i in range(6)]                  # no cross-session leak
+
+
+def _tts(pool, cancel_scope=None):
+    h = object.__new__(MI355XQwen3TTSHandler)
+    h.stop_event, h.queue_in, h.queue_out, h._times = Event(), Queue(), Queue(), []
+    h.should_listen = Event()
+    h.cancel_scope, h.speculative_turns = cancel_scope, None
+    h.streaming_chunk_size, h.max_new_tokens, h.blocksize, h.pool = 8, 1536, 512, pool
+    return h
+
+
+def test_tts_blocks_are_int16_512_and_end_of_response_maps_to_sentinel(pool):
+    h = _tts(pool)
+    blocks = list(h.process(TTSInput(text="Hello there.")))
+    assert len(blocks) == 5 and all(b.dtype == np.int16 and b.shape == (512,) for b in blocks)   # 2100 samples -> 4 full + padded tail
+    assert int(blocks[-1][-1]) == 0 and not h.should_listen.is_set()
+    assert list(h.process(EndOfResponse())) == [AUDIO_RESPONSE_DONE]
+
+
+def test_tts_cancel_generation_stops_between_chunks(pool):
+    cs = CancelScope()
+    h = _tts(pool, cs)
+    out = []
+    for b in h.process(TTSInput(text="Hello there.", cancel_generation=cs.generation)):
+        out.append(b)
+        cs.cancel()
+    assert 1 <= len(out) <= 2     # stops at the next chunk boundary
+
+
+def test_tts_coalesces_queued_inputs_of_same_response(pool):
+    h = _tts(pool)
+    first = TTSInput(text="One.", response_key="r1", cancel_generation=0, turn_id="t")
+    h.queue_in.put(TTSInput(text="Two.", response_key="r1", cancel_generation=0, turn_id="t"))
+    h.queue_in.put(TTSInput(text="Other.", response_key="r2", cancel_generation=0, turn_id="t"))
+    text, _ = h._coalesce_pending_tts_input(first)
+    assert text == "One. Two." and h.queue_in.qsize() == 1
+
+
+def test_run_loop_wraps_audio_and_forwards_session_end(pool):
+    h = _tts(pool)
+    t = threading.Thread(target=h.run)
+    t.start()
+    h.queue_in.put(TTSInput(text="Hi.", response_key="k", cancel_generation=7))
+    h.queue_in.put(SESSION_END)
+    h.queue_in.put(PIPELINE_END)
+    t.join(timeout=10)
+    items = []
+    while not h.queue_out.empty():
+        items.append(h.queue_out.get())
+    audio = [i for i in items if isinstance(i, AudioOutput)]
+    assert audio and all(a.cancel_generation == 7 and a.response_key == "k" for a in audio)
+    assert SESSION_END in items and items[-1] == PIPELINE_END
+
+
+def test_token_budget_known_answers():
+    # reference tests/test_qwen3_tts_handler_backend.py:915-964
+    assert estimate_max_new_tokens("Hello there.") == 360
+    long_text = " ".join(["This is a deliberately long sentence for the Qwen3 TTS budget estimator."] * 12)
+    assert 360 < estimate_max_new_tokens(long_text) <= 1536 and estimate_max_new_tokens(long_text) % 8 == 0
+    assert estimate_max_new_tokens("我懂，心情不好时会让人特别疲惫。") == 360
+    cjk = ("上海是一座充满活力的现代化大都市，既有繁华的金融中心和摩天大楼，也有老城厢的弄堂风情"
+           "和江南水乡的韵味。这里交通便利，餐饮选择丰富，从精致西餐到地道小馆应有尽有。同时，上海"
+           "还是文化与创新的交汇点，艺术展览、科技展会和国际活动频繁。如果你喜欢快节奏的生活和多元"
+           "的氛围，上海会是个很吸引人的地方。你想了解哪方面的具体信息呢？")
+    assert estimate_max_new_tokens(cjk) == 576
+    assert estimate_max_new_tokens(long_text, cap=400) == 400
+    assert estimate_max_new_tokens(" ".join(["This is a deliberately long sentence for the Qwen3 TTS budget estimator."] * 30), cap=2400) > 1536
+
+
+def test_registry_entries_and_lazy_factories():
+    names = {s.name: s for s in registry.MI355X_STT_BACKENDS + registry.MI355X_TTS_BACKENDS}
+    assert set(names) == {"mi355x-whisper", "mi355x-parakeet", "mi355x-qwen3"}
+    stt, tts = {}, {}
+    registry.register_mi355x_backends(stt, tts)
+    assert set(stt) == {"mi355x-whisper", "mi355x-parakeet"} and set(tts) == {"mi355x-qwen3"}
+    cfg = names["mi355x-whisper"].normalize(names["mi355x-whisper"].config_type(stt_gen_max_new_tokens=64))
+    assert cfg["model_name"] and cfg["gen_kwargs"]["max_new_tokens"] == 64 and "stt_model_name" not in cfg
+    with pytest.raises(TypeError):
+        names["mi355x-qwen3"].normalize(object())
+    # importing the registry must not import the handler modules or torch-heavy engines
+    for m in [k for k in sys.modules if k.startswith("speech_to_speech_amd.handlers") or k.endswith(".whisper") or k.endswith(".tts")]:
+        del sys.modules[m]
+    importlib.reload(registry)
+    assert not any(k.startswith("speech_to_speech_amd.handlers.") for k in sys.modules)

@@ -1,0 +1,88 @@
+"""End-to-end on the GPU through the drop-in boundary: registry factory -> handler threads -> session pool -> engines.
+N pipeline units run concurrently (one thread each, like the reference's ThreadManager); every unit's final VADAudio must
+come back as its own Transcription (ids == the oracle's greedy ids for that utterance) and the echoed text must come back
+as int16[512] blocks followed by AUDIO_RESPONSE_DONE."""
+
+import threading
+from queue import Queue
+from threading import Event
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as OL
+from oracle import whisper as OW
+from speech_to_speech_amd.boundary import (AUDIO_RESPONSE_DONE, PIPELINE_END, AudioOutput, CancelScope, EndOfResponse, Transcription, TTSInput,
+                                           VADAudio)
+from speech_to_speech_amd.boundary import registry
+from speech_to_speech_amd.session_pool import SessionPool
+from speech_to_speech_amd.synth import synth_audio
+from speech_to_speech_amd.synth_weights import WhisperDims, whisper_state_dict
+from speech_to_speech_amd.text import WhisperVocab
+
+pytestmark = pytest.mark.gpu
+VOC = WhisperVocab(sot=300, eot=319, transcribe=305, notimestamps=306, lang_to_id={"en": 301, "de": 302, "fr": 303, "es": 304},
+                   suppress=(1, 2, 7, 300, 301, 302, 303, 304, 305, 306), begin_suppress=(220, 319))
+
+
+def _context(pipeline_index):
+    return registry.HandlerContext(stop_event=Event(), queue_in=Queue(), queue_out=Queue(), text_output_queue=Queue(), should_listen=Event(),
+                                   cancel_scope=CancelScope(), speculative_turns=None, pipeline_index=pipeline_index, sample_rate=16000,
+                                   enable_live_transcription=False, live_transcription_update_interval=0.5)
+
+
+def test_units_share_one_pool_and_get_their_own_results():
+    N = 4
+    specs = {s.name: s for s in registry.MI355X_STT_BACKENDS + registry.MI355X_TTS_BACKENDS}
+    stt_cfg = specs["mi355x-whisper"].normalize(specs["mi355x-whisper"].config_type(stt_model_name="synthetic:test-tiny:3", stt_torch_dtype="float32",
+                                                                                   stt_max_batch=8, stt_batch_window_ms=30.0, stt_gen_max_new_tokens=12))
+    stt_cfg["vocab"] = VOC
+    tts_cfg = specs["mi355x-qwen3"].normalize(specs["mi355x-qwen3"].config_type(qwen3_tts_model_name="synthetic:test-tiny", qwen3_tts_dtype="float32",
+                                                                               qwen3_tts_max_batch=8, qwen3_tts_max_new_tokens=360,
+                                                                               qwen3_tts_batch_window_ms=30.0))
+    units = []
+    for i in range(N):
+        cs, ct = _context(i), _context(i)
+        stt = specs["mi355x-whisper"].create_handler(cs, stt_cfg)
+        tts = specs["mi355x-qwen3"].create_handler(ct, tts_cfg)
+        units.append((cs, stt, ct, tts))
+    pool = SessionPool.for_device("cuda:0")
+    assert all(u[1].pool is pool and u[3].pool is pool for u in units)        # one engine replica per GPU, shared
+
+    lens = [48000, 30500, 64000, 20000]
+    audios = [synth_audio(n, 200 + i) for i, n in enumerate(lens)]
+    threads = [threading.Thread(target=h.run) for u in units for h in (u[1], u[3])]
+    [t.start() for t in threads]
+    for i, (cs, stt, ct, tts) in enumerate(units):
+        cs.queue_in.put(VADAudio(audio=audios[i], mode="final", turn_id=f"turn{i}", turn_revision=0))
+    trans = [u[0].queue_out.get(timeout=120) for u in units]
+    assert all(isinstance(t, Transcription) and t.turn_id == f"turn{i}" for i, t in enumerate(trans))
+    # oracle ids for the same utterances (float32 engine -> bit-exact)
+    dims = WhisperDims.test_tiny()
+    sd = whisper_state_dict(dims, seed=3, gain=2.0, pos_std=2.0)
+    feats = torch.from_numpy(np.stack([OL.whisper_logmel(a, dims.n_mels) for a in audios]).astype(np.float32))
+    with torch.no_grad():
+        enc = OW.encode(sd, feats, dims.n_heads, dims.enc_layers)
+        ids, _ = OW.greedy_decode(sd, enc, dims.n_heads, dims.dec_layers, [VOC.prompt("en")] * N, VOC.eot, 12, VOC.suppress, VOC.begin_suppress)
+    assert [t.text for t in trans] == [" ".join(f"t{j}" for j in row) for row in ids]
+    assert pool.stats["max_stt_batch"] >= 2                                       # the 4 finals were batched
+    # echo "LLM": transcript text goes to TTS, then the response ends
+    for i, (cs, stt, ct, tts) in enumerate(units):
+        ct.queue_in.put(TTSInput(text=trans[i].text, turn_id=f"turn{i}", turn_revision=0, cancel_generation=0, response_key=f"r{i}",
+                                 speech_stopped_at_s=trans[i].speech_stopped_at_s))
+        ct.queue_in.put(EndOfResponse(turn_id=f"turn{i}", cancel_generation=0, response_key=f"r{i}"))
+    for i, (cs, stt, ct, tts) in enumerate(units):
+        blocks = []
+        while True:
+            item = ct.queue_out.get(timeout=180)
+            if isinstance(item, AudioOutput) and isinstance(item.audio, (bytes, bytearray)) and item.audio == AUDIO_RESPONSE_DONE:
+                break
+            assert isinstance(item, AudioOutput) and item.response_key == f"r{i}" and item.audio.dtype == np.int16 and item.audio.shape == (512,)
+            blocks.append(item.audio)
+        assert len(blocks) >= 1
+    for cs, stt, ct, tts in units:
+        cs.queue_in.put(PIPELINE_END)
+        ct.queue_in.put(PIPELINE_END)
+    [t.join(timeout=30) for t in threads]
+    SessionPool.shutdown_all()
