@@ -1,15 +1,20 @@
 #!/usr/bin/env python
 """bench.py - the hot path of BASELINE.json on N MI355X GPUs of one node.
 
-One "step" = one pass of the implemented hot path over one batch of synthetic sessions per GPU:
-  config C3 (default): Whisper-large-v3 STT, 64 concurrent 10 s utterances batched on each GPU:
-      PCM (resident in HBM) -> HIP log-mel -> 32-layer encoder -> cross-K/V -> 32 greedy decode tokens.
-Sessions are the unit of data parallelism: every rank runs its own session pool on its own GPU with a full weight
-replica, no collective on the data path -> "scaling": "weak".  The only cross-rank traffic is the
-barrier + max-reduce of the step time the contract prescribes.
+One "step" = one conversational turn for every session of one GPU's session pool, inputs resident in HBM:
+    16 kHz PCM of the user utterances -> HIP log-mel -> STT encoder -> greedy decode -> (echo "LLM": the transcript
+    is the reply) -> Qwen3-TTS talker + code predictor frames -> codec decoder, streamed every 8 frames ->
+    24->16 kHz + int16 on device -> host chunks.
+Workloads (BASELINE.json configs):
+    c3 (default)  Whisper-large-v3 + Qwen3-TTS-1.7B dims, 64 concurrent 10 s sessions batched per GPU
+    c2            Parakeet-TDT-0.6B + Qwen3-TTS, single session, 30 s audio
+Sessions are the unit of data parallelism: every rank runs its own pool on its own GPU with a full weight replica and
+no collective on the data path -> "scaling": "weak"; the only cross-rank traffic is the contract's
+barrier + MAX-reduce of the step time.
 
-Prints ONE JSON line (rank 0) with the `roofline` (dominant kernel, HIP events inside this process) and
-`cpu_baseline` (the CPU oracle timed on this node's host cores on a bounded sample) objects.
+Prints ONE JSON line (rank 0) incl. `roofline` (the kernel family with the largest share of the timed region, measured
+with HIP events on its own stream inside this process) and `cpu_baseline` (CPU oracle on this node's host cores, bounded
+sample).
 """
 
 from __future__ import annotations
@@ -26,6 +31,7 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md:42
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md:35
+TURN_REPLY_SECONDS = 10.0
 
 
 def shard_sessions(per_gpu: int, rank: int) -> list[int]:
@@ -48,47 +54,22 @@ def reduce_step_time(dt: float, device) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sessions", type=int, default=64, help="concurrent sessions per GPU")
-    ap.add_argument("--utt-seconds", type=float, default=10.0)
-    ap.add_argument("--decode-tokens", type=int, default=32)
-    ap.add_argument("--model", default="large-v3", choices=["large-v3", "distil-large-v3", "tiny.en", "test-tiny"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"])
+    ap.add_argument("--sessions", type=int, default=None, help="concurrent sessions per GPU (default: 64 for c3, 1 for c2)")
+    ap.add_argument("--decode-tokens", type=int, default=32, help="Whisper greedy tokens per utterance (eos masked)")
+    ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="time every kernel family with HIP events (stderr)")
+    ap.add_argument("--breakdown", action="store_true", help="per-kernel-family and per-stage times on stderr")
     return ap.parse_args()
 
 
-def dims_for(name):
-    from speech_to_speech_amd.synth_weights import WhisperDims
-
-    return {"large-v3": WhisperDims.large_v3, "distil-large-v3": WhisperDims.distil_large_v3,
-            "tiny.en": WhisperDims.tiny_en, "test-tiny": WhisperDims.test_tiny}[name]()
-
-
-def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
-    """The CPU oracle (torch-CPU float32 port of the same algorithm) on ONE session of the same workload.
-
-    Bounded sample: the model is instantiated with `layer_sample` of its (identical-cost) encoder and decoder
-    layers; the measured layer time is scaled to the full depth, log-mel / stem / logits are measured in full.
-    """
-    import copy
-
-    import numpy as np
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _rand_whisper_sd(dims, g):
     import torch
 
-    from oracle import logmel as OL
-    from oracle import whisper as OW
-    from speech_to_speech_amd.synth import synth_audio
-
-    cores = min(os.cpu_count() or 1, 32)     # torch-CPU stops scaling (and thrashes) far below 256 threads
-    torch.set_num_threads(cores)
-    dims = copy.copy(dims_full)
-    dims.enc_layers = min(dims_full.enc_layers, layer_sample)
-    dims.dec_layers = min(dims_full.dec_layers, layer_sample)
-    g = torch.Generator().manual_seed(0)
-    d, f = dims.d_model, dims.ffn
-    sd = {}
+    d, f, sd = dims.d_model, dims.ffn, {}
 
     def lin(name, o, i, bias=True):
         sd[name + ".weight"] = torch.randn(o, i, generator=g) * i ** -0.5
@@ -96,8 +77,7 @@ def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
             sd[name + ".bias"] = torch.randn(o, generator=g) * 0.02
 
     def ln(name):
-        sd[name + ".weight"] = torch.ones(d)
-        sd[name + ".bias"] = torch.zeros(d)
+        sd[name + ".weight"], sd[name + ".bias"] = torch.ones(d), torch.zeros(d)
 
     e = "model.encoder."
     sd[e + "conv1.weight"] = torch.randn(d, dims.n_mels, 3, generator=g) * (3 * dims.n_mels) ** -0.5
@@ -126,12 +106,38 @@ def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
             lin(p + a + "k_proj", d, d, bias=False)
         lin(p + "fc1", f, d); lin(p + "fc2", d, f)
     ln(dd + "layer_norm")
+    return sd
+
+
+def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
+    """The CPU oracle (torch-CPU float32 port of the same algorithm) on ONE session's STT leg of the same workload.
+
+    Bounded sample: the model is instantiated with `layer_sample` of its (identical-cost) encoder and decoder layers; the
+    measured per-layer time is scaled to the full depth, log-mel / stem / logits are measured in full.  The TTS leg of
+    the turn is not included in the CPU number (its oracle at 1.7B dims needs minutes per utterance); the value is
+    therefore an UPPER bound of what the CPU path sustains.
+    """
+    import copy
+
+    import numpy as np
+    import torch
+
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    from speech_to_speech_amd.synth import synth_audio
+
+    cores = min(os.cpu_count() or 1, 32)     # torch-CPU stops scaling (and thrashes) far below 256 threads
+    torch.set_num_threads(cores)
+    dims = copy.copy(dims_full)
+    dims.enc_layers = min(dims_full.enc_layers, layer_sample)
+    dims.dec_layers = min(dims_full.dec_layers, layer_sample)
+    sd = _rand_whisper_sd(dims, torch.Generator().manual_seed(0))
     audio = synth_audio(int(utt_seconds * 16000), 0)
     with torch.no_grad():
         t0 = time.perf_counter()
         feats = torch.from_numpy(OL.whisper_logmel(audio, dims.n_mels).astype(np.float32))[None]
         t1 = time.perf_counter()
-        enc0 = OW.encode(sd, feats, dims.n_heads, 0)                      # stem + final norm only
+        OW.encode(sd, feats, dims.n_heads, 0)                             # stem + final norm only
         t2 = time.perf_counter()
         enc = OW.encode(sd, feats, dims.n_heads, dims.enc_layers)
         t3 = time.perf_counter()
@@ -140,25 +146,28 @@ def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
         OW.greedy_decode(sd, enc, dims.n_heads, dims.dec_layers, [[1, 2, 3, 4]], eos=-1, max_new_tokens=decode_tokens)
         t5 = time.perf_counter()
     t_mel, t_stem, t_enc, t_head, t_dec = t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4
-    enc_layers_t = max(t_enc - t_stem, 0.0) * dims_full.enc_layers / max(dims.enc_layers, 1)
-    dec_layers_t = max(t_dec - t_head, 0.0) * dims_full.dec_layers / max(dims.dec_layers, 1)
-    est = t_mel + t_stem + enc_layers_t + t_head + dec_layers_t
-    return {"value": utt_seconds / est, "unit": "concurrent real-time sessions (audio-s per wall-s)", "cores": cores,
-            "kind": "port",
-            "sample": f"1 of the batch's sessions (one {utt_seconds:g} s utterance, log-mel + encoder + {decode_tokens} greedy "
-                      f"tokens) on the torch-CPU float32 oracle with {dims.enc_layers}/{dims_full.enc_layers} encoder and "
-                      f"{dims.dec_layers}/{dims_full.dec_layers} decoder layers measured ({t5 - t0:.1f} s of CPU work) and the "
-                      f"per-layer time scaled to full depth -> {est:.1f} s per utterance"}
+    est = (t_mel + t_stem + max(t_enc - t_stem, 0.0) * dims_full.enc_layers / max(dims.enc_layers, 1) + t_head
+           + max(t_dec - t_head, 0.0) * dims_full.dec_layers / max(dims.dec_layers, 1))
+    return {"value": (utt_seconds + TURN_REPLY_SECONDS) / est, "unit": "concurrent real-time sessions (20 s turn / CPU seconds of its STT leg)",
+            "cores": cores, "kind": "port",
+            "sample": f"STT leg of 1 session ({utt_seconds:g} s utterance: log-mel + Whisper encoder + {decode_tokens} greedy tokens) on the "
+                      f"torch-CPU float32 oracle, {dims.enc_layers}/{dims_full.enc_layers} encoder and {dims.dec_layers}/{dims_full.dec_layers} "
+                      f"decoder layers measured ({t5 - t0:.1f} s of CPU work), per-layer time scaled to full depth -> {est:.1f} s per "
+                      f"utterance; TTS leg excluded (upper bound for the CPU path)"}
 
 
+# --------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    import numpy as np
     import torch
 
     from speech_to_speech_amd import native
     from speech_to_speech_amd.frontend import pack_pcm
     from speech_to_speech_amd.synth import synth_audio
-    from speech_to_speech_amd.whisper import WhisperEngine
+    from speech_to_speech_amd.synth_weights import ParakeetDims, Qwen3TTSDims, WhisperDims
+    from speech_to_speech_amd.text import ByteTextFrontend, IdTextCodec
+    from speech_to_speech_amd.tts import TTSEngine, TTSPrompt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -170,24 +179,76 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    dims = dims_for(args.model)
-    B = args.sessions
-    eng = WhisperEngine.from_random(dims, torch.bfloat16, max_batch=B, device=dev, seed=rank)
-    n = int(args.utt_seconds * 16000)
-    audios = [synth_audio(n, sid) for sid in shard_sessions(B, rank)]
-    pcm, ns = pack_pcm(audios, dev)            # inputs resident in HBM before the timed region
     lib = native.load()
-    prompt = [[1, 2, 3, 4]] * B
-    suppress_eos = [dims.vocab - 1]
+
+    if args.workload == "c3":
+        B, utt_s, stt_name = args.sessions or 64, 10.0, "Whisper-large-v3"
+        wdims, tdims = WhisperDims.large_v3(), Qwen3TTSDims.tts_1_7b()
+    elif args.workload == "c2":
+        B, utt_s, stt_name = args.sessions or 1, 30.0, "Parakeet-TDT-0.6B"
+        wdims, tdims = None, Qwen3TTSDims.tts_1_7b()
+    else:
+        B, utt_s, stt_name = args.sessions or 4, 5.0, "Whisper-test-tiny"
+        wdims, tdims = WhisperDims.test_tiny(), Qwen3TTSDims.test_tiny()
+    n_frames = int(TURN_REPLY_SECONDS * 12.5 / 8 + 0.999) * 8          # 128 codec frames = 10.24 s reply, 16 streamed chunks
+    sessions = shard_sessions(B, rank)
+    audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
+    pcm, ns = pack_pcm(audios, dev)                                     # inputs resident in HBM before the timed region
+
+    if wdims is not None:
+        from speech_to_speech_amd.whisper import WhisperEngine
+
+        stt = WhisperEngine.from_random(wdims, torch.bfloat16, max_batch=B, device=dev, seed=rank)
+        eos = wdims.vocab - 1
+        prompt = [[1, 2, 3, 4]] * B
+
+        def run_stt():
+            feats = torch.empty((B, 3002, wdims.n_mels), dtype=torch.bfloat16, device=dev)
+            native.check(lib.s2s_logmel_whisper_tm(stt.frontend._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0), native.ptr(ns), B,
+                                                   native.ptr(feats), native.S2S_BF16))
+            stt.encode(feats)
+            ids, _ = stt.decode(prompt, eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
+            return ids
+    else:
+        from speech_to_speech_amd.parakeet import ParakeetEngine, convert_parakeet_state_dict
+        from speech_to_speech_amd.synth_weights import parakeet_state_dict
+
+        pd = ParakeetDims.tdt_0_6b()
+        stt = ParakeetEngine(pd, parakeet_state_dict(pd, seed=12, gain=1.0), dtype=torch.bfloat16, max_batch=B, max_seconds=utt_s, device=dev)
+        T = int(utt_s * 100) + 1
+
+        def run_stt():
+            feats, nf = stt.frontend.parakeet(pcm, ns, T, out_dtype=torch.bfloat16)
+            stt.encode(feats, nf)
+            toks, _, _ = stt.tdt_greedy()
+            return [[t for t in tk if t != pd.blank] for tk in toks]
+
+    tts = None
+    if not args.stt_only:
+        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
+        g = torch.Generator().manual_seed(7)
+        front = ByteTextFrontend((torch.randn(258, tdims.t_hidden, generator=g)).numpy())
+    codec = IdTextCodec()
+    stage = {"stt": 0.0, "tts_first_chunk": 0.0, "tts_total": 0.0}
 
     def step():
-        feats = torch.empty((B, 3002, dims.n_mels), dtype=torch.bfloat16, device=dev)
-        native.check(lib.s2s_logmel_whisper_tm(eng.frontend._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0),
-                                               native.ptr(ns), B, native.ptr(feats), native.S2S_BF16))
-        eng.encode(feats)
-        ids, _ = eng.decode(prompt, eos=dims.vocab - 1, max_new_tokens=args.decode_tokens, suppress=suppress_eos)
-        return ids
+        t0 = time.perf_counter()
+        ids = run_stt()
+        t1 = time.perf_counter()
+        ttfa = None
+        n_chunks = 0
+        if tts is not None:
+            prompts = [TTSPrompt(front.embed(codec.decode(i)[:100], 128)) for i in ids]       # echo "LLM"
+            for chunks in tts.stream(prompts, [n_frames] * B, chunk_size=8, ctx_frames=25, min_frames=n_frames):
+                if ttfa is None:
+                    ttfa = time.perf_counter() - t0
+                n_chunks += 1
+            assert n_chunks == n_frames // 8
+        t2 = time.perf_counter()
+        stage["stt"] += t1 - t0
+        stage["tts_total"] += t2 - t1
+        stage["tts_first_chunk"] += (ttfa or 0.0) - (t1 - t0)
+        return ttfa
 
     def barrier():
         if world > 1:
@@ -198,51 +259,64 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    cats = {"gemm_tile": native.PROF_GEMM_TILE, "gemm_skinny": native.PROF_GEMM_SKINNY, "attn_mfma": native.PROF_ATTN_MFMA,
-            "attn_rows": native.PROF_ATTN_ROWS}
-    native.prof_enable(*(cats.values() if args.breakdown else [native.PROF_GEMM_TILE]))
+    for k in stage:
+        stage[k] = 0.0
+    cats = {"gemm_tile": native.PROF_GEMM_TILE, "gemm_skinny": native.PROF_GEMM_SKINNY, "attn_mfma": native.PROF_ATTN_MFMA, "attn_rows": native.PROF_ATTN_ROWS}
+    native.prof_enable(*cats.values())
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids = step()
+    ttfas = [step() for _ in range(args.steps)]
     barrier()
     dt = time.perf_counter() - t0
-    prof = native.prof_collect(native.PROF_GEMM_TILE)
-    if args.breakdown and rank == 0:
-        for k, c in cats.items():
-            if k != "gemm_tile":
-                r = native.prof_collect(c)
-                print(f"[breakdown] {k}: {r['ms'] / args.steps:.3f} ms/step over {r['launches'] // args.steps} launches, "
-                      f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:.1f} TFLOP/s, {r['bytes'] / max(r['ms'], 1e-9) / 1e6:.1f} GB/s", file=sys.stderr)
-        print(f"[breakdown] gemm_tile: {prof['ms'] / args.steps:.3f} ms/step over {prof['launches'] // args.steps} launches", file=sys.stderr)
+    prof = {k: native.prof_collect(c) for k, c in cats.items()}
     native.prof_enable()
-    assert all(len(x) == args.decode_tokens for x in ids)
     dt = reduce_step_time(dt, dev)
     if rank != 0:
         return
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.utt_seconds / (dt / args.steps)
-    achieved = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+    step_s = dt / args.steps
+    turn_audio_s = utt_s + (0.0 if args.stt_only else n_frames / 12.5)
+    value = world * B * turn_audio_s / step_s
+    if args.breakdown:
+        for k, r in prof.items():
+            print(f"[breakdown] {k}: {r['ms'] / args.steps:.2f} ms/step, {r['launches'] // args.steps} launches, "
+                  f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:.1f} TFLOP/s, {r['bytes'] / max(r['ms'], 1e-9) / 1e6:.1f} GB/s", file=sys.stderr)
+        for k, v in stage.items():
+            print(f"[breakdown] stage {k}: {v / args.steps * 1e3:.1f} ms/step", file=sys.stderr)
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    r = prof[dom]
+    if dom in ("gemm_tile", "attn_mfma"):
+        ach = r["flops"] / max(r["ms"] * 1e-3, 1e-12) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+    else:
+        ach = r["bytes"] / max(r["ms"] * 1e-3, 1e-12) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    names = {"gemm_tile": "gemm_tile_kernel<bf16> (encoder / codec projections and convolutions-as-GEMM, M > 64)",
+             "gemm_skinny": "gemm_skinny_kernel<bf16> (weight-streaming decode projections, M <= 64 sessions)",
+             "attn_mfma": "attn_mfma_kernel (encoder flash attention)", "attn_rows": "attn_rows_kernel (decode attention over the KV caches)"}
+    roof.update({"kernel": names[dom], "traffic": None, "launches_per_step": r["launches"] // args.steps,
+                 "kernel_ms_per_step": round(r["ms"] / args.steps, 2), "share_of_step": round(r["ms"] / args.steps / (step_s * 1e3), 3),
+                 "algorithmic_tflop_per_step": round(r["flops"] / args.steps / 1e12, 3), "algorithmic_gb_per_step": round(r["bytes"] / args.steps / 1e9, 2),
+                 "other_families_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in prof.items() if k != dom}})
+    ttfa_ms = None if ttfas[0] is None else round(float(np.median(ttfas)) * 1e3, 1)
     line = {
         "metric": "concurrent real-time sessions/GPU; p50 time-to-first-audio (ms), 10s utterance",
-        "value": round(value, 2), "unit": "concurrent real-time sessions (audio-seconds of 10 s utterances transcribed per wall-second), whole job",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"C3 STT leg: Whisper-{args.model} (random-init weights at true dims), {B} concurrent "
-                               f"{args.utt_seconds:g} s sessions batched per GPU, log-mel + encoder + {args.decode_tokens} greedy tokens",
-                   "sessions_per_gpu": B, "utterance_seconds": args.utt_seconds, "decode_tokens": args.decode_tokens,
-                   "stages": ["logmel", "whisper_encoder", "whisper_decoder"], "tts": "not in this bench line yet",
+        "value": round(value, 2),
+        "unit": "concurrent real-time sessions, whole job (= sessions x seconds of turn audio [utterance in + reply out] / wall seconds per turn)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.workload.upper()}: {stt_name} + Qwen3-TTS-1.7B dims (random-init weights at true dims), {B} concurrent "
+                               f"{utt_s:g} s sessions batched per GPU, one turn each: STT ({args.decode_tokens if wdims else 'TDT greedy'} tokens) -> echo -> "
+                               f"{n_frames} codec frames ({n_frames / 12.5:.2f} s reply) streamed in 8-frame chunks" + (" [STT only]" if args.stt_only else ""),
+                   "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames / 12.5,
+                   "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
                    "parallelism": f"session-pool x{world} (no collectives)"},
-        "p50_ttfa_ms": None,
-        "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<bf16> (encoder projections + conv stem + cross-K/V)",
-                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "launches": prof["launches"], "kernel_ms_per_step": round(prof["ms"] / args.steps, 3),
-                     "algorithmic_tflop_per_step": round(prof["flops"] / args.steps / 1e12, 3)},
+        "p50_ttfa_ms": ttfa_ms,
+        "ttfa_note": "all sessions of the pool end their utterance at t=0; TTFA = STT batch + TTS prefill + first 8-frame chunk + codec + resample + D2H",
+        "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and wdims is not None:
         try:
-            line["cpu_baseline"] = cpu_baseline(dims, args.utt_seconds, args.decode_tokens)
+            line["cpu_baseline"] = cpu_baseline(wdims, utt_s, args.decode_tokens)
         except Exception as ex:  # pragma: no cover
             line["cpu_baseline"] = {"error": repr(ex)}
     print(json.dumps(line))

@@ -285,6 +285,13 @@ int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t mi
 int32_t s2s_codec_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, int32_t ctx,
                          float* wav_dev, int32_t n_samples);
 int64_t s2s_codec_samples(void* model, int32_t F);
+/* Exact causal streaming: after s2s_codec_stream_reset, successive calls continue ONE decode of the whole utterance -
+ * every convolution's history rows and the transformer KV cache are carried over, nothing is recomputed, and the
+ * concatenated outputs equal s2s_codec_decode of all frames at once.  n_samples = s2s_codec_samples(F) for the first
+ * call, F * total_upsample afterwards.  All sessions of the batch advance together. */
+int32_t s2s_codec_stream_reset(void* model);
+int32_t s2s_codec_stream_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, float* wav_dev,
+                                int32_t n_samples);
 /* Post-processing of Qwen3TTSHandler._stream (TTS/qwen3_tts_handler.py:612-613,674-680): per-chunk
  * scipy.signal.resample_poly(x, up=2, down=3) then clip(x*32768).astype(int16).
  *   pcm24_dev f32 [B][in_stride], n_in_dev optional int32 [B] (else in_stride samples), fir_dev f32 [taps] the

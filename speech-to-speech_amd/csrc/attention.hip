@@ -130,6 +130,161 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// single-query (decode) attention: one workgroup per (session, head); CH = 16-byte chunks per K/V row lanes cooperate
+// on one key so every load instruction covers whole 128/256-byte rows (64/CH keys per wave instruction); the 4 waves
+// split the keys.  Pass 1 scores -> LDS, block softmax, pass 2 P.V with per-lane chunk accumulators.
+// ------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnRowsParams p) {
+    constexpr int EPL = 16 / (int)sizeof(T);     // elements per lane chunk
+    constexpr int CH = D / EPL;                  // lanes per key row
+    constexpr int KPI = 64 / CH;                 // keys per wave instruction
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                             // [kvmax]
+    float* red = smem + p.kv_len_const + 8;       // [8] + [4][D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    int kv = p.kv_len ? min(p.kv_len[b], p.kv_len_const) : p.kv_len_const;
+    const int coff = p.causal_off_arr ? p.causal_off_arr[b] : p.causal_off;
+    int jlo = 0, jhi = kv;
+    if (p.causal) jhi = min(kv, coff + 1);
+    if (p.window > 0) jlo = max(0, coff - p.window + 1);
+    const int n = max(jhi - jlo, 0);
+    const int c = lane % CH, slot = lane / CH;
+
+    float q[EPL];
+    {
+        const T* qp = (const T*)p.Q + (long)b * p.q_bs + (long)h * D + c * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = Elem<T>::ld(qp + e) * p.scale;
+    }
+    const T* Kb = (const T*)p.K + (long)b * p.kv_bs + (long)hk * D + c * EPL;
+    const T* Vb = (const T*)p.V + (long)b * p.kv_bs + (long)hk * D + c * EPL;
+    // keys of this wave: contiguous quarter, rounded to KPI
+    const int per = ((n + 3) / 4 + KPI - 1) / KPI * KPI;
+    const int w0 = jlo + wave * per, w1 = min(jhi, w0 + per);
+
+    float mx = -INFINITY;
+    constexpr int UN = 4;     // key groups in flight per wave
+    for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
+        u32x4_t kvv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            kvv[u] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (j < w1) kvv[u] = *reinterpret_cast<const u32x4_t*>(Kb + (long)j * p.kv_rs);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            const u32x4_t v = kvv[u];
+            float s = 0.f;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = fmaf(__uint_as_float(v[e] << 16), q[2 * e], s);
+                    s = fmaf(__uint_as_float(v[e] & 0xffff0000u), q[2 * e + 1], s);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(v[e]), q[e], s);
+            }
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (j < w1) {
+                if (c == 0) sc[j - jlo] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
+        u32x4_t kvv[UN];
+        float pj[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            kvv[u] = (u32x4_t){0u, 0u, 0u, 0u};
+            pj[u] = 0.f;
+            if (j < w1) {
+                kvv[u] = *reinterpret_cast<const u32x4_t*>(Vb + (long)j * p.kv_rs);
+                pj[u] = sc[j - jlo];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const u32x4_t v = kvv[u];
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] = fmaf(pj[u], __uint_as_float(v[e] << 16), acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(pj[u], __uint_as_float(v[e] & 0xffff0000u), acc[2 * e + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pj[u], __uint_as_float(v[e]), acc[e]);
+            }
+        }
+    }
+    // combine the KPI key slots of the wave (lanes with the same chunk c), then the 4 waves
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    float* part = red + 8;     // [4][D]
+    if (slot == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) part[wave * D + c * EPL + e] = acc[e];
+    }
+    __syncthreads();
+    T* o = (T*)p.O + (long)b * p.o_bs + (long)h * D;
+    for (int d = tid; d < D; d += 256) Elem<T>::st(o + d, ((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) * inv);
+}
+
+template <typename T>
+static int launch_attn_decode(hipStream_t st, const AttnRowsParams& p) {
+    dim3 grid(p.H, p.B);
+    ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.kv_len_const * p.D,
+                   (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_len_const * p.D * 2 + (double)p.H * p.D * 2));
+    const size_t lds = sizeof(float) * (size_t)(p.kv_len_const + 8 + 8 + 4 * p.D);
+#define S2S_DEC(DV)                                                                                       \
+    do {                                                                                                  \
+        if (lds > 64 * 1024)                                                                              \
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)attn_decode_kernel<T, DV>,                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        attn_decode_kernel<T, DV><<<grid, 256, lds, st>>>(p);                                             \
+    } while (0)
+    switch (p.D) {
+        case 32: S2S_DEC(32); break;
+        case 64: S2S_DEC(64); break;
+        case 128: S2S_DEC(128); break;
+        default: return fail(S2S_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32/64/128)", p.D);
+    }
+#undef S2S_DEC
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
 template <typename T>
 static int launch_attn_rows(hipStream_t st, const AttnRowsParams& p) {
     dim3 grid(cdiv(p.Tq, 4), p.H, p.B);
@@ -158,6 +313,8 @@ static int launch_attn_rows(hipStream_t st, const AttnRowsParams& p) {
 int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype) {
     S2S_REQUIRE(p.B > 0 && p.H > 0 && p.Hkv > 0 && p.H % p.Hkv == 0 && p.Tq > 0, "attention: bad shape");
     if (p.kv_len_const <= 0) return fail(S2S_ERR_ARG, "attention: kv_len_const must be > 0");
+    if (p.Tq == 1 && !p.bias && p.kv_len_const >= 64)
+        return dtype == S2S_BF16 ? launch_attn_decode<__hip_bfloat16>(st, p) : launch_attn_decode<float>(st, p);
     return dtype == S2S_BF16 ? launch_attn_rows<__hip_bfloat16>(st, p) : launch_attn_rows<float>(st, p);
 }
 

@@ -12,10 +12,9 @@
 //                         so that each XCD's L2 sees a contiguous band of N-tiles sharing W.
 //  * gemm_skinny_kernel : M <= 64 (decode steps: one row per live session).  Weights are
 //                         streamed exactly once straight from HBM into MFMA B-fragments
-//                         (no LDS), activations come from L2; N is cut into 16-column
-//                         slabs and K into slices so that >= 256 workgroups are in flight;
-//                         K-slices are combined with f32 atomics onto the (residual)
-//                         output when split, or written directly when not.
+//                         (no LDS staging), activations come from L2; one 8-wave workgroup
+//                         per 16-column slab, the waves split K and combine through LDS
+//                         (deterministic), full epilogue on the combined tile.
 //
 // Element types: bf16 inputs -> v_mfma_f32_16x16x32_bf16, f32 inputs ->
 // v_mfma_f32_16x16x4_f32 (exact f32, used by the parity policy).  Accumulation is f32.
@@ -218,15 +217,22 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 }
 
 // ---- skinny (decode) GEMM --------------------------------------------------
-// grid = ceil(N/64) * ksplit, block = 256: four waves, each one 16-column slab of the same
-// K-slice (so the activation fragments of three of them are L1 hits).
-// MT = ceil(M/16) row fragments.
-template <typename T, typename CT, int MT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(
+// M <= 64 rows (one per live session): pure weight streaming.  One workgroup of 8 waves owns a 16-column slab of
+// W over the WHOLE of K; the 8 waves split K, so every weight element is read exactly once, straight from HBM into
+// an MFMA B-fragment (16 B per lane, all loads of a wave's slice in flight together), activations come from L2 as
+// A-fragments.  The 8 partial accumulators are combined through LDS (deterministic - no atomics), then the full
+// epilogue (bias, activation, alpha, residual, cast) runs on the combined tile.  grid = ceil(N/16) workgroups.
+// GLU = true: W holds [gate rows | up rows] (N each); the workgroup accumulates both for its 16 channels and the
+// epilogue writes silu(gate) * up (SwiGLU fused, output width N).
+template <typename T, typename CT, int MT, bool GLU>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int ksplit, int kslice,
-    RowMap rm) {
-    constexpr int KPF = MfmaTraits<T>::KPF;
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm) {
+    constexpr int EPC = MfmaTraits<T>::EPC;          // k per 16-byte load: 8 (bf16) / 4 (f32)
+    constexpr int KB = EPC * 4;                      // k consumed per load step by the 4 lane groups: 32 / 16
+    constexpr int U = GLU ? 4 : 8;                   // load steps in flight per wave
+    constexpr int NW = GLU ? 2 : 1;
+    __shared__ float red[8][MT * NW][64][4];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
         A += z1 * rm.a_z1 + z2 * rm.a_z2;
@@ -234,98 +240,88 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
         C += z1 * rm.c_z1 + z2 * rm.c_z2;
         if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
     }
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
-    const int nb = blockIdx.x / ksplit, ks = blockIdx.x - nb * ksplit;
-    const int n = (nb * 4 + (threadIdx.x >> 6)) * 16 + l15;
-    const int kbeg = ks * kslice, kend = min(K, kbeg + kslice);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int n = n0 + l15;
+    const int kslice = ((K + 7) / 8 + KB - 1) / KB * KB;
+    const int kbeg = wave * kslice, kend = min(K, kbeg + kslice);
 
-    f32x4_t acc[MT];
+    f32x4_t acc[MT * NW];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
+    for (int i = 0; i < MT * NW; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool nvalid = n < N;
     const T* wrow = W + (long)(nvalid ? n : 0) * rm.ldw;
+    const T* wrow2 = wrow + (long)N * rm.ldw;        // GLU: the "up" row of the same channel
     const T* arow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + l15;
         arow[i] = m < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : nullptr;
     }
-    if constexpr (sizeof(T) == 2) {
-        for (int k0 = kbeg; k0 < kend; k0 += 4 * KPF) {
-            bf16x8_t fw[4];
+    for (int k0 = kbeg; k0 < kend; k0 += U * KB) {
+        u32x4_t fw[U], fw2[GLU ? U : 1];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * KPF + lg * 8;
-                u32x4_t v = {0u, 0u, 0u, 0u};
-                if (nvalid && k < kend) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + k));
-                fw[u] = __builtin_bit_cast(bf16x8_t, v);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * KPF + lg * 8;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    u32x4_t v = {0u, 0u, 0u, 0u};
-                    if (arow[i] && k < kend) {
-                        long ao = k;
-                        if (rm.tap_len > 0) {
-                            const int tap = k / rm.tap_len;
-                            ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
-                        }
-                        v = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
-                    }
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v), fw[u], acc[i], 0, 0, 0);
-                }
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * KB + lg * EPC;
+            fw[u] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (nvalid && k < kend) fw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + k));
+            if constexpr (GLU) {
+                fw2[u] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (nvalid && k < kend) fw2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow2 + k));
             }
         }
-    } else {
-        for (int k0 = kbeg; k0 < kend; k0 += 8 * KPF) {
-            float fw[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * KPF + lg;
-                fw[u] = (nvalid && k < kend) ? wrow[k] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * KB + lg * EPC;
+            long ao = k;
+            if (rm.tap_len > 0) {
+                const int tap = k / rm.tap_len;
+                ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * KPF + lg;
+            for (int i = 0; i < MT; ++i) {
+                u32x4_t va = {0u, 0u, 0u, 0u};
+                if (arow[i] && k < kend) va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                if constexpr (sizeof(T) == 2) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, fw[u]), acc[i], 0, 0, 0);
+                    if constexpr (GLU)
+                        acc[MT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, fw2[u]), acc[MT + i], 0, 0, 0);
+                } else {
+                    // lane (lg, .) holds k = kb + lg*4 + s for both operands; MFMA step s pairs element s of each
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    float a = 0.f;
-                    if (arow[i] && k < kend) {
-                        long ao = k;
-                        if (rm.tap_len > 0) {
-                            const int tap = k / rm.tap_len;
-                            ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
-                        }
-                        a = arow[i][ao];
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[s4]), __uint_as_float(fw[u][s4]), acc[i], 0, 0, 0);
+                        if constexpr (GLU)
+                            acc[MT + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[s4]), __uint_as_float(fw2[u][s4]), acc[MT + i], 0, 0, 0);
                     }
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, fw[u], acc[i], 0, 0, 0);
                 }
             }
         }
     }
-
-    if (!nvalid) return;
-    const float bv = (bias && ks == 0) ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT * NW; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = i * 16 + lg * 4 + r;
-            if (m >= M) continue;
-            const int mb = m / rm.G, mr = m % rm.G;
-            CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + n;
-            if (ksplit == 1) {
-                float v = apply_act(acc[i][r] + bv, act) * rm.alpha;
-                if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
-                Elem<CT>::st(cp, v);
-            } else {
-                // split-K: C (f32) already holds the residual; partial sums are added onto it
-                atomicAdd(reinterpret_cast<float*>(cp), (acc[i][r] + bv) * rm.alpha);
-            }
+        for (int r = 0; r < 4; ++r) red[wave][i][lane][r] = acc[i][r];
+    __syncthreads();
+    // combined tile element e -> (fragment i, lane l, reg r): row = i*16 + (l>>4)*4 + r, col = l & 15
+    for (int e = tid; e < MT * 256; e += 512) {
+        const int i = e >> 8, l = (e >> 2) & 63, r = e & 3;
+        const int m = i * 16 + (l >> 4) * 4 + r, nn = n0 + (l & 15);
+        if (m >= M || nn >= N) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w][i][l][r];
+        if constexpr (GLU) {
+            float u2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) u2 += red[w][MT + i][l][r];
+            v = v / (1.0f + expf(-v)) * u2;
         }
+        v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
+        const int mb = m / rm.G, mr = m % rm.G;
+        if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + nn];
+        Elem<CT>::st(C + (long)mb * rm.c_bs + (long)mr * ldc + nn, v);
+    }
 }
 
 template <typename T, typename CT>
@@ -345,37 +341,33 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     rm.tap_len = g.tap_len;
     rm.tap_stride = g.tap_stride;
     const int M = g.M, N = g.N, K = g.K;
-    if (M <= 64) {
+    if (M <= 128 && !(g.glu && M > 64)) {
         const int MT = cdiv(M, 16);
-        const int ntiles = cdiv(N, 64);
-        int ksplit = 1;
-        // split K only where partial sums can be combined by plain addition onto C
-        const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
-        const bool can_split = g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 &&
-                               (g.residual == nullptr || in_place) && rm.G == M && nz == 1;
-        constexpr int KQ = sizeof(T) == 2 ? 128 : 32;   // K consumed per loop trip
-        if (can_split) {
-            while (ntiles * ksplit < 256 && K / (ksplit * 2) >= 2 * KQ) ksplit *= 2;
-        }
-        int kslice = cdiv(cdiv(K, ksplit), KQ) * KQ;
-        ksplit = cdiv(K, kslice);
-        if (ksplit > 1 && g.residual == nullptr) {
-            // no residual in place: C must start from zero
-            hipError_t e = hipMemset2DAsync(g.C, g.ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
-            if (e != hipSuccess) return fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(e));
-        }
-        dim3 grid(ntiles * ksplit, nz);
+        dim3 grid(cdiv(N, 16), nz);
         ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-#define S2S_SKINNY(MTV)                                                                          \
-    gemm_skinny_kernel<T, CT, MTV><<<grid, 256, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
-                                                         g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
-                                                         N, K, g.act, ksplit, kslice, rm)
-        switch (MT) {
-            case 1: S2S_SKINNY(1); break;
-            case 2: S2S_SKINNY(2); break;
-            case 3: S2S_SKINNY(3); break;
-            default: S2S_SKINNY(4); break;
+#define S2S_SKINNY(MTV, GLUV)                                                                          \
+    gemm_skinny_kernel<T, CT, MTV, GLUV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
+                                                               g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
+                                                               N, K, g.act, rm)
+        if (g.glu) {
+            switch (MT) {
+                case 1: S2S_SKINNY(1, true); break;
+                case 2: S2S_SKINNY(2, true); break;
+                case 3: S2S_SKINNY(3, true); break;
+                default: S2S_SKINNY(4, true); break;
+            }
+        } else {
+            switch (MT) {
+                case 1: S2S_SKINNY(1, false); break;
+                case 2: S2S_SKINNY(2, false); break;
+                case 3: S2S_SKINNY(3, false); break;
+                case 4: S2S_SKINNY(4, false); break;
+                case 5: S2S_SKINNY(5, false); break;
+                case 6: S2S_SKINNY(6, false); break;
+                case 7: S2S_SKINNY(7, false); break;
+                default: S2S_SKINNY(8, false); break;
+            }
         }
 #undef S2S_SKINNY
     } else {
@@ -394,6 +386,7 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
     S2S_REQUIRE(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.M == 0) return S2S_OK;
     S2S_REQUIRE(g.A && g.W && g.C, "gemm: null operand");
+    S2S_REQUIRE(!g.glu || g.M <= 64, "gemm: fused SwiGLU epilogue is a decode-path (M <= 64) feature");
     const int epc = g.ab_dtype == S2S_BF16 ? 8 : 4;
     S2S_REQUIRE(g.K % epc == 0 && g.lda % epc == 0 && g.a_bs % epc == 0,
                 "gemm: K=%d / lda=%ld / a_bs=%ld must be multiples of %d", g.K, g.lda, g.a_bs, epc);

@@ -17,6 +17,7 @@ struct GemmArgs {
     long a_z1, a_z2, w_z1, w_z2, c_z1, c_z2;     // per-batch element offsets (C strides also apply to residual)
     float alpha; bool alpha_set;                 // C = act(acc+bias)*alpha + residual (alpha_set false -> 1)
     int tap_len; long tap_stride;                // dilated conv taps: A index k -> (k/tap_len)*tap_stride + k%tap_len
+    bool glu;                                    // M <= 64: W = [gate rows | up rows] (N each), C = silu(gate) * up (width N)
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,

@@ -19,7 +19,7 @@
 namespace s2s {
 
 int rope_qknorm(hipStream_t st, void* qkv, int rows, int T_len, int H, int Hk, int D, const float* qw, const float* kw, float eps,
-                const float* cosT, const float* sinT, const int* pos0, int dtype);
+                const float* cosT, const float* sinT, const int* pos0, void* kc, void* vc, long c_bs, int dtype);
 int kv_append_rows(hipStream_t st, const void* src, long src_rs, int k_off, int v_off, void* kc, void* vc, long c_bs,
                    const int* pos0, int B, int T_len, int n, int dtype);
 int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dtype);
@@ -31,7 +31,7 @@ int snake(hipStream_t st, const void* x, void* y, const float* a, const float* i
 int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias, const float* g, const float* be, void* y, int B,
                int Tn, int C, int lpad, float eps, int dtype);
 int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, int skip, int n, int dtype);
-int add_f32_into_padded(hipStream_t st, void* x, const float* y, int B, int Tn, int C, int lpad, int dtype);
+int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype);
 int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
 
 constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
@@ -74,6 +74,9 @@ struct Tts {
     int frames_done = 0, cur_B = 0, prompt_max = 0;
     // codec decoder buffers
     float* cx;  void *ca, *cb_, *cc;   // residual stream + ping-pong activations
+    std::vector<void*> cstate;         // streaming history rows, one [B][LPAD][C] block per history-carrying stage
+    int* pos_c = nullptr;              // codec transformer positions (device, [B])
+    int codec_frames_done = 0;
     int* host_flag = nullptr;
 };
 
@@ -133,7 +136,8 @@ static int finalize(Tts* m) {
     m->talker.prefix = "talker.";
     m->pred.c = StackCfg{c.p_hidden, c.p_layers, c.p_heads, c.p_kv_heads, c.p_head_dim, c.p_ffn, 1, 0, c.n_groups + 1, c.eps};
     m->pred.prefix = "pred.";
-    m->codec.c = StackCfg{c.c_hidden, c.c_layers, c.c_heads, c.c_heads, c.c_hidden / c.c_heads, c.c_ffn, 0, c.c_window, c.max_codec_frames, c.c_eps};
+    m->codec.c = StackCfg{c.c_hidden, c.c_layers, c.c_heads, c.c_heads, c.c_hidden / c.c_heads, c.c_ffn, 0, c.c_window,
+                          std::max(c.max_codec_frames, c.max_pos), c.c_eps};
     m->codec.prefix = "codec.";
     for (Stack* s : {&m->talker, &m->pred, &m->codec}) {
         if ((rc = check_stack(m, *s))) return rc;
@@ -200,7 +204,7 @@ static int finalize(Tts* m) {
     T(B * E * 4);                              // 10 xnext
     T(B * 2 * E * 4);                          // 11 pin
     T(B * 2 * E * e);                          // 12 pin_t
-    T((8 * B + 16) * 4);                       // 13 ints
+    T((9 * B + 16) * 4);                       // 13 ints
     T(B * (size_t)c.max_frames * G * 4);       // 14 codes_out
     T((size_t)c.codec_vocab);                  // 15 sup_mask
     for (Stack* s : {&m->talker, &m->pred, &m->codec}) {   // 16..21 caches
@@ -241,6 +245,18 @@ static int finalize(Tts* m) {
     for (int i = c.codebook; i < c.codec_vocab; ++i) sup[i] = (i == c.codec_eos) ? 0 : 1;
     S2S_HIP_CHECK(hipMemcpy(m->sup_mask, sup.data(), sup.size(), hipMemcpyHostToDevice));
     S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, 64, 0));
+    // streaming history: 2 (ConvNeXt inputs) + 2 (ConvNeXt outputs) + per decoder block (1 + 3) + 1 (final conv input)
+    {
+        const size_t cmax = (size_t)std::max<long>(H, Dd);
+        const int n_slots = 4 + 4 * c.n_dec_blocks + 1;
+        for (int i = 0; i < n_slots; ++i) {
+            void* p = nullptr;
+            S2S_HIP_CHECK(hipMalloc(&p, B * LPAD * cmax * e));
+            S2S_HIP_CHECK(hipMemset(p, 0, B * LPAD * cmax * e));
+            m->cstate.push_back(p);
+        }
+        m->pos_c = ints + 7 * B + 8;
+    }
     m->finalized = true;
     return S2S_OK;
 }
@@ -261,11 +277,10 @@ static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int 
         const std::string p = s.prefix + std::to_string(l) + ".";
         if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
         if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
-        if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
-                              c.eps, s.cosT, s.sinT, pos0, dt))) return rc;
         void* kc = at(s.kc, l * cache_layer);
         void* vc = at(s.vc, l * cache_layer);
-        if ((rc = kv_append_rows(st, m->qkv, nq, H * D, (H + Hk) * D, kc, vc, (long)c.max_pos * Hk * D, pos0, B, T_len, Hk * D, dt))) return rc;
+        if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
+                              c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
         AttnRowsParams a{};
         a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
         a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
@@ -275,12 +290,25 @@ static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int 
         if ((rc = attn_rows(st, a, dt))) return rc;
         if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
         if ((rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
-        if ((rc = gemm(st, m->h, hid, TP(m, p + "gu.w"), nullptr, nullptr, m->gu, 2 * c.ffn, M, 2 * c.ffn, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
-        if ((rc = swiglu(st, m->gu, m->act, M, c.ffn, dt))) return rc;
+        if (M <= 64) {   // decode: SwiGLU fused into the weight-streaming GEMM's epilogue
+            GemmArgs gg{};
+            gg.A = m->h; gg.lda = hid; gg.W = TP(m, p + "gu.w"); gg.C = m->act; gg.ldc = c.ffn; gg.M = M; gg.N = c.ffn; gg.K = hid;
+            gg.ab_dtype = dt; gg.c_dtype = dt; gg.act = S2S_ACT_NONE; gg.glu = true;
+            if ((rc = gemm_ex(st, gg))) return rc;
+        } else {
+            if ((rc = gemm(st, m->h, hid, TP(m, p + "gu.w"), nullptr, nullptr, m->gu, 2 * c.ffn, M, 2 * c.ffn, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+            if ((rc = swiglu(st, m->gu, m->act, M, c.ffn, dt))) return rc;
+        }
         if ((rc = gemm(st, m->act, c.ffn, TP(m, p + "down.w"), nullptr, x, x, hid, M, hid, c.ffn, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
     }
     return S2S_OK;
 }
+
+__global__ void fill_int_kernel_tts(int* p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+#define fill_int_kernel fill_int_kernel_tts
 
 // kv_len[b] = pos0[b] + T  (valid keys after appending)
 __global__ void kvlen_kernel(const int* pos0, int T, int* out, int B) {
@@ -404,6 +432,7 @@ extern "C" int32_t s2s_tts_destroy(void* model) {
     Tts* m = (Tts*)model;
     if (m->arena) (void)hipFree(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
+    for (void* p : m->cstate) (void)hipFree(p);
     delete m;
     return S2S_OK;
 }
@@ -440,7 +469,7 @@ extern "C" int32_t s2s_tts_prefill(void* model, void* stream, const float* promp
     const int E = m->cfg.t_hidden;
     int rc;
     S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)B * Tp * E, hipMemcpyDeviceToDevice, st));
-    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (8 * (size_t)m->max_batch + 16), st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (7 * (size_t)m->max_batch + 8), st));
     S2S_HIP_CHECK(hipMemsetAsync(m->codes_out, 0xff, sizeof(int) * (size_t)m->max_batch * m->cfg.max_frames * m->cfg.n_groups, st));
     // padded rows beyond a session's prompt are cached too but never attended: kv_len = prompt_len
     if ((rc = stack_forward(m, st, m->talker, m->x, B, Tp, nullptr, Tp, prompt_len_dev))) return rc;
@@ -518,124 +547,162 @@ static int conv_gemm(Tts* m, hipStream_t st, const void* in, int T, int Cin, int
 
 }  // namespace s2s
 
+namespace s2s {
+
+// Codec decoder over F frames of codes.  streaming = false: stateless decode of the window, the first ctx frames
+// are left context whose samples are dropped (the sibling's chunked_decode pattern).  streaming = true: exact causal
+// continuation of the previous call - every convolution's history rows and the transformer's KV cache are carried
+// over, so the concatenated chunks equal one decode of the whole utterance and nothing is recomputed.
+static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F, int ctx, bool streaming, float* wav_dev, int n_samples) {
+    const auto& c = m->cfg;
+    const int dt = c.dtype, e = m->esz, H = c.c_hidden, G = c.n_groups;
+    const bool first = !streaming || m->codec_frames_done == 0;
+    const int saveB = m->cur_B;
+    m->cur_B = B;
+    int rc;
+    int slot = 0;
+    auto done = [&](int r) { m->cur_B = saveB; return r; };
+    // Buffers are reused with a different [T][C] geometry at every stage.  Before a stage's input is produced its
+    // LPAD history rows are (re)established: zeros (stateless / first chunk) or the tail of the previous chunk.
+    auto hist_load = [&](void* buf, int Tn, int Cn) -> int {
+        const int sl = slot++;
+        hipError_t er;
+        if (first) er = hipMemset2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, 0, (size_t)LPAD * Cn * e, B, st);
+        else er = hipMemcpy2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, m->cstate[sl], (size_t)LPAD * Cn * e, (size_t)LPAD * Cn * e, B, hipMemcpyDeviceToDevice, st);
+        return er == hipSuccess ? sl : fail(S2S_ERR_HIP, "codec history load: %s", hipGetErrorString(er));
+    };
+    auto hist_save = [&](void* buf, int Tn, int Cn, int sl) -> int {
+        if (!streaming) return S2S_OK;
+        hipError_t er = hipMemcpy2DAsync(m->cstate[sl], (size_t)LPAD * Cn * e, at(buf, (size_t)Tn * Cn * e), (size_t)(LPAD + Tn) * Cn * e,
+                                         (size_t)LPAD * Cn * e, B, hipMemcpyDeviceToDevice, st);
+        return er == hipSuccess ? S2S_OK : fail(S2S_ERR_HIP, "codec history save: %s", hipGetErrorString(er));
+    };
+#define HLOAD(var, buf, Tn, Cn) const int var = hist_load(buf, Tn, Cn); if (var < 0) return done(var)
+    // code embeddings -> sliding-window transformer (KV cache continues across streamed chunks)
+    if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
+    const int f0 = streaming ? m->codec_frames_done : 0;
+    if (streaming) {
+        fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->pos_c, f0, B);
+        S2S_LAUNCH_CHECK();
+    }
+    if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
+    if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
+    S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,
+                                   hipMemcpyDeviceToDevice, st));
+    int T = F;
+    void *cur = m->ca, *alt = m->cb_, *tmp = m->cc;
+    for (int i = 0; i < 2; ++i) {
+        const std::string q = "codec.up." + std::to_string(i) + ".";
+        const int r = c.up_ratio[i];
+        // transposed conv kernel == stride: out[t*r + j] = x[t] . W[j]  -> GEMM N = r*H, rows land time-major (stateless)
+        GemmArgs g{};
+        g.A = at(cur, (size_t)LPAD * H * e); g.lda = H; g.a_bs = (long)(LPAD + T) * H;
+        g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
+        g.C = at(alt, (size_t)LPAD * H * e); g.ldc = (long)r * H; g.c_bs = (long)(LPAD + T * r) * H;
+        g.M = B * T; g.N = r * H; g.K = H; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+        HLOAD(s_dw, alt, T * r, H);
+        if ((rc = gemm_ex(st, g))) return done(rc);
+        T *= r;
+        if ((rc = hist_save(alt, T, H, s_dw))) return done(rc);
+        // ConvNeXt: dwconv7 + LN -> pw1 GELU -> pw2 (gamma folded); x_out = x + that, written to the third buffer
+        if ((rc = dwconv7_ln(st, alt, TPF(m, q + "dw.w"), TPF(m, q + "dw.b"), TPF(m, q + "ln.g"), TPF(m, q + "ln.b"), cur, B, T, H, LPAD, 1e-6f, dt))) return done(rc);
+        if ((rc = gemm(st, cur, H, TP(m, q + "pw1.w"), TPF(m, q + "pw1.b"), nullptr, tmp, 4 * H, B * T, 4 * H, H, dt, dt, S2S_ACT_GELU, false))) return done(rc);
+        GemmArgs g2{};
+        g2.A = tmp; g2.lda = 4 * H; g2.a_bs = (long)T * 4 * H;
+        g2.W = TP(m, q + "pw2.w"); g2.bias = TPF(m, q + "pw2.b");
+        g2.C = m->cx; g2.ldc = H; g2.c_bs = (long)T * H;
+        g2.M = B * T; g2.N = H; g2.K = 4 * H; g2.G = T; g2.ab_dtype = dt; g2.c_dtype = S2S_F32; g2.act = S2S_ACT_NONE;
+        if ((rc = gemm_ex(st, g2))) return done(rc);
+        HLOAD(s_out, cur, T, H);
+        if ((rc = add_f32_padded(st, cur, alt, m->cx, B, T, H, LPAD, dt))) return done(rc);     // cur = alt + cx
+        if ((rc = hist_save(cur, T, H, s_out))) return done(rc);
+    }
+    // decoder.0: causal conv k7 H -> Dd
+    int C = c.c_decoder_dim;
+    if ((rc = conv_gemm(m, st, cur, T, H, 7, 1, "codec.dec.in.w", "codec.dec.in.b", alt, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+    std::swap(cur, alt);
+    for (int i = 0; i < c.n_dec_blocks; ++i) {
+        const std::string q = "codec.dec." + std::to_string(i) + ".";
+        const int r = c.up_rate[i], Co = C >> 1;
+        HLOAD(s_sn, alt, T, C);
+        if ((rc = snake(st, cur, alt, TPF(m, q + "snake.a"), TPF(m, q + "snake.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+        if ((rc = hist_save(alt, T, C, s_sn))) return done(rc);
+        // transposed conv k=2r, s=r (trimmed r on both sides): out[(t-1)*r + j] = x[t-1].W[j+r] + x[t].W[j]
+        // first chunk: t = 1..T-1; later chunks: t = 0..T-1 with x[-1] = last row of the previous chunk (history row)
+        const int Tm = first ? T - 1 : T;
+        {
+            GemmArgs g{};
+            g.A = at(alt, (size_t)(first ? LPAD : LPAD - 1) * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+            g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
+            g.C = at(tmp, (size_t)LPAD * Co * e); g.ldc = (long)r * Co; g.c_bs = (long)(LPAD + Tm * r) * Co;
+            g.M = B * Tm; g.N = r * Co; g.K = 2 * C; g.G = Tm; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+            if ((rc = gemm_ex(st, g))) return done(rc);
+        }
+        T = Tm * r;
+        C = Co;
+        void* xbuf = tmp;
+        void* y1 = cur;
+        void* y2 = alt;
+        for (int j = 0; j < 3; ++j) {
+            const std::string u = q + "ru" + std::to_string(j) + ".";
+            const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
+            HLOAD(s_y1, y1, T, C);
+            if ((rc = snake(st, xbuf, y1, TPF(m, u + "s1.a"), TPF(m, u + "s1.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+            if ((rc = hist_save(y1, T, C, s_y1))) return done(rc);
+            if ((rc = conv_gemm(m, st, y1, T, C, 7, dil, u + "c1.w", u + "c1.b", y2, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+            if ((rc = snake(st, y2, y1, TPF(m, u + "s2.a"), TPF(m, u + "s2.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+            GemmArgs g{};
+            g.A = at(y1, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+            g.W = TP(m, u + "c2.w"); g.bias = TPF(m, u + "c2.b");
+            g.C = y2; g.ldc = C; g.c_bs = (long)T * C;     // unpadded model-dtype scratch
+            g.M = B * T; g.N = C; g.K = C; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+            if ((rc = gemm_ex(st, g))) return done(rc);
+            if ((rc = add_into_padded(st, xbuf, y2, B, T, C, LPAD, dt))) return done(rc);
+        }
+        void* a0 = cur; void* a1 = alt;
+        cur = xbuf; alt = a0; tmp = a1;
+    }
+    // output: snake -> conv k7 C -> 1, clamp
+    HLOAD(s_fin, alt, T, C);
+    if ((rc = snake(st, cur, alt, TPF(m, "codec.dec.out.a"), TPF(m, "codec.dec.out.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+    if ((rc = hist_save(alt, T, C, s_fin))) return done(rc);
+    if ((rc = conv_gemm(m, st, alt, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", tmp, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+#undef HLOAD
+    const long skip = (long)ctx * c.total_upsample;
+    S2S_REQUIRE(n_samples == T - skip, "codec_decode: n_samples %d != %ld", n_samples, T - skip);
+    if ((rc = wav_out(st, tmp, wav_dev, B, T, LPAD, (int)skip, n_samples, dt))) return done(rc);
+    if (streaming) m->codec_frames_done += F;
+    return done(S2S_OK);
+}
+
+}  // namespace s2s
+
 // codes_dev int32 [B][F][G] frame-major (ctx frames of left context first); wav_dev f32 [B][n_samples] receives the
 // samples after the first ctx*total_upsample ones; n_samples = codec_samples(F) - ctx*total_upsample.
 extern "C" int32_t s2s_codec_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, int32_t ctx,
                                     float* wav_dev, int32_t n_samples) {
     Tts* m = (Tts*)model;
     S2S_REQUIRE(m && m->finalized, "codec_decode: model not finalized");
-    const auto& c = m->cfg;
-    S2S_REQUIRE(B > 0 && B <= m->max_batch && F >= 1 && F <= c.max_codec_frames && ctx >= 0 && ctx < F && codes_dev && wav_dev, "codec_decode: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    const int dt = c.dtype, e = m->esz, H = c.c_hidden, G = c.n_groups;
-    const int saveB = m->cur_B;
-    m->cur_B = B;
-    int rc;
-    auto done = [&](int r) { m->cur_B = saveB; return r; };
-    // a buffer is reused with a different [T][C] geometry at every stage: re-establish its LPAD zero rows first
-    auto prep = [&](void* buf, int Tn, int Cn) -> int {
-        hipError_t er = hipMemset2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, 0, (size_t)LPAD * Cn * e, B, st);
-        return er == hipSuccess ? S2S_OK : fail(S2S_ERR_HIP, "memset2D: %s", hipGetErrorString(er));
-    };
-    // code embeddings -> sliding-window transformer
-    if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
-    if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, nullptr, F, nullptr))) return done(rc);
-    // final norm -> ca [B][LPAD+F][H]
-    {
-        // rmsnorm writes contiguous rows; place them behind the LPAD rows of every item with a strided copy
-        if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
-        if ((rc = prep(m->ca, F, H))) return done(rc);
-        S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,
-                                       hipMemcpyDeviceToDevice, st));
-    }
-    int T = F;
-    void *cur = m->ca, *alt = m->cb_, *tmp = m->cc;
-    for (int i = 0; i < 2; ++i) {
-        const std::string q = "codec.up." + std::to_string(i) + ".";
-        const int r = c.up_ratio[i];
-        // transposed conv kernel == stride: out[t*r + j] = x[t] . W[j]  -> GEMM N = r*H, rows land time-major
-        GemmArgs g{};
-        g.A = at(cur, (size_t)LPAD * H * e); g.lda = H; g.a_bs = (long)(LPAD + T) * H;
-        g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
-        g.C = at(alt, (size_t)LPAD * H * e); g.ldc = (long)r * H; g.c_bs = (long)(LPAD + T * r) * H;
-        g.M = B * T; g.N = r * H; g.K = H; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
-        if ((rc = prep(alt, T * r, H))) return done(rc);
-        if ((rc = gemm_ex(st, g))) return done(rc);
-        T *= r;
-        std::swap(cur, alt);
-        // ConvNeXt: dwconv7 + LN -> pw1 GELU -> pw2 (gamma folded) + residual
-        if ((rc = dwconv7_ln(st, cur, TPF(m, q + "dw.w"), TPF(m, q + "dw.b"), TPF(m, q + "ln.g"), TPF(m, q + "ln.b"), alt, B, T, H, LPAD, 1e-6f, dt))) return done(rc);
-        if ((rc = gemm(st, alt, H, TP(m, q + "pw1.w"), TPF(m, q + "pw1.b"), nullptr, tmp, 4 * H, B * T, 4 * H, H, dt, dt, S2S_ACT_GELU, false))) return done(rc);
-        {
-            // residual lives in the padded model-dtype buffer: out = x + pw2(...).  The GEMM residual input is f32 only,
-            // so the sum is formed by a dedicated add below.
-            GemmArgs g2{};
-            g2.A = tmp; g2.lda = 4 * H; g2.a_bs = (long)T * 4 * H;
-            g2.W = TP(m, q + "pw2.w"); g2.bias = TPF(m, q + "pw2.b");
-            g2.C = m->cx; g2.ldc = H; g2.c_bs = (long)T * H;
-            g2.M = B * T; g2.N = H; g2.K = 4 * H; g2.G = T; g2.ab_dtype = dt; g2.c_dtype = S2S_F32; g2.act = S2S_ACT_NONE;
-            if ((rc = gemm_ex(st, g2))) return done(rc);
-            // cur (padded, model dtype) += cx (f32, unpadded)
-            if ((rc = add_f32_into_padded(st, cur, m->cx, B, T, H, LPAD, dt))) return done(rc);
-        }
-    }
-    // decoder.0: causal conv k7 H -> Dd
-    int C = c.c_decoder_dim;
-    if ((rc = prep(alt, T, C))) return done(rc);
-    if ((rc = conv_gemm(m, st, cur, T, H, 7, 1, "codec.dec.in.w", "codec.dec.in.b", alt, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
-    std::swap(cur, alt);
-    for (int i = 0; i < c.n_dec_blocks; ++i) {
-        const std::string q = "codec.dec." + std::to_string(i) + ".";
-        const int r = c.up_rate[i], Co = C >> 1;
-        if ((rc = prep(alt, T, C))) return done(rc);
-        if ((rc = snake(st, cur, alt, TPF(m, q + "snake.a"), TPF(m, q + "snake.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-        if ((rc = prep(tmp, (T - 1) * r, Co))) return done(rc);
-        // transposed conv k=2r, s=r, trimmed r on both sides: out[(t-1)*r + j] = x[t-1].W[j+r] + x[t].W[j], t = 1..T-1
-        {
-            GemmArgs g{};
-            g.A = at(alt, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;   // row t' = t-1 reads [x[t'] | x[t'+1]]
-            g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
-            g.C = at(tmp, (size_t)LPAD * Co * e); g.ldc = (long)r * Co; g.c_bs = (long)(LPAD + (T - 1) * r) * Co;
-            g.M = B * (T - 1); g.N = r * Co; g.K = 2 * C; g.G = T - 1; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
-            if ((rc = gemm_ex(st, g))) return done(rc);
-        }
-        T = (T - 1) * r;
-        C = Co;
-        // x = tmp ; three residual units (dilations 1, 3, 9)
-        void* xbuf = tmp;
-        void* y1 = cur;
-        void* y2 = alt;
-        if ((rc = prep(y1, T, C)) || (rc = prep(y2, T, C))) return done(rc);
-        for (int j = 0; j < 3; ++j) {
-            const std::string u = q + "ru" + std::to_string(j) + ".";
-            const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            if ((rc = snake(st, xbuf, y1, TPF(m, u + "s1.a"), TPF(m, u + "s1.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-            if ((rc = conv_gemm(m, st, y1, T, C, 7, dil, u + "c1.w", u + "c1.b", y2, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
-            if ((rc = snake(st, y2, y1, TPF(m, u + "s2.a"), TPF(m, u + "s2.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-            // 1x1 conv -> f32 scratch, then x += it
-            {
-                GemmArgs g{};
-                g.A = at(y1, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
-                g.W = TP(m, u + "c2.w"); g.bias = TPF(m, u + "c2.b");
-                g.C = y2; g.ldc = C; g.c_bs = (long)T * C;     // unpadded model-dtype scratch
-                g.M = B * T; g.N = C; g.K = C; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
-                if ((rc = gemm_ex(st, g))) return done(rc);
-                if ((rc = add_into_padded(st, xbuf, y2, B, T, C, LPAD, dt))) return done(rc);
-            }
-        }
-        // rotate buffers so that `cur` holds x
-        void* a0 = cur; void* a1 = alt;
-        cur = xbuf; alt = a0; tmp = a1;
-    }
-    // output: snake -> conv k7 C -> 1 (weights padded to 8 output channels), clamp
-    if ((rc = prep(alt, T, C)) || (rc = prep(tmp, T, 1))) return done(rc);
-    if ((rc = snake(st, cur, alt, TPF(m, "codec.dec.out.a"), TPF(m, "codec.dec.out.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-    if ((rc = conv_gemm(m, st, alt, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", tmp, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
-    const long total = T;
-    const long skip = (long)ctx * c.total_upsample;
-    S2S_REQUIRE(n_samples == total - skip, "codec_decode: n_samples %d != %ld", n_samples, total - skip);
-    if ((rc = wav_out(st, tmp, wav_dev, B, T, LPAD, (int)skip, n_samples, dt))) return done(rc);
-    return done(S2S_OK);
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && F >= 1 && F <= m->cfg.max_codec_frames && ctx >= 0 && ctx < F && codes_dev && wav_dev, "codec_decode: bad arguments");
+    return codec_run(m, (hipStream_t)stream, codes_dev, B, F, ctx, false, wav_dev, n_samples);
+}
+
+extern "C" int32_t s2s_codec_stream_reset(void* model) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "codec_stream_reset: model not finalized");
+    m->codec_frames_done = 0;
+    return S2S_OK;
+}
+
+// Streaming continuation: F new frames -> exactly the samples a whole-utterance decode adds for them
+// (first call: s2s_codec_samples(F); later calls: F * total_upsample).
+extern "C" int32_t s2s_codec_stream_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, float* wav_dev,
+                                           int32_t n_samples) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "codec_stream_decode: model not finalized");
+    S2S_REQUIRE(B > 0 && B <= m->max_batch && F >= 1 && F <= m->cfg.max_codec_frames && codes_dev && wav_dev, "codec_stream_decode: bad arguments");
+    S2S_REQUIRE(m->codec_frames_done + F <= m->codec.c.max_pos, "codec_stream_decode: %d frames exceed the stream capacity %d", m->codec_frames_done + F, m->codec.c.max_pos);
+    return codec_run(m, (hipStream_t)stream, codes_dev, B, F, 0, true, wav_dev, n_samples);
 }
 
 extern "C" int64_t s2s_codec_samples(void* model, int32_t F) {

@@ -21,13 +21,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void rope_qknorm_kernel(T* __restrict__ qkv, int T_len, int H, int Hk, int D,
                                                           const float* __restrict__ qw, const float* __restrict__ kw, float eps,
                                                           const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                                          const int* __restrict__ pos0) {
+                                                          const int* __restrict__ pos0, T* __restrict__ kc, T* __restrict__ vc, long c_bs) {
     const int head = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (head >= H + Hk) return;
+    if (head >= H + 2 * Hk) return;
     const int row = blockIdx.y, lane = threadIdx.x & 63;
     const int b = row / T_len, t = row - b * T_len;
     const int pos = (pos0 ? pos0[b] : 0) + t;
     T* x = qkv + (long)row * (H + 2 * Hk) * D + (long)head * D;
+    if (head >= H + Hk) {     // V head: append to the cache (kc != nullptr) - no rotation
+        if (vc) {
+            T* dst = vc + (long)b * c_bs + ((long)pos * Hk + (head - H - Hk)) * D;
+            for (int i = lane; i < D; i += 64) dst[i] = x[i];
+        }
+        return;
+    }
     const float* w = head < H ? qw : kw;
     const int half = D >> 1;
     float a = 0.f, c = 0.f;
@@ -45,16 +52,24 @@ __global__ __launch_bounds__(256) void rope_qknorm_kernel(T* __restrict__ qkv, i
     }
     if (lane < half) {
         const float cs = cosT[(long)pos * half + lane], sn = sinT[(long)pos * half + lane];
-        Elem<T>::st(x + lane, a * cs - c * sn);
-        Elem<T>::st(x + lane + half, c * cs + a * sn);
+        const float r0 = a * cs - c * sn, r1 = c * cs + a * sn;
+        Elem<T>::st(x + lane, r0);
+        Elem<T>::st(x + lane + half, r1);
+        if (kc && head >= H) {   // rotated K head -> cache row of this position
+            T* dst = kc + (long)b * c_bs + ((long)pos * Hk + (head - H)) * D;
+            Elem<T>::st(dst + lane, r0);
+            Elem<T>::st(dst + lane + half, r1);
+        }
     }
 }
 
+// kc / vc (optional): the per-layer KV cache [B][max_pos][Hk*D]; when given, the rotated K and the V of every row are
+// appended at their position in the same launch.
 int rope_qknorm(hipStream_t st, void* qkv, int rows, int T_len, int H, int Hk, int D, const float* qw, const float* kw, float eps,
-                const float* cosT, const float* sinT, const int* pos0, int dtype) {
+                const float* cosT, const float* sinT, const int* pos0, void* kc, void* vc, long c_bs, int dtype) {
     S2S_REQUIRE(D <= 128 && D % 2 == 0, "rope: head_dim %d unsupported", D);
-    dim3 grid(cdiv(H + Hk, 4), rows);
-    S2S_DT(TT, (rope_qknorm_kernel<TT><<<grid, 256, 0, st>>>((TT*)qkv, T_len, H, Hk, D, qw, kw, eps, cosT, sinT, pos0)));
+    dim3 grid(cdiv(H + 2 * Hk, 4), rows);
+    S2S_DT(TT, (rope_qknorm_kernel<TT><<<grid, 256, 0, st>>>((TT*)qkv, T_len, H, Hk, D, qw, kw, eps, cosT, sinT, pos0, (TT*)kc, (TT*)vc, c_bs)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -244,9 +259,19 @@ __global__ void add_into_padded_kernel(T* __restrict__ x, const Y* __restrict__ 
         Elem<T>::st(xb + i, Elem<T>::ld(xb + i) + Elem<Y>::ld(yb + i));
 }
 
-int add_f32_into_padded(hipStream_t st, void* x, const float* y, int B, int Tn, int C, int lpad, int dtype) {
+// dst[b][lpad + t][c] = src[b][lpad + t][c] + y[b][t][c]   (dst, src padded model-dtype buffers; y f32 unpadded)
+template <typename T>
+__global__ void add_f32_padded_kernel(T* __restrict__ dst, const T* __restrict__ src, const float* __restrict__ y, int Tn, int C, int lpad) {
+    const int b = blockIdx.y;
+    const long total = (long)Tn * C;
+    const long off = ((long)b * (lpad + Tn) + lpad) * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        Elem<T>::st(dst + off + i, Elem<T>::ld(src + off + i) + y[(long)b * total + i]);
+}
+
+int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype) {
     dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
-    S2S_DT(TT, (add_into_padded_kernel<TT, float><<<grid, 256, 0, st>>>((TT*)x, y, Tn, C, lpad)));
+    S2S_DT(TT, (add_f32_padded_kernel<TT><<<grid, 256, 0, st>>>((TT*)dst, (const TT*)src, y, Tn, C, lpad)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

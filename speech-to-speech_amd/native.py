@@ -99,6 +99,8 @@ _SIGNATURES = {
     "s2s_tts_generate": [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
     "s2s_codec_decode": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32],
     "s2s_codec_samples": [_vp, _i32],
+    "s2s_codec_stream_reset": [_vp],
+    "s2s_codec_stream_decode": [_vp, _vp, _vp, _i32, _i32, _vp, _i32],
     "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }

@@ -76,7 +76,7 @@ def convert_tts_state_dict(sd: Mapping[str, torch.Tensor], dims: Qwen3TTSDims, d
     _stack(out, sd, "code_predictor.model.", "pred.", dims.p_layers, dtype)
     _stack(out, sd, "code2wav.pre_transformer.", "codec.", dims.c_layers, dtype, layer_scale=True, qk_norm=False)
     for pre, n, hd, th in (("talker.", max_pos, dims.t_head_dim, dims.t_theta), ("pred.", dims.n_groups + 1, dims.p_head_dim, dims.p_theta),
-                           ("codec.", max_codec_frames, dims.c_hidden // dims.c_heads, dims.c_theta)):
+                           ("codec.", max(max_codec_frames, max_pos), dims.c_hidden // dims.c_heads, dims.c_theta)):
         out[pre + "rope.cos"], out[pre + "rope.sin"] = rope_cos_sin(n, hd, th)
     out["talker.norm"] = F32(sd["talker.model.norm.weight"])
     out["talker.emb"] = W(sd["talker.model.codec_embedding.weight"])
@@ -133,6 +133,68 @@ def convert_tts_state_dict(sd: Mapping[str, torch.Tensor], dims: Qwen3TTSDims, d
     n = len(dims.upsample_rates) + 1
     snake("codec.dec.out", f"{d}{n}.alpha", f"{d}{n}.beta")
     out["codec.dec.out.w"] = conv_w(sd[f"{d}{n + 1}.conv.weight"]); out["codec.dec.out.b"] = F32(sd[f"{d}{n + 1}.conv.bias"])
+    return out
+
+
+def random_tts_engine_tensors(dims: Qwen3TTSDims, dtype: torch.dtype, device: torch.device, max_pos: int, max_codec_frames: int,
+                              seed: int = 0) -> dict[str, torch.Tensor]:
+    """Random-init weights generated directly on the GPU in the engine layout (bench: no checkpoints offline)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out: dict[str, torch.Tensor] = {}
+
+    def w(name, rows, cols, std=None):
+        out[name] = (torch.randn((rows, cols), generator=g, device=device, dtype=torch.float32) * (std or cols ** -0.5)).to(dtype)
+
+    def v(name, n, mean=0.0, std=0.02):
+        out[name] = mean + std * torch.randn((n,), generator=g, device=device, dtype=torch.float32)
+
+    def stack(pre, hid, layers, H, Hk, D, ffn, qk_norm, out_scale=1.0):
+        for l in range(layers):
+            q = f"{pre}{l}."
+            v(q + "ln1", hid, 1.0, 0.05); w(q + "qkv.w", (H + 2 * Hk) * D, hid)
+            if qk_norm:
+                v(q + "qnorm", D, 1.0, 0.05); v(q + "knorm", D, 1.0, 0.05)
+            w(q + "o.w", hid, H * D, out_scale * (H * D) ** -0.5); v(q + "ln2", hid, 1.0, 0.05)
+            w(q + "gu.w", 2 * ffn, hid); w(q + "down.w", hid, ffn, out_scale * ffn ** -0.5)
+
+    E, P, H, G, CB = dims.t_hidden, dims.p_hidden, dims.c_hidden, dims.n_groups, dims.codebook
+    stack("talker.", E, dims.t_layers, dims.t_heads, dims.t_kv_heads, dims.t_head_dim, dims.t_ffn, True)
+    stack("pred.", P, dims.p_layers, dims.p_heads, dims.p_kv_heads, dims.p_head_dim, dims.p_ffn, True)
+    stack("codec.", H, dims.c_layers, dims.c_heads, dims.c_heads, H // dims.c_heads, dims.c_ffn, False, out_scale=0.3)
+    for pre, n, hd, th in (("talker.", max_pos, dims.t_head_dim, dims.t_theta), ("pred.", G + 1, dims.p_head_dim, dims.p_theta),
+                           ("codec.", max(max_codec_frames, max_pos), H // dims.c_heads, dims.c_theta)):
+        c, s_ = rope_cos_sin(n, hd, th)
+        out[pre + "rope.cos"], out[pre + "rope.sin"] = c.to(device), s_.to(device)
+    v("talker.norm", E, 1.0, 0.05); w("talker.emb", dims.codec_vocab, E, 1.0); w("talker.head.w", dims.codec_vocab, E)
+    out["talker.pad_embed"] = (0.5 * torch.randn((E,), generator=g, device=device)).to(dtype)
+    eos = torch.zeros(dims.codec_vocab, dtype=torch.uint8, device=device); eos[dims.codec_eos] = 1
+    out["talker.eos_mask"] = eos
+    v("pred.norm", P, 1.0, 0.05)
+    if P != E:
+        w("pred.in_proj.w", P, E); v("pred.in_proj.b", P)
+    for i in range(G - 1):
+        w(f"pred.emb.{i}", CB, E, 1.0); w(f"pred.head.{i}.w", CB, P)
+    w("codec.emb", CB * G, H, 1.0); v("codec.norm", H, 1.0, 0.05)
+    for i, r in enumerate(dims.upsampling_ratios):
+        q = f"codec.up.{i}."
+        w(q + "tconv.w", r * H, H); v(q + "tconv.b", r * H)
+        out[q + "dw.w"] = torch.randn((H, 7), generator=g, device=device) * 7 ** -0.5; v(q + "dw.b", H)
+        v(q + "ln.g", H, 1.0, 0.05); v(q + "ln.b", H)
+        w(q + "pw1.w", 4 * H, H); v(q + "pw1.b", 4 * H); w(q + "pw2.w", H, 4 * H, 0.3 * (4 * H) ** -0.5); v(q + "pw2.b", H)
+    Dd = dims.c_decoder_dim
+    w("codec.dec.in.w", Dd, 7 * H); v("codec.dec.in.b", Dd)
+    for i, r in enumerate(dims.upsample_rates):
+        cin, cout = Dd >> i, Dd >> (i + 1)
+        q = f"codec.dec.{i}."
+        v(q + "snake.a", cin, 1.0, 0.2); v(q + "snake.ib", cin, 1.0, 0.2)
+        w(q + "tconv.w", r * cout, 2 * cin); v(q + "tconv.b", r * cout)
+        for j in range(3):
+            u = f"{q}ru{j}."
+            v(u + "s1.a", cout, 1.0, 0.2); v(u + "s1.ib", cout, 1.0, 0.2); w(u + "c1.w", cout, 7 * cout, 0.5 * (7 * cout) ** -0.5); v(u + "c1.b", cout)
+            v(u + "s2.a", cout, 1.0, 0.2); v(u + "s2.ib", cout, 1.0, 0.2); w(u + "c2.w", cout, cout, 0.5 * cout ** -0.5); v(u + "c2.b", cout)
+    co = Dd >> len(dims.upsample_rates)
+    v("codec.dec.out.a", co, 1.0, 0.2); v("codec.dec.out.ib", co, 1.0, 0.2); w("codec.dec.out.w", 1, 7 * co, 0.05 * (7 * co) ** -0.5)
+    out["codec.dec.out.b"] = torch.zeros(1, device=device)
     return out
 
 
@@ -222,6 +284,14 @@ class TTSEngine:
             native.check(self._lib.s2s_tts_finalize(h), "s2s_tts_finalize")
             self._fir = torch.from_numpy(resample_fir_2_3()).to(self.device)
         self._B = 0
+        self._stream_frames = 0
+
+    @classmethod
+    def from_random(cls, dims: Qwen3TTSDims, dtype: torch.dtype = torch.bfloat16, max_batch: int = 8, max_prompt: int = 128, max_frames: int = 128,
+                    max_codec_frames: int = 33, device: str | torch.device = "cuda:0", seed: int = 0) -> "TTSEngine":
+        dev = torch.device(device)
+        t = random_tts_engine_tensors(dims, dtype, dev, max_prompt + max_frames, max_codec_frames, seed)
+        return cls(dims, None, dtype, max_batch, max_prompt, max_frames, max_codec_frames, None, dev, engine_tensors=t)
 
     @property
     def workspace_bytes(self) -> int:
@@ -271,6 +341,21 @@ class TTSEngine:
             native.check(self._lib.s2s_codec_decode(self._h, native.stream_handle(), native.ptr(codes), B, F, ctx, native.ptr(wav), n), "s2s_codec_decode")
         return wav
 
+    def codec_stream_reset(self) -> None:
+        native.check(self._lib.s2s_codec_stream_reset(self._h), "s2s_codec_stream_reset")
+        self._stream_frames = 0
+
+    def codec_stream_decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """Exact causal continuation: codes int32 [B][F_new][G] -> the float32 24 kHz samples a whole-utterance decode adds."""
+        B, F, _ = codes.shape
+        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        n = self.codec_samples(F) if self._stream_frames == 0 else F * self.dims.total_upsample
+        wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_codec_stream_decode(self._h, native.stream_handle(), native.ptr(codes), B, F, native.ptr(wav), n), "s2s_codec_stream_decode")
+        self._stream_frames += F
+        return wav
+
     def resample_int16(self, wav24: torch.Tensor, n_valid: torch.Tensor | None = None, want_float: bool = False):
         """Per-row scipy.signal.resample_poly(x, 2, 3) then clip(x*32768).astype(int16) -> int16 [B][ceil(2n/3)]."""
         B, n = wav24.shape
@@ -289,30 +374,26 @@ class TTSEngine:
         """Yields, every `chunk_size` frames, one int16 16 kHz numpy chunk per session (None once a session ended)."""
         B = len(prompts)
         self.prefill(prompts)
+        self.codec_stream_reset()
         budget = max(max_new_tokens)
-        history = torch.empty((B, 0, self.dims.n_groups), dtype=torch.int32, device=self.device)
         produced = 0
         while produced < budget:
             n = min(chunk_size, budget - produced)
             codes, nfr, all_done = self.generate(n, min_total_frames=min_frames)
             nfr_h = nfr.cpu().numpy()
-            history = torch.cat([history, codes], 1)
-            ctx = min(ctx_frames, produced)
-            window = history[:, produced - ctx : produced + n].contiguous()
-            wav = self.codec_decode(window.clamp(min=0), ctx)
+            if ctx_frames < 0:
+                raise ValueError("ctx_frames must be >= 0")
+            wav = self.codec_stream_decode(codes.clamp(min=0).contiguous())     # exact causal streaming: nothing is recomputed
             pcm16 = self.resample_int16(wav).cpu().numpy()
             out: list[np.ndarray | None] = []
             for b in range(B):
                 valid = int(min(nfr_h[b], max_new_tokens[b])) - produced
                 if valid <= 0:
                     out.append(None)
-                    continue
-                if valid >= n:
+                elif valid >= n:
                     out.append(pcm16[b])
-                else:
-                    # the utterance ended inside this chunk: keep only the samples of its valid frames
-                    keep = (2 * (self.codec_samples(ctx + valid) - ctx * self.dims.total_upsample) + 2) // 3
-                    out.append(pcm16[b][:keep])
+                else:   # the utterance ended inside this chunk: keep only the samples of its valid frames
+                    out.append(pcm16[b][: (2 * valid * self.dims.total_upsample + 2) // 3])
             produced += n
             yield out
             if all_done:

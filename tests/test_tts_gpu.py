@@ -69,6 +69,13 @@ def test_f32_codes_exact_and_waveform_close(ref):
     with torch.no_grad():
         ref_c = OT.codec_decode(sd, dims.codec_cfg(), codes[:, 2:10].permute(0, 2, 1))[:, 0][:, ctx * dims.total_upsample :]
     assert wc.shape == ref_c.shape and (wc - ref_c).abs().max().item() < 2e-3
+    # exact causal streaming: chunks of 3, 3 and 4 frames concatenate to the whole-utterance decode
+    eng.codec_stream_reset()
+    parts = [eng.codec_stream_decode(got[:, a:b].to(eng.device).contiguous()).cpu() for a, b in ((0, 3), (3, 6), (6, 10))]
+    ws = torch.cat(parts, 1)
+    err_s = (ws - wav).abs().max().item()
+    print(f"f32 streamed codec (3+3+4 frames) vs whole-utterance oracle: max_abs_err={err_s:.3e}, chunk samples {[p.shape[1] for p in parts]}")
+    assert ws.shape == wav.shape and err_s < 2e-3
     eng.close()
 
 
