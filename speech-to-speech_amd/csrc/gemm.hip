@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 template <typename T, typename CT, int MT, bool GLU>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm, int ksplit) {
     constexpr int EPC = MfmaTraits<T>::EPC;          // k per 16-byte load: 8 (bf16) / 4 (f32)
     constexpr int KB = EPC * 4;                      // k consumed per load step by the 4 lane groups: 32 / 16
     constexpr int U = GLU ? 4 : 8;                   // load steps in flight per wave
@@ -241,10 +241,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
         if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    // blockIdx.x = n-slab * ksplit + k-part: with ksplit > 1 (bf16 serving policy, residual GEMMs with few columns)
+    // several workgroups share a slab and add their partial tiles onto the in-place residual with f32 atomics
+    const int kpart = blockIdx.x % ksplit;
+    const int n0 = (blockIdx.x / ksplit) * 16;
     const int n = n0 + l15;
-    const int kslice = ((K + 7) / 8 + KB - 1) / KB * KB;
-    const int kbeg = wave * kslice, kend = min(K, kbeg + kslice);
+    const int kblk = ((K + ksplit - 1) / ksplit + KB - 1) / KB * KB;
+    const int kb0 = kpart * kblk, kb1 = min(K, kb0 + kblk);
+    const int kslice = ((kblk + 7) / 8 + KB - 1) / KB * KB;
+    const int kbeg = kb0 + wave * kslice, kend = min(kb1, kbeg + kslice);
 
     f32x4_t acc[MT * NW];
 #pragma unroll
@@ -264,10 +269,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u * KB + lg * EPC;
             fw[u] = (u32x4_t){0u, 0u, 0u, 0u};
-            if (nvalid && k < kend) fw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + k));
+            if (nvalid && k < kend) fw[u] = *reinterpret_cast<const u32x4_t*>(wrow + k);
             if constexpr (GLU) {
                 fw2[u] = (u32x4_t){0u, 0u, 0u, 0u};
-                if (nvalid && k < kend) fw2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow2 + k));
+                if (nvalid && k < kend) fw2[u] = *reinterpret_cast<const u32x4_t*>(wrow2 + k);
             }
         }
 #pragma unroll
@@ -317,10 +322,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
             for (int w = 0; w < 8; ++w) u2 += red[w][MT + i][l][r];
             v = v / (1.0f + expf(-v)) * u2;
         }
-        v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
         const int mb = m / rm.G, mr = m % rm.G;
+        CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + nn;
+        if (ksplit > 1) {   // C (f32) already holds the residual; act == NONE
+            if constexpr (sizeof(CT) == 4)
+                atomicAdd(reinterpret_cast<float*>(cp), (v + ((bias && kpart == 0) ? bias[nn] : 0.f)) * rm.alpha);
+            continue;
+        }
+        v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
         if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + nn];
-        Elem<CT>::st(C + (long)mb * rm.c_bs + (long)mr * ldc + nn, v);
+        Elem<CT>::st(cp, v);
     }
 }
 
@@ -343,13 +354,21 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     const int M = g.M, N = g.N, K = g.K;
     if (M <= 128 && !(g.glu && M > 64)) {
         const int MT = cdiv(M, 16);
-        dim3 grid(cdiv(N, 16), nz);
+        const int slabs = cdiv(N, 16);
+        int ksplit = 1;
+        // few-column residual GEMMs (out / down projections) would leave most CUs idle: split K across workgroups
+        const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
+        if (g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 && in_place && !g.glu) {
+            constexpr int KB = MfmaTraits<T>::EPC * 4;
+            while (slabs * ksplit < 384 && ksplit < 8 && K / (ksplit * 2) >= 8 * KB) ksplit *= 2;
+        }
+        dim3 grid(slabs * ksplit, nz);
         ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
 #define S2S_SKINNY(MTV, GLUV)                                                                          \
     gemm_skinny_kernel<T, CT, MTV, GLUV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
                                                                g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
-                                                               N, K, g.act, rm)
+                                                               N, K, g.act, rm, ksplit)
         if (g.glu) {
             switch (MT) {
                 case 1: S2S_SKINNY(1, true); break;
