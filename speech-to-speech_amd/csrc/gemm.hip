@@ -4,12 +4,13 @@
 // operands are read along K ("B^T input"): no transposes anywhere on the path.
 //
 //  * gemm_tile_kernel   : 128x128 output tile per 256-thread workgroup (2x2 waves, each
-//                         a 4x4 grid of 16x16 MFMA fragments), K staged through LDS in
-//                         128-byte rows with a 16-byte-chunk XOR swizzle so that both the
-//                         ds_write_b128 staging stores and the fragment reads are
-//                         conflict-free; the next K-slab is already in flight in registers
-//                         while the current one is multiplied.  Workgroup ids are remapped
-//                         so that each XCD's L2 sees a contiguous band of N-tiles sharing W.
+//                         a 4x4 grid of 16x16 MFMA fragments), K-slabs land in LDS by
+//                         direct global->LDS loads (global_load_lds_dwordx4, no VGPR round
+//                         trip) into two stages: slab t+1 is in flight while slab t is
+//                         multiplied, one barrier per slab.  128-byte LDS rows with a
+//                         16-byte-chunk XOR swizzle (applied on the source address) keep the
+//                         ds_read_b128 fragment reads conflict-free.  Workgroup ids are
+//                         remapped so each XCD's L2 sees a contiguous band of tiles sharing W.
 //  * gemm_skinny_kernel : M <= 64 (decode steps: one row per live session).  Weights are
 //                         streamed exactly once straight from HBM into MFMA B-fragments
 //                         (no LDS staging), activations come from L2; one 8-wave workgroup
@@ -70,15 +71,18 @@ struct RowMap {
     long tap_stride;                //      (dilated 1-D convolution taps over a time-major buffer)
 };
 
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];   // source of out-of-range chunks
+
 template <typename T, typename CT>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
     constexpr int EPC = MfmaTraits<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
-    unsigned char* sA = lds;
-    unsigned char* sW = lds + TILE_BYTES;
+    // two stages x (A tile | W tile); filled by direct global->LDS loads (global_load_lds_dwordx4: the wave's 64 lanes
+    // land as one linear 1 KiB piece), so the XOR swizzle is applied to the per-lane SOURCE address: LDS chunk
+    // (row, p) holds logical chunk p ^ (row & 7) of that row, and the fragment reads use the same involution.
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * TILE_BYTES];
 
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
@@ -102,58 +106,54 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread
-    u32x4_t ga[4], gw[4];
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread; chunk c -> (row c>>3, physical slot c&7)
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
     const T* arow[4];
     const T* wrow[4];
+    int lch[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + i * 256;
-        const int row = c >> 3, ch = c & 7;
+        const int row = c >> 3;
+        lch[i] = (c & 7) ^ (row & 7);
         const int m = m0 + row, n = n0 + row;
         arow[i] = nullptr;
-        wrow[i] = nullptr;
-        if (m < M) arow[i] = A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda + ch * EPC;
-        if (n < N) wrow[i] = W + (long)n * rm.ldw + ch * EPC;
+        if (m < M) arow[i] = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+        wrow[i] = n < N ? W + (long)n * rm.ldw : nullptr;
     }
-    auto load_tile = [&](int k0) {
+    const int wave_base = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
+    auto issue = [&](int k0, int stage) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ch = (tid + i * 256) & 7;
-            const int k = k0 + ch * EPC;
-            u32x4_t va = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+            const int k = k0 + lch[i] * EPC;
+            const T* pa = zero;
+            const T* pw = zero;
             if (k < K) {
                 if (arow[i]) {
-                    long ao = k0;
+                    long ao = k;
                     if (rm.tap_len > 0) {
                         const int tap = k / rm.tap_len;
-                        ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len) - ch * EPC;
+                        ao = (long)tap * rm.tap_stride + (k - tap * rm.tap_len);
                     }
-                    va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                    pa = arow[i] + ao;
                 }
-                if (wrow[i]) vw = *reinterpret_cast<const u32x4_t*>(wrow[i] + k0);
+                if (wrow[i]) pw = wrow[i] + k;
             }
-            ga[i] = va;
-            gw[i] = vw;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256;
-            const int row = c >> 3, ch = c & 7;
-            const int off = row * ROWB + ((ch ^ (row & 7)) << 4);
-            *reinterpret_cast<u32x4_t*>(sA + off) = ga[i];
-            *reinterpret_cast<u32x4_t*>(sW + off) = gw[i];
+            unsigned char* dst = &lds[stage][0] + i * 4096 + wave_base;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw,
+                                             (__attribute__((address_space(3))) void*)(dst + TILE_BYTES), 16, 0, 0);
         }
     };
 
     const int nk = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
+    issue(0, 0);
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile((t + 1) * BK);
+        __syncthreads();     // tile t has landed (vmcnt drained) and every wave is done reading the other stage
+        if (t + 1 < nk) issue((t + 1) * BK, (t + 1) & 1);
+        const unsigned char* sA = &lds[t & 1][0];
+        const unsigned char* sW = sA + TILE_BYTES;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -189,31 +189,41 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fw[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
-        if (t + 1 < nk) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
-    // epilogue: C fragment (i,j): row = lg*4 + r, col = l15
+    // epilogue: C fragment (i,j): row = lg*4 + r, col = l15.  Rows outermost so the row mapping (a division only when the
+    // rows are grouped, i.e. conv / batched layouts) is computed once per row instead of once per element.
+    float bv[4];
+    int ncol[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn + j * 16 + l15;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + lg * 4 + r;
-                if (m >= M) continue;
-                const int mb = m / rm.G, mr = m % rm.G;
-                float v = apply_act(acc[i][j][r] + bv, act) * rm.alpha;
-                if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + n];
-                Elem<CT>::st(C + (long)mb * rm.c_bs + (long)mr * ldc + n, v);
-            }
+        ncol[j] = n0 + wn + j * 16 + l15;
+        bv[j] = (bias && ncol[j] < N) ? bias[ncol[j]] : 0.f;
     }
+    const bool grouped = rm.G < M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + i * 16 + lg * 4 + r;
+            if (m >= M) continue;
+            long coff, roff;
+            if (grouped) {
+                const int mb = m / rm.G, mr = m - mb * rm.G;
+                coff = (long)mb * rm.c_bs + (long)mr * ldc;
+                roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+            } else {
+                coff = (long)m * ldc;
+                roff = (long)m * rm.ldr;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ncol[j] >= N) continue;
+                float v = apply_act(acc[i][j][r] + bv[j], act) * rm.alpha;
+                if (residual) v += residual[roff + ncol[j]];
+                Elem<CT>::st(C + coff + ncol[j], v);
+            }
+        }
 }
 
 // ---- skinny (decode) GEMM --------------------------------------------------
