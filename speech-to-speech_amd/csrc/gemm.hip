@@ -232,17 +232,20 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
 // an MFMA B-fragment (16 B per lane, all loads of a wave's slice in flight together), activations come from L2 as
 // A-fragments.  The 8 partial accumulators are combined through LDS (deterministic - no atomics), then the full
 // epilogue (bias, activation, alpha, residual, cast) runs on the combined tile.  grid = ceil(N/16) workgroups.
-// GLU = true: W holds [gate rows | up rows] (N each); the workgroup accumulates both for its 16 channels and the
+// NF = 16-column fragments per workgroup: every activation fragment a wave fetches is reused for NF weight
+// fragments (the fragment-shaped activation loads, not the weight stream, are what saturates the load path at M = 64).
+// GLU = true: W holds [gate rows | up rows] (N each); the workgroup accumulates both for its channels and the
 // epilogue writes silu(gate) * up (SwiGLU fused, output width N).
-template <typename T, typename CT, int MT, bool GLU>
+template <typename T, typename CT, int MT, int NF, bool GLU>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm, int ksplit) {
     constexpr int EPC = MfmaTraits<T>::EPC;          // k per 16-byte load: 8 (bf16) / 4 (f32)
     constexpr int KB = EPC * 4;                      // k consumed per load step by the 4 lane groups: 32 / 16
-    constexpr int U = GLU ? 4 : 8;                   // load steps in flight per wave
-    constexpr int NW = GLU ? 2 : 1;
-    __shared__ float red[8][MT * NW][64][4];
+    constexpr int NS = NF * (GLU ? 2 : 1);           // weight streams per wave
+    constexpr int U = 8 / NS;                        // load steps in flight per stream
+    constexpr int RS = GLU ? 2 * MT : MT;
+    __shared__ float red[8][RS][64][4];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
         A += z1 * rm.a_z1 + z2 * rm.a_z2;
@@ -254,35 +257,39 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     // blockIdx.x = n-slab * ksplit + k-part: with ksplit > 1 (bf16 serving policy, residual GEMMs with few columns)
     // several workgroups share a slab and add their partial tiles onto the in-place residual with f32 atomics
     const int kpart = blockIdx.x % ksplit;
-    const int n0 = (blockIdx.x / ksplit) * 16;
-    const int n = n0 + l15;
+    const int n0 = (blockIdx.x / ksplit) * 16 * NF;
     const int kblk = ((K + ksplit - 1) / ksplit + KB - 1) / KB * KB;
     const int kb0 = kpart * kblk, kb1 = min(K, kb0 + kblk);
     const int kslice = ((kblk + 7) / 8 + KB - 1) / KB * KB;
     const int kbeg = kb0 + wave * kslice, kend = min(kb1, kbeg + kslice);
 
-    f32x4_t acc[MT * NW];
+    f32x4_t acc[MT][NS];
 #pragma unroll
-    for (int i = 0; i < MT * NW; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bool nvalid = n < N;
-    const T* wrow = W + (long)(nvalid ? n : 0) * rm.ldw;
-    const T* wrow2 = wrow + (long)N * rm.ldw;        // GLU: the "up" row of the same channel
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[i][s] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const T* wrow[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int n = n0 + (s % NF) * 16 + l15;
+        wrow[s] = n < N ? W + ((long)n + (s >= NF ? N : 0)) * rm.ldw : nullptr;
+    }
     const T* arow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + l15;
-        arow[i] = m < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : nullptr;
+        arow[i] = nullptr;
+        if (m < M) arow[i] = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
     }
     for (int k0 = kbeg; k0 < kend; k0 += U * KB) {
-        u32x4_t fw[U], fw2[GLU ? U : 1];
+        u32x4_t fw[U][NS];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u * KB + lg * EPC;
-            fw[u] = (u32x4_t){0u, 0u, 0u, 0u};
-            if (nvalid && k < kend) fw[u] = *reinterpret_cast<const u32x4_t*>(wrow + k);
-            if constexpr (GLU) {
-                fw2[u] = (u32x4_t){0u, 0u, 0u, 0u};
-                if (nvalid && k < kend) fw2[u] = *reinterpret_cast<const u32x4_t*>(wrow2 + k);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                fw[u][s] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (wrow[s] && k < kend) fw[u][s] = *reinterpret_cast<const u32x4_t*>(wrow[s] + k);
             }
         }
 #pragma unroll
@@ -297,51 +304,65 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
             for (int i = 0; i < MT; ++i) {
                 u32x4_t va = {0u, 0u, 0u, 0u};
                 if (arow[i] && k < kend) va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
-                if constexpr (sizeof(T) == 2) {
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, fw[u]), acc[i], 0, 0, 0);
-                    if constexpr (GLU)
-                        acc[MT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, fw2[u]), acc[MT + i], 0, 0, 0);
-                } else {
-                    // lane (lg, .) holds k = kb + lg*4 + s for both operands; MFMA step s pairs element s of each
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[s4]), __uint_as_float(fw[u][s4]), acc[i], 0, 0, 0);
-                        if constexpr (GLU)
-                            acc[MT + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[s4]), __uint_as_float(fw2[u][s4]), acc[MT + i], 0, 0, 0);
+                for (int s = 0; s < NS; ++s) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, fw[u][s]), acc[i][s], 0, 0, 0);
+                    } else {
+                        // lane (lg, .) holds k = kb + lg*4 + e for both operands; MFMA step e pairs element e of each
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4)
+                            acc[i][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[e4]), __uint_as_float(fw[u][s][e4]), acc[i][s], 0, 0, 0);
                     }
                 }
             }
         }
     }
+    const bool grouped = rm.G < M;
 #pragma unroll
-    for (int i = 0; i < MT * NW; ++i)
+    for (int f = 0; f < NF; ++f) {
+        if (f > 0) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][i][lane][r] = acc[i][r];
-    __syncthreads();
-    // combined tile element e -> (fragment i, lane l, reg r): row = i*16 + (l>>4)*4 + r, col = l & 15
-    for (int e = tid; e < MT * 256; e += 512) {
-        const int i = e >> 8, l = (e >> 2) & 63, r = e & 3;
-        const int m = i * 16 + (l >> 4) * 4 + r, nn = n0 + (l & 15);
-        if (m >= M || nn >= N) continue;
-        float v = 0.f;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[w][i][l][r];
-        if constexpr (GLU) {
-            float u2 = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                red[wave][i][lane][r] = acc[i][f][r];
+                if constexpr (GLU) red[wave][MT + i][lane][r] = acc[i][NF + f][r];
+            }
+        __syncthreads();
+        // combined tile element e -> (fragment i, lane l, reg r): row = i*16 + (l>>4)*4 + r, col = l & 15
+        for (int e = tid; e < MT * 256; e += 512) {
+            const int i = e >> 8, l = (e >> 2) & 63, r = e & 3;
+            const int m = i * 16 + (l >> 4) * 4 + r, nn = n0 + f * 16 + (l & 15);
+            if (m >= M || nn >= N) continue;
+            float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) u2 += red[w][MT + i][l][r];
-            v = v / (1.0f + expf(-v)) * u2;
+            for (int w = 0; w < 8; ++w) v += red[w][i][l][r];
+            if constexpr (GLU) {
+                float u2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) u2 += red[w][MT + i][l][r];
+                v = v / (1.0f + expf(-v)) * u2;
+            }
+            long coff, roff;
+            if (grouped) {
+                const int mb = m / rm.G, mr = m - mb * rm.G;
+                coff = (long)mb * rm.c_bs + (long)mr * ldc;
+                roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+            } else {
+                coff = (long)m * ldc;
+                roff = (long)m * rm.ldr;
+            }
+            CT* cp = C + coff + nn;
+            if (ksplit > 1) {   // C (f32) already holds the residual; act == NONE
+                if constexpr (sizeof(CT) == 4)
+                    atomicAdd(reinterpret_cast<float*>(cp), (v + ((bias && kpart == 0) ? bias[nn] : 0.f)) * rm.alpha);
+                continue;
+            }
+            v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
+            if (residual) v += residual[roff + nn];
+            Elem<CT>::st(cp, v);
         }
-        const int mb = m / rm.G, mr = m % rm.G;
-        CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + nn;
-        if (ksplit > 1) {   // C (f32) already holds the residual; act == NONE
-            if constexpr (sizeof(CT) == 4)
-                atomicAdd(reinterpret_cast<float*>(cp), (v + ((bias && kpart == 0) ? bias[nn] : 0.f)) * rm.alpha);
-            continue;
-        }
-        v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
-        if (residual) v += residual[(long)mb * rm.r_bs + (long)mr * rm.ldr + nn];
-        Elem<CT>::st(cp, v);
     }
 }
 
@@ -364,41 +385,50 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     const int M = g.M, N = g.N, K = g.K;
     if (M <= 128 && !(g.glu && M > 64)) {
         const int MT = cdiv(M, 16);
-        const int slabs = cdiv(N, 16);
+        int NF = 1;
+        if (MT <= 4) {
+            if (g.glu) NF = N >= 4096 ? 2 : 1;
+            else NF = N >= 8192 ? 4 : (N >= 2048 ? 2 : 1);
+        }
+        const int slabs = cdiv(N, 16 * NF);
         int ksplit = 1;
         // few-column residual GEMMs (out / down projections) would leave most CUs idle: split K across workgroups
         const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
         if (g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 && in_place && !g.glu) {
             constexpr int KB = MfmaTraits<T>::EPC * 4;
-            while (slabs * ksplit < 384 && ksplit < 8 && K / (ksplit * 2) >= 8 * KB) ksplit *= 2;
+            while (slabs * ksplit < 256 && ksplit < 8 && K / (ksplit * 2) >= 8 * KB) ksplit *= 2;
         }
         dim3 grid(slabs * ksplit, nz);
-        ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz,
-                       ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-#define S2S_SKINNY(MTV, GLUV)                                                                          \
-    gemm_skinny_kernel<T, CT, MTV, GLUV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W,     \
-                                                               g.bias, g.residual, (CT*)g.C, g.ldc, M,  \
-                                                               N, K, g.act, rm, ksplit)
-        if (g.glu) {
+        ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz * (g.glu ? 2 : 1),
+                       ((double)N * K * sizeof(T) * (g.glu ? 2 : 1) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+#define S2S_SK(MTV, NFV, GLUV)                                                                                  \
+    gemm_skinny_kernel<T, CT, MTV, NFV, GLUV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W, g.bias, \
+                                                                     g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, rm, ksplit)
+#define S2S_SK_MT(NFV, GLUV)                  \
+    switch (MT) {                             \
+        case 1: S2S_SK(1, NFV, GLUV); break;  \
+        case 2: S2S_SK(2, NFV, GLUV); break;  \
+        case 3: S2S_SK(3, NFV, GLUV); break;  \
+        default: S2S_SK(4, NFV, GLUV); break; \
+    }
+        if (MT > 4) {
             switch (MT) {
-                case 1: S2S_SKINNY(1, true); break;
-                case 2: S2S_SKINNY(2, true); break;
-                case 3: S2S_SKINNY(3, true); break;
-                default: S2S_SKINNY(4, true); break;
+                case 5: S2S_SK(5, 1, false); break;
+                case 6: S2S_SK(6, 1, false); break;
+                case 7: S2S_SK(7, 1, false); break;
+                default: S2S_SK(8, 1, false); break;
             }
+        } else if (g.glu) {
+            if (NF == 2) { S2S_SK_MT(2, true) } else { S2S_SK_MT(1, true) }
+        } else if (NF == 4) {
+            S2S_SK_MT(4, false)
+        } else if (NF == 2) {
+            S2S_SK_MT(2, false)
         } else {
-            switch (MT) {
-                case 1: S2S_SKINNY(1, false); break;
-                case 2: S2S_SKINNY(2, false); break;
-                case 3: S2S_SKINNY(3, false); break;
-                case 4: S2S_SKINNY(4, false); break;
-                case 5: S2S_SKINNY(5, false); break;
-                case 6: S2S_SKINNY(6, false); break;
-                case 7: S2S_SKINNY(7, false); break;
-                default: S2S_SKINNY(8, false); break;
-            }
+            S2S_SK_MT(1, false)
         }
-#undef S2S_SKINNY
+#undef S2S_SK_MT
+#undef S2S_SK
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
