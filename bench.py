@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--sessions", type=int, default=None, help="concurrent sessions per GPU (default: 64 for c3, 1 for c2)")
     ap.add_argument("--decode-tokens", type=int, default=32, help="Whisper greedy tokens per utterance (eos masked)")
     ap.add_argument("--stt-only", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream (default: the TTS leg of step i "
+                                                          "overlaps the STT leg of step i+1 on a second stream/thread, as the session pool does)")
+    ap.add_argument("--tts-streams", type=int, default=1, help="split the pool's TTS batch over this many engine replicas (shared weights), "
+                                                               "each on its own HIP stream + host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-kernel-family and per-stage times on stderr")
     return ap.parse_args()
@@ -224,31 +228,102 @@ def main():
             return [[t for t in tk if t != pd.blank] for tk in toks]
 
     tts = None
+    tts_replicas = []
     if not args.stt_only:
-        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
+        K = max(1, args.tts_streams)
+        assert B % K == 0
+        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B // K, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
+        tts_replicas = [tts] + [TTSEngine(tdims, None, torch.bfloat16, B // K, 128, n_frames, 33, None, dev, engine_tensors=tts._weights) for _ in range(K - 1)]
         g = torch.Generator().manual_seed(7)
         front = ByteTextFrontend((torch.randn(258, tdims.t_hidden, generator=g)).numpy())
     codec = IdTextCodec()
     stage = {"stt": 0.0, "tts_first_chunk": 0.0, "tts_total": 0.0}
 
+    def run_tts_one(eng, ids, t0):
+        ttfa, n_chunks = None, 0
+        prompts = [TTSPrompt(front.embed(codec.decode(i)[:100], 128)) for i in ids]       # echo "LLM"
+        for chunks in eng.stream(prompts, [n_frames] * len(ids), chunk_size=8, ctx_frames=25, min_frames=n_frames):
+            if ttfa is None:
+                ttfa = time.perf_counter() - t0
+            n_chunks += 1
+        assert n_chunks == n_frames // 8
+        return ttfa
+
+    def run_tts(ids, t0):
+        K = len(tts_replicas)
+        if K == 1:
+            return run_tts_one(tts, ids, t0)
+        import threading
+
+        per = len(ids) // K
+        res, errs = [None] * K, []
+
+        def work(k):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    res[k] = run_tts_one(tts_replicas[k], ids[k * per:(k + 1) * per], t0)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(K)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        if errs:
+            raise errs[0]
+        return max(res)
+
     def step():
         t0 = time.perf_counter()
         ids = run_stt()
         t1 = time.perf_counter()
-        ttfa = None
-        n_chunks = 0
-        if tts is not None:
-            prompts = [TTSPrompt(front.embed(codec.decode(i)[:100], 128)) for i in ids]       # echo "LLM"
-            for chunks in tts.stream(prompts, [n_frames] * B, chunk_size=8, ctx_frames=25, min_frames=n_frames):
-                if ttfa is None:
-                    ttfa = time.perf_counter() - t0
-                n_chunks += 1
-            assert n_chunks == n_frames // 8
+        ttfa = run_tts(ids, t0) if tts is not None else None
         t2 = time.perf_counter()
         stage["stt"] += t1 - t0
         stage["tts_total"] += t2 - t1
         stage["tts_first_chunk"] += (ttfa or 0.0) - (t1 - t0)
         return ttfa
+
+    def run_steps(n):
+        """n steps; unless --serial the TTS leg of step i runs on its own thread + HIP stream while step i+1's STT leg runs."""
+        if args.serial or tts is None:
+            return [step() for _ in range(n)]
+        import queue
+        import threading
+
+        q: "queue.Queue" = queue.Queue(maxsize=1)
+        out, err = [], []
+        tts_stream = torch.cuda.Stream(device=dev)
+
+        def tts_worker():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(tts_stream):
+                    while True:
+                        item = q.get()
+                        if item is None:
+                            return
+                        ids, t0 = item
+                        ta = time.perf_counter()
+                        out.append(run_tts(ids, t0))
+                        stage["tts_total"] += time.perf_counter() - ta
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+
+        th = threading.Thread(target=tts_worker)
+        th.start()
+        for _ in range(n):
+            t0 = time.perf_counter()
+            ids = run_stt()
+            stage["stt"] += time.perf_counter() - t0
+            q.put((ids, t0))
+            if err:
+                break
+        q.put(None)
+        th.join()
+        if err:
+            raise err[0]
+        return out
 
     def barrier():
         if world > 1:
@@ -257,15 +332,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     for k in stage:
         stage[k] = 0.0
     cats = {"gemm_tile": native.PROF_GEMM_TILE, "gemm_skinny": native.PROF_GEMM_SKINNY, "attn_mfma": native.PROF_ATTN_MFMA, "attn_rows": native.PROF_ATTN_ROWS}
     native.prof_enable(*cats.values())
     barrier()
     t0 = time.perf_counter()
-    ttfas = [step() for _ in range(args.steps)]
+    ttfas = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof = {k: native.prof_collect(c) for k, c in cats.items()}
@@ -309,6 +383,8 @@ def main():
                                f"{n_frames} codec frames ({n_frames / 12.5:.2f} s reply) streamed in 8-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames / 12.5,
                    "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
+                   "tts_streams": len(tts_replicas),
+                   "schedule": "serial" if (args.serial or tts is None) else "pipelined: TTS leg of turn-batch i overlaps STT leg of turn-batch i+1 (2 HIP streams)",
                    "parallelism": f"session-pool x{world} (no collectives)"},
         "p50_ttfa_ms": ttfa_ms,
         "ttfa_note": "all sessions of the pool end their utterance at t=0; TTFA = STT batch + TTS prefill + first 8-frame chunk + codec + resample + D2H",

@@ -327,7 +327,7 @@ static int tdt_greedy(Parakeet* m, hipStream_t st, int max_steps, int* out_tok, 
 using namespace s2s;
 
 extern "C" int32_t s2s_parakeet_create(const s2s_parakeet_config* cfg, int32_t max_batch, void** out) {
-    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 64, "parakeet_create: bad arguments (max_batch 1..64)");
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 128, "parakeet_create: bad arguments (max_batch 1..128)");
     S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "parakeet_create: bad dtype");
     S2S_REQUIRE(cfg->d_model % cfg->n_heads == 0 && cfg->d_model % 64 == 0 && cfg->n_mels % 8 == 0 && cfg->ffn % 8 == 0 &&
                     cfg->sub_channels % 8 == 0 && cfg->dec_hidden % 8 == 0 && cfg->dec_layers >= 1 && cfg->dec_layers <= 4,

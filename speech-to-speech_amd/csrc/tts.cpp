@@ -413,7 +413,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B, int frame) {
 using namespace s2s;
 
 extern "C" int32_t s2s_tts_create(const s2s_tts_config* cfg, int32_t max_batch, void** out) {
-    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 64, "tts_create: bad arguments (max_batch 1..64)");
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 128, "tts_create: bad arguments (max_batch 1..128)");
     S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "tts_create: bad dtype");
     S2S_REQUIRE(cfg->t_hidden % 8 == 0 && cfg->p_hidden % 8 == 0 && cfg->c_hidden % 8 == 0 && cfg->t_ffn % 8 == 0 && cfg->p_ffn % 8 == 0 &&
                     cfg->c_ffn % 8 == 0 && cfg->n_dec_blocks >= 1 && cfg->n_dec_blocks <= 4 && (cfg->c_decoder_dim >> cfg->n_dec_blocks) % 8 == 0,

@@ -303,7 +303,7 @@ __global__ void whisper_advance_kernel(const int* __restrict__ picked, const int
 using namespace s2s;
 
 extern "C" int32_t s2s_whisper_create(const s2s_whisper_config* cfg, int32_t max_batch, void** out) {
-    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 64, "whisper_create: bad arguments (max_batch 1..64)");
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 128, "whisper_create: bad arguments (max_batch 1..128)");
     S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "whisper_create: bad dtype");
     S2S_REQUIRE(cfg->d_model % cfg->n_heads == 0 && cfg->d_model % 8 == 0 && cfg->n_mels % 8 == 0 && cfg->ffn % 8 == 0,
                 "whisper_create: dimensions must be multiples of 8");
