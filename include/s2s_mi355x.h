@@ -61,6 +61,11 @@ int32_t s2s_device_count(void);
 #define S2S_PROF_NCAT 8
 int32_t s2s_prof_enable(uint32_t category_mask);
 int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches);
+/* The autoregressive loops (TTS codec frames, Whisper decode steps) keep every per-step quantity on the
+ * device and replay one captured hipGraph per step.  on = 0 forces plain stream launches (the same kernels,
+ * the same results); graphs are also bypassed while kernel timing is enabled.  Default on; the environment
+ * variable S2S_NO_GRAPHS=1 starts with it off. */
+int32_t s2s_graphs_enable(int32_t on);
 
 /* ------------------------------------------------------------------------- *
  * Log-mel front-ends.

@@ -56,6 +56,10 @@ class ProfScope {
     void* stop_ = nullptr;
 };
 
+// decode loops replay captured graphs unless kernel timing is on (events cannot be recorded inside a replay)
+bool prof_active();
+bool graphs_enabled();
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers --------------------------------------------------------

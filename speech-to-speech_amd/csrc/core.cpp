@@ -1,4 +1,5 @@
 // Error plumbing and library-level queries of libs2s_mi355x.
+#include <cstdlib>
 #include "common.h"
 
 #include <stdarg.h>
@@ -44,6 +45,10 @@ static hipEvent_t take_event() {
     return e;
 }
 
+static bool g_graphs = getenv("S2S_NO_GRAPHS") == nullptr;
+bool prof_active() { return g_prof_mask != 0; }
+bool graphs_enabled() { return g_graphs; }
+
 ProfScope::ProfScope(hipStream_t st, int cat, double flops, double bytes) : st_(st), cat_(cat), on_(false) {
     if (!(g_prof_mask & (1u << cat))) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -66,6 +71,11 @@ ProfScope::~ProfScope() {
 extern "C" int32_t s2s_prof_enable(uint32_t category_mask) {
     std::lock_guard<std::mutex> lk(s2s::g_prof_mu);
     s2s::g_prof_mask = category_mask;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_graphs_enable(int32_t on) {
+    s2s::g_graphs = on != 0;
     return S2S_OK;
 }
 

@@ -12,11 +12,11 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         OutT* __restrict__ y, int rows, int cols,
-                                                        float eps) {
+                                                        float eps, long x_rs, float* __restrict__ y_f32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (long)row * cols;
+    const float* xr = x + (long)row * x_rs;
     const int nv4 = cols >> 2;
     float4 v[NORM_MAX_V4];
     float s = 0.f;
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                 p.w = f32_to_bf16_bits(o3);
                 reinterpret_cast<ushort4*>(yr)[c] = p;
             }
+            if (y_f32) reinterpret_cast<float4*>(y_f32 + (long)row * cols)[c] = make_float4(o0, o1, o2, o3);
         }
     }
 }
@@ -80,23 +81,28 @@ int layernorm(hipStream_t st, const float* x, const float* gamma, const float* b
     S2S_REQUIRE(cols % 4 == 0 && cols <= NORM_MAX_V4 * 256, "layernorm: cols=%d unsupported", cols);
     if (rows == 0) return S2S_OK;
     if (y_dtype == S2S_F32)
-        norm_rows_kernel<float, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (float*)y, rows, cols, eps);
+        norm_rows_kernel<float, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (float*)y, rows, cols, eps, cols, nullptr);
     else
-        norm_rows_kernel<__hip_bfloat16, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (__hip_bfloat16*)y, rows, cols, eps);
+        norm_rows_kernel<__hip_bfloat16, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (__hip_bfloat16*)y, rows, cols, eps, cols, nullptr);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int rmsnorm_ex(hipStream_t st, const float* x, long x_rs, const float* gamma, void* y, float* y_f32, int rows, int cols, float eps,
+               int y_dtype) {
+    S2S_REQUIRE(cols % 4 == 0 && cols <= NORM_MAX_V4 * 256 && x_rs % 4 == 0, "rmsnorm: cols=%d unsupported", cols);
+    if (rows == 0) return S2S_OK;
+    if (y_dtype == S2S_F32)
+        norm_rows_kernel<float, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (float*)y, rows, cols, eps, x_rs, y_f32);
+    else
+        norm_rows_kernel<__hip_bfloat16, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (__hip_bfloat16*)y, rows, cols, eps, x_rs, y_f32);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
 int rmsnorm(hipStream_t st, const float* x, const float* gamma, void* y, int rows, int cols, float eps,
             int y_dtype) {
-    S2S_REQUIRE(cols % 4 == 0 && cols <= NORM_MAX_V4 * 256, "rmsnorm: cols=%d unsupported", cols);
-    if (rows == 0) return S2S_OK;
-    if (y_dtype == S2S_F32)
-        norm_rows_kernel<float, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (float*)y, rows, cols, eps);
-    else
-        norm_rows_kernel<__hip_bfloat16, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (__hip_bfloat16*)y, rows, cols, eps);
-    S2S_LAUNCH_CHECK();
-    return S2S_OK;
+    return rmsnorm_ex(st, x, cols, gamma, y, nullptr, rows, cols, eps, y_dtype);
 }
 
 }  // namespace s2s

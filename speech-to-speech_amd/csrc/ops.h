@@ -25,6 +25,9 @@ int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bi
          int act, bool allow_splitk);
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,
               int cols, float eps, int y_dtype);
+// rows at x + r*x_rs; optional second copy of the normalised rows in f32 (y_f32, contiguous)
+int rmsnorm_ex(hipStream_t st, const float* x, long x_rs, const float* gamma, void* y, float* y_f32, int rows, int cols, float eps,
+               int y_dtype);
 int rmsnorm(hipStream_t st, const float* x, const float* gamma, void* y, int rows, int cols, float eps,
             int y_dtype);
 

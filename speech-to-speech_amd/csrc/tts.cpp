@@ -24,6 +24,12 @@ int kv_append_rows(hipStream_t st, const void* src, long src_rs, int k_off, int 
                    const int* pos0, int B, int T_len, int n, int dtype);
 int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dtype);
 int add_int(hipStream_t st, int* p, int v, int n);
+int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
+                const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype);
+int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype);
+int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
                  int dim, int accumulate, const void* addvec, int dtype);
 int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* h, long rows, int Q, int cb, int dim, int dtype);
@@ -68,7 +74,7 @@ struct Tts {
     float *xnext;      // next talker input [B][E]
     float *pin;        // predictor input before in_proj [B*2][E]
     void *pin_t;
-    int *pos_t, *pos_p, *code0, *codes_frame, *finished, *n_frames, *n_active, *step;
+    int *pos_t, *pos_p, *code0, *finished, *n_frames;
     int *codes_out;    // [B][max_frames][G]
     unsigned char* sup_mask;   // [codec_vocab] built-in suppress mask (codec specials except eos)
     int frames_done = 0, cur_B = 0, prompt_max = 0;
@@ -78,6 +84,10 @@ struct Tts {
     int* pos_c = nullptr;              // codec transformer positions (device, [B])
     int codec_frames_done = 0;
     int* host_flag = nullptr;
+    // decode-frame graph: one captured frame body per batch size, replayed once per frame (all per-frame state lives on the device)
+    int *frame_dev = nullptr, *min_dev = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, hipGraphExec_t> frame_graphs;
 };
 
 static const TTensor* tf(const Tts* m, const std::string& n) {
@@ -231,9 +241,8 @@ static int finalize(Tts* m) {
     m->x = (float*)(b0 + o[5]); m->xp = (float*)(b0 + o[6]); m->hn = (float*)(b0 + o[7]); m->hn_t = b0 + o[8];
     m->logits = (float*)(b0 + o[9]); m->xnext = (float*)(b0 + o[10]); m->pin = (float*)(b0 + o[11]); m->pin_t = b0 + o[12];
     int* ints = (int*)(b0 + o[13]);
-    m->pos_t = ints; m->pos_p = ints + B; m->code0 = ints + 2 * B; m->finished = ints + 3 * B; m->n_frames = ints + 4 * B;
-    m->codes_frame = ints + 5 * B;   // unused tail
-    m->n_active = ints + 7 * B; m->step = ints + 7 * B + 4;
+    m->pos_t = ints; m->code0 = ints + 2 * B; m->finished = ints + 3 * B; m->n_frames = ints + 4 * B;
+    m->frame_dev = ints + 7 * B + 1; m->min_dev = ints + 7 * B + 2;   // device-side frame counter / eos gate threshold
     m->codes_out = (int*)(b0 + o[14]);
     m->sup_mask = (unsigned char*)(b0 + o[15]);
     m->talker.kc = b0 + o[16]; m->talker.vc = b0 + o[17];
@@ -244,7 +253,14 @@ static int finalize(Tts* m) {
     std::vector<unsigned char> sup(c.codec_vocab, 0);
     for (int i = c.codebook; i < c.codec_vocab; ++i) sup[i] = (i == c.codec_eos) ? 0 : 1;
     S2S_HIP_CHECK(hipMemcpy(m->sup_mask, sup.data(), sup.size(), hipMemcpyHostToDevice));
-    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, 64, 0));
+    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, sizeof(int) * B, 0));
+    {   // code-predictor positions are host constants per group pass: row g = tokens cached before pass g (0, 2, 3, ...)
+        std::vector<int> tab((size_t)c.n_groups * B);
+        for (int g = 0; g < c.n_groups; ++g)
+            for (long b = 0; b < (long)B; ++b) tab[(size_t)g * B + b] = g == 0 ? 0 : g + 1;
+        S2S_HIP_CHECK(hipMalloc((void**)&m->pos_p, tab.size() * sizeof(int)));
+        S2S_HIP_CHECK(hipMemcpy(m->pos_p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     // streaming history: 2 (ConvNeXt inputs) + 2 (ConvNeXt outputs) + per decoder block (1 + 3) + 1 (final conv input)
     {
         const size_t cmax = (size_t)std::max<long>(H, Dd);
@@ -255,7 +271,7 @@ static int finalize(Tts* m) {
             S2S_HIP_CHECK(hipMemset(p, 0, B * LPAD * cmax * e));
             m->cstate.push_back(p);
         }
-        m->pos_c = ints + 7 * B + 8;
+        m->pos_c = ints + 8 * B + 8;
     }
     m->finalized = true;
     return S2S_OK;
@@ -323,88 +339,78 @@ __global__ void last_row_kernel(const float* __restrict__ x, const int* __restri
     for (int i = threadIdx.x; i < dim; i += blockDim.x) dst[(long)b * dim + i] = r[i];
 }
 
-// after the talker head: code0 = argmax (already in code0), handle eos / frame bookkeeping
-__global__ void tts_frame_begin_kernel(const int* __restrict__ code0, int eos, int* finished, int* n_frames, int* codes_out, int max_frames,
-                                       int G, int frame, int B, int* n_active) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int f = finished[b];
-    if (!f && code0[b] == eos) f = 1;
-    finished[b] = f;
-    codes_out[((long)b * max_frames + frame) * G] = f ? -1 : code0[b];
-    if (!f) {
-        n_frames[b] = frame + 1;
-        atomicAdd(n_active, 1);
-    }
-}
-
-__global__ void tts_store_code_kernel(const int* __restrict__ picked, const int* __restrict__ finished, int* codes_out, int max_frames, int G,
-                                      int frame, int g, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    codes_out[((long)b * max_frames + frame) * G + g] = finished[b] ? -1 : picked[b];
-}
-
-// pin rows: [b][0] = talker normed hidden, [b][1] = talker embedding of code0 (both f32, dim E)
-__global__ void pred_input_kernel(const float* __restrict__ hn, const float* __restrict__ e0, float* __restrict__ pin, int E) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < E; i += blockDim.x) {
-        pin[((long)b * 2) * E + i] = hn[(long)b * E + i];
-        pin[((long)b * 2 + 1) * E + i] = e0[(long)b * E + i];
-    }
-}
-
-static int talker_head(Tts* m, hipStream_t st, int B, const float* hidden_rows, int min_frames_left) {
+// talker head + greedy pick of code 0 + everything that only depends on it (see talker_pick_kernel)
+static int talker_head(Tts* m, hipStream_t st, int B) {
     const auto& c = m->cfg;
     const int dt = c.dtype, E = c.t_hidden;
     int rc;
-    if ((rc = rmsnorm(st, hidden_rows, TPF(m, "talker.norm"), m->hn, B, E, c.eps, S2S_F32))) return rc;
-    if ((rc = cast_f32(st, m->hn, m->hn_t, (long)B * E, dt))) return rc;
+    if ((rc = rmsnorm_ex(st, m->x, E, TPF(m, "talker.norm"), m->hn_t, m->hn, B, E, c.eps, dt))) return rc;
     if ((rc = gemm(st, m->hn_t, E, TP(m, "talker.head.w"), nullptr, nullptr, m->logits, c.codec_vocab, B, c.codec_vocab, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
-    // min_frames: eos suppressed through the begin-mask slot (a mask that only has the eos byte set)
-    const unsigned char* eos_mask = (const unsigned char*)TP(m, "talker.eos_mask");
-    return argmax_suppress(st, m->logits, c.codec_vocab, B, c.codec_vocab, m->sup_mask, min_frames_left > 0 ? eos_mask : nullptr,
-                           min_frames_left > 0 ? m->step : nullptr, 0, m->code0, nullptr);
+    // x's hidden rows are consumed (hn); the pick writes the next talker input over them
+    return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_dev,
+                       m->min_dev, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
+                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, B, dt);
 }
 
-// run the code predictor for the current frame and build the next talker input in m->xnext
-static int predictor_frame(Tts* m, hipStream_t st, int B, int frame) {
+// run the code predictor for the current frame; the residual groups' embeddings accumulate into the next talker input (m->x)
+static int predictor_frame(Tts* m, hipStream_t st, int B) {
     const auto& c = m->cfg;
     const int dt = c.dtype, E = c.t_hidden, P = c.p_hidden, G = c.n_groups, CB = c.codebook;
     int rc;
-    // xnext = talker embedding of code0 + tts_pad_embed; the residual groups' embeddings are accumulated below
-    if ((rc = gather_embed(st, TP(m, "talker.emb"), m->code0, 1, 0, m->xnext, E, B, E, 0, TP(m, "talker.pad_embed"), dt))) return rc;
-    // predictor prefill rows per session: [normed talker hidden, talker embedding of code0]
-    S2S_HIP_CHECK(hipMemcpy2DAsync(m->pin, sizeof(float) * 2 * E, m->hn, sizeof(float) * E, sizeof(float) * E, B, hipMemcpyDeviceToDevice, st));
-    if ((rc = gather_embed(st, TP(m, "talker.emb"), m->code0, 1, 0, m->pin + E, 2L * E, B, E, 0, nullptr, dt))) return rc;
-    S2S_HIP_CHECK(hipMemsetAsync(m->pos_p, 0, sizeof(int) * m->max_batch, st));
     for (int g = 0; g < G - 1; ++g) {
-        const int T_len = g == 0 ? 2 : 1;
+        const int T_len = g == 0 ? 2 : 1;     // prefill rows [normed talker hidden, embedding of code 0], then one row per group
         const int M = B * T_len;
-        if (g > 0) {
-            // input = predictor embedding g-1 of the code just drawn
-            if ((rc = gather_embed(st, TP(m, "pred.emb." + std::to_string(g - 1)), m->codes_frame, 1, 0, m->pin, E, B, E, 0, nullptr, dt))) return rc;
-        }
         if (P != E) {
-            if ((rc = cast_f32(st, m->pin, m->pin_t, (long)M * E, dt))) return rc;
             if ((rc = gemm(st, m->pin_t, E, TP(m, "pred.in_proj.w"), TPF(m, "pred.in_proj.b"), nullptr, m->xp, P, M, P, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
         } else {
-            S2S_HIP_CHECK(hipMemcpyAsync(m->xp, m->pin, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, st));
+            if ((rc = cast_f32(st, m->pin, m->xp, (long)M * E, S2S_F32))) return rc;
         }
-        if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, m->pos_p, g + 2, nullptr))) return rc;
-        if ((rc = add_int(st, m->pos_p, T_len, B))) return rc;
-        const float* last = m->xp;
-        if (T_len == 2) {   // compact the second row of every session
-            S2S_HIP_CHECK(hipMemcpy2DAsync(m->pin, sizeof(float) * P, m->xp + P, sizeof(float) * 2 * P, sizeof(float) * P, B, hipMemcpyDeviceToDevice, st));
-            last = m->pin;
-        }
-        if ((rc = rmsnorm(st, last, TPF(m, "pred.norm"), m->h, B, P, c.eps, dt))) return rc;
+        // cached positions before this pass are a host constant: 0, then g + 1 (row g of the constant table)
+        if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, m->pos_p + (size_t)g * m->max_batch, g + 2, nullptr))) return rc;
+        // last row of every session (second row of the prefill pass) -> norm -> group head
+        if ((rc = rmsnorm_ex(st, m->xp + (size_t)(T_len - 1) * P, (long)T_len * P, TPF(m, "pred.norm"), m->h, nullptr, B, P, c.eps, dt))) return rc;
         if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
-        if ((rc = argmax_suppress(st, m->logits, CB, B, CB, nullptr, nullptr, nullptr, 0, m->codes_frame, nullptr))) return rc;
-        tts_store_code_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->codes_frame, m->finished, m->codes_out, c.max_frames, G, frame, g + 1, B);
-        S2S_LAUNCH_CHECK();
-        if ((rc = gather_embed(st, TP(m, "pred.emb." + std::to_string(g)), m->codes_frame, 1, 0, m->xnext, E, B, E, 1, nullptr, dt))) return rc;
+        if ((rc = pred_pick(st, m->logits, CB, m->frame_dev, m->finished, m->codes_out, c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)),
+                            m->x, m->pin, m->pin_t, E, B, dt))) return rc;
     }
+    return S2S_OK;
+}
+
+// One codec frame for the whole batch: talker head -> code 0 -> code predictor (groups 1..G-1) -> talker step on the
+// summed embeddings.  Every per-frame quantity (frame index, eos gate, positions) is read from device memory, so the
+// launch sequence is identical for every frame and can be replayed from a captured graph.
+static int frame_body(Tts* m, hipStream_t st, int B) {
+    int rc;
+    if ((rc = talker_head(m, st, B))) return rc;
+    if ((rc = predictor_frame(m, st, B))) return rc;
+    // kv capacity is the (constant) cache length; the causal bound pos_t[b] + 1 limits the keys actually read
+    if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos, nullptr))) return rc;
+    return tts_frame_end(st, m->pos_t, m->frame_dev, B);
+}
+
+// captured frame body for batch size B (built on first use; the arena and the weights never move after finalize)
+static int frame_graph(Tts* m, int B, hipGraphExec_t* out) {
+    auto it = m->frame_graphs.find(B);
+    if (it != m->frame_graphs.end()) {
+        *out = it->second;
+        return S2S_OK;
+    }
+    if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    S2S_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = frame_body(m, m->cap_stream, B);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    S2S_HIP_CHECK(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2S_HIP_CHECK(ie);
+    m->frame_graphs[B] = exec;
+    *out = exec;
     return S2S_OK;
 }
 
@@ -432,7 +438,10 @@ extern "C" int32_t s2s_tts_destroy(void* model) {
     Tts* m = (Tts*)model;
     if (m->arena) (void)hipFree(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
+    if (m->pos_p) (void)hipFree(m->pos_p);
     for (void* p : m->cstate) (void)hipFree(p);
+    for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return S2S_OK;
 }
@@ -469,13 +478,15 @@ extern "C" int32_t s2s_tts_prefill(void* model, void* stream, const float* promp
     const int E = m->cfg.t_hidden;
     int rc;
     S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)B * Tp * E, hipMemcpyDeviceToDevice, st));
-    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (7 * (size_t)m->max_batch + 8), st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (8 * (size_t)m->max_batch + 8), st));
     S2S_HIP_CHECK(hipMemsetAsync(m->codes_out, 0xff, sizeof(int) * (size_t)m->max_batch * m->cfg.max_frames * m->cfg.n_groups, st));
     // padded rows beyond a session's prompt are cached too but never attended: kv_len = prompt_len
     if ((rc = stack_forward(m, st, m->talker, m->x, B, Tp, nullptr, Tp, prompt_len_dev))) return rc;
     S2S_HIP_CHECK(hipMemcpyAsync(m->pos_t, prompt_len_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
     last_row_kernel<<<B, 256, 0, st>>>(m->x, prompt_len_dev, Tp, E, m->xnext);
     S2S_LAUNCH_CHECK();
+    // the frame body always reads the hidden of the last processed position from x[0 .. B)
+    S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
     m->cur_B = B;
     m->prompt_max = Tp;
     m->frames_done = 0;
@@ -496,22 +507,15 @@ extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames,
     const int B = m->cur_B, E = c.t_hidden, G = c.n_groups;
     int rc;
     const int f0 = m->frames_done;
-    for (int f = f0; f < f0 + n_frames; ++f) {
-        // hidden of the last processed position is in xnext (prefill) or in x (previous frame's talker step)
-        const float* hidden = f == 0 ? m->xnext : m->x;
-        if (f == 0) {
-            S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
-            hidden = m->x;
-        }
-        if ((rc = talker_head(m, st, B, hidden, min_total_frames - f))) return rc;
-        S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
-        tts_frame_begin_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->code0, c.codec_eos, m->finished, m->n_frames, m->codes_out, c.max_frames, G, f, B, m->n_active);
-        S2S_LAUNCH_CHECK();
-        if ((rc = predictor_frame(m, st, B, f))) return rc;
-        // talker step on the summed embeddings
-        S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
-        if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->prompt_max + f + 1, nullptr))) return rc;
-        if ((rc = add_int(st, m->pos_t, 1, B))) return rc;
+    fill_int_kernel<<<1, 64, 0, st>>>(m->min_dev, min_total_frames, 1);
+    S2S_LAUNCH_CHECK();
+    if (graphs_enabled() && !prof_active()) {
+        hipGraphExec_t exec = nullptr;
+        if ((rc = frame_graph(m, B, &exec))) return rc;
+        for (int f = 0; f < n_frames; ++f) S2S_HIP_CHECK(hipGraphLaunch(exec, st));
+    } else {
+        for (int f = 0; f < n_frames; ++f)
+            if ((rc = frame_body(m, st, B))) return rc;
     }
     m->frames_done = f0 + n_frames;
     if (codes_dev)
@@ -519,9 +523,11 @@ extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames,
                                        sizeof(int) * n_frames * G, B, hipMemcpyDeviceToDevice, st));
     if (n_frames_dev) S2S_HIP_CHECK(hipMemcpyAsync(n_frames_dev, m->n_frames, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
     if (all_done_host) {
-        S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
         S2S_HIP_CHECK(hipStreamSynchronize(st));
-        *all_done_host = *m->host_flag == 0 ? 1 : 0;
+        int all = 1;
+        for (int b = 0; b < B; ++b) all &= m->host_flag[b] != 0;
+        *all_done_host = all;
     }
     return S2S_OK;
 }

@@ -146,6 +146,130 @@ int gather_embed(hipStream_t st, const void* table, const int* ids, int id_strid
     return S2S_OK;
 }
 
+// ---- fused greedy picks of the frame loop ----------------------------------------------------------------
+// block-wide argmax of one logits row with optional suppress masks; ties -> lowest index (torch.argmax)
+__device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
+                                                const unsigned char* __restrict__ mask2) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float x = row[v];
+        if ((mask && mask[v]) || (mask2 && mask2[v])) x = -INFINITY;
+        if (x > best || (x == best && v < bi)) {
+            best = x;
+            bi = v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sv[wave] = best;
+        si[wave] = bi;
+    }
+    __syncthreads();
+    best = sv[0];
+    bi = si[0];
+    for (int w = 1; w < 4; ++w)
+        if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+            best = sv[w];
+            bi = si[w];
+        }
+    return bi;
+}
+
+// Talker pick (one block per session): code 0 = argmax over the codec vocabulary (specials suppressed; eos too while
+// frame < min_frames), eos / frame bookkeeping, then the inputs that depend on it:
+//   xnext[b] = talker_emb[code0] + pad_embed          (next talker input, residual-group embeddings are added later)
+//   pin[b][0] = hn[b], pin[b][1] = talker_emb[code0]  (code predictor prefill rows; f32 and model-dtype copies)
+template <typename T>
+__global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restrict__ logits, int V, const unsigned char* __restrict__ sup_mask,
+                                                          const unsigned char* __restrict__ eos_mask, int eos,
+                                                          const int* __restrict__ frame_dev, const int* __restrict__ min_dev,
+                                                          int* __restrict__ code0, int* __restrict__ finished, int* __restrict__ n_frames,
+                                                          int* __restrict__ codes_out, int max_frames, int G,
+                                                          const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
+                                                          float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E) {
+    const int b = blockIdx.x;
+    const int frame = *frame_dev;
+    const int code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
+    if (threadIdx.x == 0) {
+        int f = finished[b];
+        if (!f && code == eos) f = 1;
+        finished[b] = f;
+        code0[b] = code;
+        codes_out[((long)b * max_frames + frame) * G] = f ? -1 : code;
+        if (!f) n_frames[b] = frame + 1;
+    }
+    const T* row = emb + (long)code * E;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const float e = Elem<T>::ld(row + i);
+        const float h = hn[(long)b * E + i];
+        xnext[(long)b * E + i] = e + Elem<T>::ld(pad + i);
+        pin[((long)b * 2) * E + i] = h;
+        pin[((long)b * 2 + 1) * E + i] = e;
+        Elem<T>::st(pin_t + ((long)b * 2) * E + i, h);
+        Elem<T>::st(pin_t + ((long)b * 2 + 1) * E + i, e);
+    }
+}
+
+// Code-predictor pick for residual group g (one block per session): code = argmax, stored (or -1 once finished), and its
+// embedding row both accumulated into the next talker input and written as the predictor's next input row.
+template <typename T>
+__global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, const int* __restrict__ frame_dev,
+                                                        const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
+                                                        int G, int g, const T* __restrict__ emb, float* __restrict__ xnext,
+                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E) {
+    const int b = blockIdx.x;
+    const int code = block_argmax_256(logits + (long)b * V, V, nullptr, nullptr);
+    if (threadIdx.x == 0) codes_out[((long)b * max_frames + *frame_dev) * G + g] = finished[b] ? -1 : code;
+    const T* row = emb + (long)code * E;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const float e = Elem<T>::ld(row + i);
+        xnext[(long)b * E + i] += e;
+        pin[(long)b * E + i] = e;
+        Elem<T>::st(pin_t + (long)b * E + i, e);
+    }
+}
+
+__global__ void tts_frame_end_kernel(int* pos_t, int* frame_dev, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) pos_t[b] += 1;
+    if (b == 0) *frame_dev += 1;
+}
+
+int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
+                const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype) {
+    S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
+                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype) {
+    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
+                                                       pin, (TT*)pin_t, E)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B) {
+    tts_frame_end_kernel<<<cdiv(B, 64), 64, 0, st>>>(pos_t, frame_dev, B);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
 // h[b][t][:] = mean_q table[q*cb + codes[b][t][q]][:]   (codes frame-major [B][F][Q]; negative codes count as 0)
 template <typename T>
 __global__ void code_embed_mean_kernel(const T* __restrict__ table, const int* __restrict__ codes, float* __restrict__ h, int Q,

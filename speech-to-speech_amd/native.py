@@ -62,6 +62,7 @@ _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_device_count": [],
     "s2s_prof_enable": [C.c_uint32],
+    "s2s_graphs_enable": [_i32],
     "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],
     "s2s_frontend_destroy": [_vp],
@@ -153,6 +154,11 @@ def prof_enable(*categories: int) -> None:
     for c in categories:
         mask |= 1 << c
     check(load().s2s_prof_enable(mask), "s2s_prof_enable")
+
+
+def graphs_enable(on: bool) -> None:
+    """Replay captured hipGraphs in the autoregressive loops (default) or launch every kernel on the stream."""
+    check(load().s2s_graphs_enable(1 if on else 0), "s2s_graphs_enable")
 
 
 def prof_collect(category: int) -> dict:

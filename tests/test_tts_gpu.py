@@ -111,6 +111,30 @@ def test_eos_stops_sessions(ref):
     eng.close()
 
 
+def test_graph_replay_equals_stream_launches(ref):
+    """The captured frame graph (default) and plain stream launches must give identical codes, also when the frames
+    are produced over several generate() calls and the eos gate (min_total_frames) opens mid-way."""
+    from speech_to_speech_amd import native
+
+    dims, sd, prompts, pad, n_frames, codes, wav = ref
+    outs = []
+    for graphs in (True, False):
+        native.graphs_enable(graphs)
+        try:
+            eng = _engine(ref, torch.float32)
+            eng.prefill([TTSPrompt(p.numpy()) for p in prompts])
+            parts = []
+            for n in (3, 4, 3):
+                got, nfr, done = eng.generate(n, min_total_frames=5)
+                parts.append(got.cpu())
+            outs.append((torch.cat(parts, 1), nfr.cpu().tolist()))
+        finally:
+            native.graphs_enable(True)
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    # the first 5 frames cannot be eos-terminated and equal the oracle's (its eos is suppressed for all 10 frames)
+    assert torch.equal(outs[0][0][:, :5].long(), codes[:, :5])
+
+
 def test_resample_and_blocking_match_reference_post_processing(ref):
     from scipy.signal import resample_poly
 
