@@ -54,16 +54,16 @@ def reduce_step_time(dt: float, device) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"])
     ap.add_argument("--sessions", type=int, default=None, help="concurrent sessions per GPU (default: 64 for c3, 1 for c2)")
     ap.add_argument("--decode-tokens", type=int, default=32, help="Whisper greedy tokens per utterance (eos masked)")
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream (default: the TTS leg of step i "
                                                           "overlaps the STT leg of step i+1 on a second stream/thread, as the session pool does)")
-    ap.add_argument("--tts-streams", type=int, default=1, help="split the pool's TTS batch over this many engine replicas (shared weights), "
-                                                               "each on its own HIP stream + host thread")
+    ap.add_argument("--tts-lanes", type=int, default=3, help="TTS turn-batches in flight at once: each lane is an engine instance (shared weights, own KV "
+                    "cache / workspace) on its own thread + HIP stream; the decode kernels are latency-bound, so two lanes overlap on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the HIP-event roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
@@ -233,10 +233,9 @@ def main():
     tts = None
     tts_replicas = []
     if not args.stt_only:
-        K = max(1, args.tts_streams)
-        assert B % K == 0
-        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B // K, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
-        tts_replicas = [tts] + [TTSEngine(tdims, None, torch.bfloat16, B // K, 128, n_frames, 33, None, dev, engine_tensors=tts._weights) for _ in range(K - 1)]
+        K = 1 if args.serial else max(1, args.tts_lanes)
+        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
+        tts_replicas = [tts] + [TTSEngine(tdims, None, torch.bfloat16, B, 128, n_frames, 33, None, dev, engine_tensors=tts._weights) for _ in range(K - 1)]
         g = torch.Generator().manual_seed(7)
         front = ByteTextFrontend((torch.randn(258, tdims.t_hidden, generator=g)).numpy())
     codec = IdTextCodec()
@@ -252,35 +251,11 @@ def main():
         assert n_chunks == n_frames // 8
         return ttfa
 
-    def run_tts(ids, t0):
-        K = len(tts_replicas)
-        if K == 1:
-            return run_tts_one(tts, ids, t0)
-        import threading
-
-        per = len(ids) // K
-        res, errs = [None] * K, []
-
-        def work(k):
-            try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                    res[k] = run_tts_one(tts_replicas[k], ids[k * per:(k + 1) * per], t0)
-            except BaseException as e:  # noqa: BLE001
-                errs.append(e)
-
-        ths = [threading.Thread(target=work, args=(k,)) for k in range(K)]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        if errs:
-            raise errs[0]
-        return max(res)
-
     def step():
         t0 = time.perf_counter()
         ids = run_stt()
         t1 = time.perf_counter()
-        ttfa = run_tts(ids, t0) if tts is not None else None
+        ttfa = run_tts_one(tts, ids, t0) if tts is not None else None
         t2 = time.perf_counter()
         stage["stt"] += t1 - t0
         stage["tts_total"] += t2 - t1
@@ -288,7 +263,8 @@ def main():
         return ttfa
 
     def run_steps(n):
-        """n steps; unless --serial the TTS leg of step i runs on its own thread + HIP stream while step i+1's STT leg runs."""
+        """n steps; unless --serial the TTS leg of a turn-batch runs on one of the TTS lanes (own thread + HIP stream) while the
+        following turn-batches' STT legs (and the other lane's TTS leg) run."""
         if args.serial or tts is None:
             return [step() for _ in range(n)]
         import queue
@@ -296,34 +272,45 @@ def main():
 
         q: "queue.Queue" = queue.Queue(maxsize=1)
         out, err = [], []
-        tts_stream = torch.cuda.Stream(device=dev)
 
-        def tts_worker():
+        def tts_worker(eng):
             try:
                 torch.cuda.set_device(dev)
-                with torch.cuda.stream(tts_stream):
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
                     while True:
                         item = q.get()
                         if item is None:
                             return
                         ids, t0 = item
                         ta = time.perf_counter()
-                        out.append(run_tts(ids, t0))
+                        out.append(run_tts_one(eng, ids, t0))
                         stage["tts_total"] += time.perf_counter() - ta
             except BaseException as e:  # noqa: BLE001
                 err.append(e)
 
-        th = threading.Thread(target=tts_worker)
-        th.start()
+        ths = [threading.Thread(target=tts_worker, args=(e,)) for e in tts_replicas]
+        [t.start() for t in ths]
         for _ in range(n):
             t0 = time.perf_counter()
             ids = run_stt()
             stage["stt"] += time.perf_counter() - t0
-            q.put((ids, t0))
+            while not err:
+                try:
+                    q.put((ids, t0), timeout=1.0)
+                    break
+                except queue.Full:
+                    pass
             if err:
                 break
-        q.put(None)
-        th.join()
+        for _ in ths:
+            while True:
+                try:
+                    q.put(None, timeout=1.0)
+                    break
+                except queue.Full:
+                    if err and not any(t.is_alive() for t in ths):
+                        break
+        [t.join() for t in ths]
         if err:
             raise err[0]
         return out
@@ -395,8 +382,8 @@ def main():
                                f"{n_frames} codec frames ({n_frames / 12.5:.2f} s reply) streamed in 8-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames / 12.5,
                    "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
-                   "tts_streams": len(tts_replicas), "decode_graphs": not args.no_graphs,
-                   "schedule": "serial" if (args.serial or tts is None) else "pipelined: TTS leg of turn-batch i overlaps STT leg of turn-batch i+1 (2 HIP streams)",
+                   "tts_lanes": len(tts_replicas), "decode_graphs": not args.no_graphs,
+                   "schedule": "serial" if (args.serial or tts is None) else f"pipelined: STT legs back to back on one stream; TTS legs on {len(tts_replicas)} lane(s) (thread + HIP stream each) overlapping the following turn-batches",
                    "parallelism": f"session-pool x{world} (no collectives)"},
         "p50_ttfa_ms": ttfa_ms,
         "ttfa_note": "all sessions of the pool end their utterance at t=0; TTFA = STT batch + TTS prefill + first 8-frame chunk + codec + resample + D2H",

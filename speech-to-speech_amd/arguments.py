@@ -47,4 +47,5 @@ class MI355XQwen3TTSHandlerArguments:
     qwen3_tts_blocksize: int = field(default=512)
     qwen3_tts_max_batch: int = field(default=64)
     qwen3_tts_batch_window_ms: float = field(default=4.0)
+    qwen3_tts_lanes: int = field(default=3, metadata={"help": "TTS turn-batches in flight per GPU (engine replicas sharing the weights, one HIP stream each)."})
     qwen3_tts_codec_context_frames: int = field(default=25)

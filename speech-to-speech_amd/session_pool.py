@@ -3,11 +3,14 @@ ONE pool that owns one replica of each engine and batches the STT / TTS work of 
 mapped to it.  This is the new component the reference does not have (it instantiates one model per pipeline unit,
 s2s_pipeline.py:474-477, 554-565); it sits entirely behind the per-unit handler API.
 
-Threading: handler threads only enqueue requests and block on a future / chunk queue; every GPU call happens on the
-pool's single worker thread (one HIP stream), so the engines need no locking.  Scheduling per loop turn:
-  1. all pending final-STT requests (up to max_batch) are batched and run - keeps time-to-first-audio low;
-  2. the active TTS batch advances by one streamed chunk (chunk_size codec frames);
-  3. if no TTS batch is active, pending TTS requests (up to max_batch) are prefilled as a new batch.
+Threading: handler threads only enqueue requests and block on a future / chunk queue.  GPU work runs on the pool's
+own threads, each engine instance is only ever touched by one of them, so the engines need no locking:
+  * the STT worker batches all pending final-STT requests (up to max_batch) and runs them on its stream;
+  * ``tts_lanes`` TTS lanes (thread + HIP stream + engine instance each; lanes > 0 are replicas that share lane 0's
+    weights and own only their KV caches / workspace) each take a batch of pending TTS requests (up to max_batch),
+    prefill it and stream it chunk by chunk (chunk_size codec frames) to the requesting handlers.
+The autoregressive TTS kernels are latency-bound and leave most of the chip idle, so the lanes' turn-batches and the
+STT worker's encoder passes overlap on the device (measured in bench.py).
 Multi-GPU = one pool per device (``SessionPool.for_device``), sessions are pinned to a pool when their handlers are
 built; there is no cross-GPU traffic.
 """
@@ -56,6 +59,8 @@ class SessionPool:
         with cls._pools_lock:
             if device not in cls._pools:
                 cls._pools[device] = cls(device, **kw)
+            elif "tts_lanes" in kw:          # the pool may have been created by the STT handler: grow to the TTS handler's lane count
+                cls._pools[device]._ensure_lanes(int(kw["tts_lanes"]))
             return cls._pools[device]
 
     @classmethod
@@ -65,21 +70,35 @@ class SessionPool:
         for p in pools:
             p.shutdown()
 
-    def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25):
+    def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
+                 tts_lanes: int = 3):
         self.device = device
+        self.tts_lanes = max(1, int(tts_lanes))
         self.max_batch = int(max_batch)
         self.batch_window_s = batch_window_ms * 1e-3
         self.tts_chunk_size, self.tts_ctx_frames = int(tts_chunk_size), int(tts_ctx_frames)
         self._engines: dict[str, Any] = {}
+        self._lane_replicas: list[Any] = []
         self._factories: dict[str, Callable[[], Any]] = {}
         self._stt_q: "queue.Queue[Any]" = queue.Queue()
         self._tts_q: "queue.Queue[Any]" = queue.Queue()
         self._wake = threading.Event()
         self._engine_lock = threading.Lock()
-        self.stats = {"stt_batches": 0, "stt_requests": 0, "tts_batches": 0, "tts_requests": 0, "max_stt_batch": 0}
+        self.stats = {"stt_batches": 0, "stt_requests": 0, "tts_batches": 0, "tts_requests": 0, "max_stt_batch": 0, "tts_lanes_used": 0}
+        self._stats_lock = threading.Lock()
         self._thread = threading.Thread(target=self._run, name=f"s2s-pool-{device}", daemon=True)
+        self._lanes: list[threading.Thread] = []
         self._stopping = False
         self._thread.start()
+        self._ensure_lanes(self.tts_lanes)
+
+    def _ensure_lanes(self, n: int) -> None:
+        while len(self._lanes) < max(1, n):
+            i = len(self._lanes)
+            t = threading.Thread(target=self._run_tts_lane, args=(i,), name=f"s2s-pool-{self.device}-tts{i}", daemon=True)
+            self._lanes.append(t)
+            t.start()
+        self.tts_lanes = len(self._lanes)
 
     # ---- engines ---------------------------------------------------------------------------------
     def ensure_engine(self, name: str, factory: Callable[[], Any]) -> None:
@@ -130,9 +149,13 @@ class SessionPool:
     def shutdown(self) -> None:
         self._stopping = True
         self._stt_q.put(_STOP)
+        for _ in self._lanes:
+            self._tts_q.put(_STOP)
         self._wake.set()
         self._thread.join(timeout=10)
-        for e in self._engines.values():
+        for t in self._lanes:
+            t.join(timeout=10)
+        for e in list(self._engines.values()) + self._lane_replicas:
             try:
                 e.close()
             except Exception:  # noqa: BLE001
@@ -149,73 +172,122 @@ class SessionPool:
         return items
 
     def _run(self) -> None:
-        tts_active: tuple[Iterator, list[_TTSRequest]] | None = None
+        """STT worker (also builds the engines, so that model loading stays on one thread)."""
         while True:
-            if tts_active is None and self._stt_q.empty() and self._tts_q.empty():
-                self._wake.wait(timeout=0.05)
-                self._wake.clear()
-                if self._stopping and self._stt_q.empty():
+            try:
+                first = self._stt_q.get(timeout=0.05)
+            except queue.Empty:
+                if self._stopping:
                     return
                 continue
-            # 1. STT (and engine builds)
-            if not self._stt_q.empty():
-                if tts_active is None and self.batch_window_s > 0:
-                    time.sleep(self.batch_window_s)      # let concurrent sessions' finals join the batch
-                items = self._drain(self._stt_q, self.max_batch)
-                reqs: list[_STTRequest] = []
-                for it in items:
-                    if it is _STOP:
-                        self._stopping = True
-                    elif isinstance(it, tuple) and it[0] == "build":
-                        _, name, factory, fut = it
-                        try:
-                            self._engines[name] = factory()
-                            fut.set_result(True)
-                        except BaseException as e:  # noqa: BLE001
-                            fut.set_exception(e)
-                    else:
-                        reqs.append(it)
-                for model in sorted({r.model for r in reqs}):
-                    self._run_stt([r for r in reqs if r.model == model], model)
-            # 2./3. TTS
-            if tts_active is not None:
-                gen, batch = tts_active
+            if self.batch_window_s > 0 and not (isinstance(first, tuple) or first is _STOP):
+                time.sleep(self.batch_window_s)      # let concurrent sessions' finals join the batch
+            items = [first] + self._drain(self._stt_q, self.max_batch - 1)
+            reqs: list[_STTRequest] = []
+            for it in items:
+                if it is _STOP:
+                    self._stopping = True
+                elif isinstance(it, tuple) and it[0] == "build":
+                    _, name, factory, fut = it
+                    try:
+                        self._engines[name] = factory()
+                        fut.set_result(True)
+                    except BaseException as e:  # noqa: BLE001
+                        fut.set_exception(e)
+                else:
+                    reqs.append(it)
+            for model in sorted({r.model for r in reqs}):
+                self._run_stt([r for r in reqs if r.model == model], model)
+            if self._stopping and self._stt_q.empty():
+                return
+
+    def _lane_engine(self, lane: int) -> Any:
+        """Lane 0 streams on the pool's TTS engine; further lanes on replicas that share its weights (built on first use,
+        on the lane's own thread).  An engine without ``replica()`` (a test double) is served by lane 0 only."""
+        eng = self._engines["tts"]
+        if lane == 0:
+            return eng
+        if not hasattr(eng, "replica"):
+            return None
+        rep = eng.replica()
+        self._lane_replicas.append(rep)
+        return rep
+
+    def _lane_stream_ctx(self):
+        """Every lane issues its GPU work on its own HIP stream (no-op for devices torch does not know, e.g. test doubles)."""
+        import contextlib
+
+        try:
+            import torch
+
+            dev = torch.device(self.device)
+            if dev.type == "cuda" and torch.cuda.is_available():
+                torch.cuda.set_device(dev)
+                torch.cuda.synchronize(dev)      # weights were uploaded on the STT worker's stream
+                return torch.cuda.stream(torch.cuda.Stream(device=dev))
+        except Exception:  # noqa: BLE001
+            pass
+        return contextlib.nullcontext()
+
+    def _run_tts_lane(self, lane: int) -> None:
+        eng, ctx = None, None
+        while True:
+            try:
+                first = self._tts_q.get(timeout=0.05)
+            except queue.Empty:
+                if self._stopping:
+                    return
+                continue
+            if first is _STOP:
+                return
+            if eng is None:
                 try:
-                    chunks = next(gen)
+                    eng = self._lane_engine(lane)
+                except BaseException as e:  # noqa: BLE001
+                    logger.error("TTS lane %d could not build its engine replica: %s", lane, e, exc_info=True)
+                    eng = None
+                if eng is None:                      # hand the request back to the lanes that have an engine and retire
+                    self._tts_q.put(first)
+                    return
+                ctx = self._lane_stream_ctx()
+                ctx.__enter__()
+                with self._stats_lock:
+                    self.stats["tts_lanes_used"] += 1
+            if self.batch_window_s > 0:
+                time.sleep(self.batch_window_s)
+            drained = self._drain(self._tts_q, self.max_batch - 1)
+            for it in drained:
+                if it is _STOP:
+                    self._tts_q.put(_STOP)           # leave it for shutdown handling after this batch
+            batch = [r for r in [first] + [d for d in drained if d is not _STOP] if not r.cancelled.is_set()]
+            if not batch:
+                continue
+            with self._stats_lock:
+                self.stats["tts_batches"] += 1
+                self.stats["tts_requests"] += len(batch)
+            try:
+                gen = eng.stream([r.prompt for r in batch], [r.max_new_tokens for r in batch], chunk_size=self.tts_chunk_size,
+                                 ctx_frames=self.tts_ctx_frames)
+                for chunks in gen:
                     for r, ch in zip(batch, chunks):
                         if ch is not None and not r.cancelled.is_set():
                             r.chunks.put(ch)
                     if all(r.cancelled.is_set() for r in batch):
-                        raise StopIteration
-                except StopIteration:
-                    for r in batch:
-                        r.chunks.put(None)
-                    tts_active = None
-                except BaseException as e:  # noqa: BLE001
-                    logger.error("TTS batch failed: %s", e, exc_info=True)
-                    for r in batch:
-                        r.chunks.put(e)
-                    tts_active = None
-            elif not self._tts_q.empty():
-                if self.batch_window_s > 0:
-                    time.sleep(self.batch_window_s)
-                batch = [r for r in self._drain(self._tts_q, self.max_batch) if not r.cancelled.is_set()]
-                if batch:
-                    self.stats["tts_batches"] += 1
-                    self.stats["tts_requests"] += len(batch)
-                    eng = self._engines["tts"]
-                    gen = eng.stream([r.prompt for r in batch], [r.max_new_tokens for r in batch], chunk_size=self.tts_chunk_size,
-                                     ctx_frames=self.tts_ctx_frames)
-                    tts_active = (gen, batch)
-            if self._stopping and tts_active is None and self._stt_q.empty() and self._tts_q.empty():
-                return
+                        break
+                for r in batch:
+                    r.chunks.put(None)
+            except BaseException as e:  # noqa: BLE001
+                logger.error("TTS batch failed: %s", e, exc_info=True)
+                for r in batch:
+                    r.chunks.put(e)
 
     def _run_stt(self, reqs: list[_STTRequest], model: str) -> None:
         if not reqs:
             return
-        self.stats["stt_batches"] += 1
-        self.stats["stt_requests"] += len(reqs)
-        self.stats["max_stt_batch"] = max(self.stats["max_stt_batch"], len(reqs))
+        with self._stats_lock:
+            self.stats["stt_batches"] += 1
+            self.stats["stt_requests"] += len(reqs)
+            self.stats["max_stt_batch"] = max(self.stats["max_stt_batch"], len(reqs))
         try:
             results = self._engines[model].transcribe_batch([r.audio for r in reqs], [r.options for r in reqs])
             for r, res in zip(reqs, results):

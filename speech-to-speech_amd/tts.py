@@ -293,6 +293,13 @@ class TTSEngine:
         t = random_tts_engine_tensors(dims, dtype, dev, max_prompt + max_frames, max_codec_frames, seed)
         return cls(dims, None, dtype, max_batch, max_prompt, max_frames, max_codec_frames, None, dev, engine_tensors=t)
 
+    def replica(self) -> "TTSEngine":
+        """A second engine instance on the same GPU that shares this one's weight tensors (no copy) and owns only its KV
+        caches / workspace / decode graphs - one per TTS lane of the session pool."""
+        rep = TTSEngine(self.dims, None, self.dtype, self.max_batch, self.max_prompt, self.max_frames, self.max_codec_frames, None, self.device,
+                        engine_tensors=self._weights)
+        return rep
+
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.s2s_tts_workspace_bytes(self._h))

@@ -196,3 +196,40 @@ def test_registry_entries_and_lazy_factories():
         del sys.modules[m]
     importlib.reload(registry)
     assert not any(k.startswith("speech_to_speech_amd.handlers.") for k in sys.modules)
+
+
+def test_tts_lanes_overlap_turn_batches():
+    """Two TTS lanes (thread + stream + engine replica each) serve two turn-batches at the same time; a lane whose engine
+    cannot be replicated retires and lane 0 serves everything."""
+
+    class SlowTTS(FakeTTSEngine):
+        instances = 0
+
+        def replica(self):
+            SlowTTS.instances += 1
+            return SlowTTS()
+
+        def stream(self, prompts, max_new_tokens, chunk_size=8, ctx_frames=25, min_frames=0):
+            for k in range(4):
+                time.sleep(0.05)
+                yield [np.full(512, k, np.int16) for _ in prompts]
+
+    p = SessionPool("fake:1", max_batch=1, batch_window_ms=1.0, tts_lanes=2)
+    p._engines.update(tts=SlowTTS())
+    try:
+        t0 = time.perf_counter()
+        its = [p.synthesize(object(), 8)[0] for _ in range(2)]
+        got = [None, None]
+
+        def drain(i):
+            got[i] = [c.copy() for c in its[i]]
+
+        ts = [threading.Thread(target=drain, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        assert all(len(g) == 4 for g in got)
+        assert p.stats["tts_lanes_used"] == 2 and SlowTTS.instances == 1 and p.stats["tts_batches"] == 2
+        assert dt < 0.35, f"two 0.2 s batches on two lanes took {dt:.2f} s (serial would be 0.4 s)"
+    finally:
+        p.shutdown()
