@@ -22,6 +22,7 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace s2s {
 
@@ -226,6 +227,223 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
         }
 }
 
+// ---- large-M tile GEMM: 256x128 tile, 8 waves, 3-stage LDS ring ----------------------------
+// The encoder-sized projections (M = sessions x frames) run here.  Same fragment layout and swizzle as gemm_tile_kernel,
+// but (a) the per-thread source pointers are advanced incrementally (no address arithmetic or branches in the K loop;
+// requires K % BK == 0 and no tap addressing), (b) the ring holds three K-slabs, so two slabs of direct global->LDS
+// loads are in flight while one is multiplied - the wait before a slab is a partial vmcnt wait (the 6 loads of the
+// younger slab may still be outstanding), and (c) the workgroup tile is 256 x 128 (4 x 2 waves of 64 x 64), which
+// halves the W re-reads per flop.  LDS: 3 x (32 KiB A + 16 KiB W) = 144 KiB -> one 8-wave workgroup per CU.
+constexpr int T3_M = 256, T3_N = 128, T3_A_BYTES = T3_M * ROWB, T3_W_BYTES = T3_N * ROWB, T3_STAGE = T3_A_BYTES + T3_W_BYTES, T3_NST = 3;
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left unconstrained); gfx9 encoding: vmcnt = {simm16[15:14], simm16[3:0]}
+#define S2S_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
+
+template <typename T, typename CT>
+__global__ __launch_bounds__(512) void gemm_tile3_kernel(
+    const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
+    constexpr int EPC = MfmaTraits<T>::EPC;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    {
+        const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
+        A += z1 * rm.a_z1 + z2 * rm.a_z2;
+        W += z1 * rm.w_z1 + z2 * rm.w_z2;
+        C += z1 * rm.c_z1 + z2 * rm.c_z2;
+        if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
+    }
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg % tiles_m, tn = wg / tiles_m;
+    const int m0 = tm * T3_M, n0 = tn * T3_N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: A tile = 2048 16-byte chunks (4 per thread), W tile = 1024 (2 per thread); chunk c -> (row c >> 3, slot c & 7),
+    // LDS slot p of a row holds logical chunk p ^ (row & 7).  Out-of-range rows stream the zero page with step 0.
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const T* pa[4];
+    const T* pw[2];
+    int sa[4], sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 512, row = c >> 3, m = m0 + row;
+        const int lch = (c & 7) ^ (row & 7);
+        pa[i] = zero;
+        sa[i] = 0;
+        if (m < M) {
+            pa[i] = (rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda) + lch * EPC;
+            sa[i] = BK;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 512, row = c >> 3, n = n0 + row;
+        const int lch = (c & 7) ^ (row & 7);
+        pw[i] = zero;
+        sw[i] = 0;
+        if (n < N) {
+            pw[i] = W + (long)n * rm.ldw + lch * EPC;
+            sw[i] = BK;
+        }
+    }
+    const int wave_base = __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto issue = [&](int stage) {
+        unsigned char* base = lds3 + stage * T3_STAGE + wave_base;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+                                             (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+            pa[i] += sa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
+                                             (__attribute__((address_space(3))) void*)(base + T3_A_BYTES + i * 8192), 16, 0, 0);
+            pw[i] += sw[i];
+        }
+    };
+
+    const int nk = K / BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) S2S_WAIT_VMCNT(6);   // slab t has landed; the 6 loads of slab t + 1 may still be in flight
+        else S2S_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading slab t - 1's stage
+        if (t + 2 < nk) issue(stage >= 1 ? stage - 1 : T3_NST - 1);   // (t + 2) % 3 == (t - 1) % 3
+        const unsigned char* sA = lds3 + stage * T3_STAGE;
+        const unsigned char* sW = sA + T3_A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm + i * 16 + l15;
+                    fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * ROWB + (((kk * 4 + lg) ^ (ra & 7)) << 4));
+                    const int rw = wn + i * 16 + l15;
+                    fw[i] = *reinterpret_cast<const bf16x8_t*>(sW + rw * ROWB + (((kk * 4 + lg) ^ (rw & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm + i * 16 + l15;
+                    fa[i] = *reinterpret_cast<const float*>(sA + ra * ROWB + ((ks ^ (ra & 7)) << 4) + lg * 4);
+                    const int rw = wn + i * 16 + l15;
+                    fw[i] = *reinterpret_cast<const float*>(sW + rw * ROWB + ((ks ^ (rw & 7)) << 4) + lg * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fw[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        stage = stage + 1 == T3_NST ? 0 : stage + 1;
+    }
+
+    // Epilogue through LDS: the C fragments (column-strided per lane) are staged as a 64 x 64 f32 tile per wave
+    // (row pitch 68 floats: conflict-free fragment writes) and read back row-wise, so every lane stores 16 contiguous
+    // bytes of one output row (8 rows x 128 B per wave instruction for bf16) instead of 2-byte scattered stores.
+    __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
+    constexpr int PITCH = 68;
+    float* stg = reinterpret_cast<float*>(lds3) + wave * (64 * PITCH);
+    {
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = n0 + wn + j * 16 + l15;
+            bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act(acc[i][j][r] + bv[j], act) * rm.alpha;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int VEC = 16 / (int)sizeof(CT);   // output elements per 16-byte store: 8 (bf16) / 4 (f32)
+    constexpr int LPR = 64 / VEC;               // lanes per output row
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    const bool grouped = rm.G < M;
+    const int cc = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc;
+#pragma unroll 4
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + lane / LPR;
+        const int m = m0 + wm + row;
+        if (m >= M || n >= N) continue;
+        long coff, roff;
+        if (grouped) {
+            const int mb = m / rm.G, mr = m - mb * rm.G;
+            coff = (long)mb * rm.c_bs + (long)mr * ldc;
+            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+        } else {
+            coff = (long)m * ldc;
+            roff = (long)m * rm.ldr;
+        }
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(stg + row * PITCH + cc + q * 4);
+            v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
+        }
+        CT* cp = C + coff + n;
+        const bool full = n + VEC <= N;
+        if (residual) {
+            const float* rp = residual + roff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
+                    v[q * 4 + 0] += r4.x; v[q * 4 + 1] += r4.y; v[q * 4 + 2] += r4.z; v[q * 4 + 3] += r4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) v[e] += rp[e];
+            }
+        }
+        if (full && ((uintptr_t)cp & 15) == 0) {
+            if constexpr (sizeof(CT) == 4) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                u32x4_t pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pk[q] = (unsigned)f32_to_bf16_bits(v[2 * q]) | ((unsigned)f32_to_bf16_bits(v[2 * q + 1]) << 16);
+                *reinterpret_cast<u32x4_t*>(cp) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (n + e < N) Elem<CT>::st(cp + e, v[e]);
+        }
+    }
+}
+
 // ---- skinny (decode) GEMM --------------------------------------------------
 // M <= 64 rows (one per live session): pure weight streaming.  One workgroup of 8 waves owns a 16-column slab of
 // W over the WHOLE of K; the 8 waves split K, so every weight element is read exactly once, straight from HBM into
@@ -366,6 +584,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     }
 }
 
+static bool tile3_disabled() {
+    static const bool off = getenv("S2S_NO_TILE3") != nullptr;   // A/B switch for tools/bench_ops.py
+    return off;
+}
+
 template <typename T, typename CT>
 static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     RowMap rm;
@@ -429,6 +652,20 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         }
 #undef S2S_SK_MT
 #undef S2S_SK
+    } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
+               g.tap_len == 0 && K % BK3 == 0 && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {
+        const int tiles_m = cdiv(M, T3_M), tiles_n = cdiv(N, T3_N);
+        constexpr int lds_bytes = T3_NST * T3_STAGE;
+        static bool attr_set = false;      // per (T, CT) instantiation; benign race (idempotent)
+        if (!attr_set) {
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            attr_set = true;
+        }
+        ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
+                       ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+        gemm_tile3_kernel<T, CT><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
+            (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
+            tiles_m, rm);
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,

@@ -36,7 +36,9 @@ def _ref(A, W, bias, resid, act):
 
 
 SHAPES = [(128, 128, 64), (300, 200, 136), (1500, 384, 384), (64, 1280, 1280), (1, 51864, 384), (17, 100, 72),
-          (65, 130, 264)]
+          (65, 130, 264),
+          # large-M shapes that take the 256x128 / 3-stage ring kernel (ragged M and N edges; 3, 5 and 6 K-slabs)
+          (9000, 650, 192), (8192, 1024, 320)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
