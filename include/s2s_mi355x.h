@@ -138,6 +138,14 @@ int32_t s2s_op_conv1d_tm(void* stream, const void* x, const void* w, const float
                          int32_t stride, int32_t pad, int32_t y_rows, int32_t y_row0,
                          int32_t ab_dtype, int32_t c_dtype, int32_t act);
 
+/* Causal dilated 1-D convolution over a history-padded time-major buffer (the codec decoder's residual-unit convolution,
+ * sibling Qwen3OmniMoeCausalConvNet, modeling_qwen3_omni_moe.py:3180-3213): x [B][lpad + T][Cin] where the lpad >=
+ * (ksize-1)*dilation rows in front of every item are its history (zeros at utterance start); w [Cout][ksize][Cin];
+ * y [B][T][Cout], y[b][t] = bias + sum_j w[:, j, :] . x[b][lpad + t - (ksize-1-j)*dilation]. */
+int32_t s2s_op_conv1d_causal_tm(void* stream, const void* x, const void* w, const float* bias, void* y,
+                                int32_t B, int32_t T, int32_t Cin, int32_t Cout, int32_t ksize, int32_t dilation,
+                                int32_t lpad, int32_t ab_dtype, int32_t c_dtype, int32_t act);
+
 /* Scaled-dot-product attention over token-major buffers (f32 softmax).
  *   q: [B][Tq][q_rs] (head h at columns h*D), k / v: [B][Tk][kv_rs] (Hkv heads, grouped-query
  *   when H > Hkv), o: [B][Tq][H*D].  kv_len_dev: optional int32[B] valid keys.  bias: optional

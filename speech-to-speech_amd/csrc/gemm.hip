@@ -239,7 +239,7 @@ constexpr int T3_M = 256, T3_N = 128, T3_A_BYTES = T3_M * ROWB, T3_W_BYTES = T3_
 // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left unconstrained); gfx9 encoding: vmcnt = {simm16[15:14], simm16[3:0]}
 #define S2S_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
 
-template <typename T, typename CT>
+template <typename T, typename CT, bool GEN>
 __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
@@ -268,18 +268,35 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
 
     // staging: A tile = 2048 16-byte chunks (4 per thread), W tile = 1024 (2 per thread); chunk c -> (row c >> 3, slot c & 7),
     // LDS slot p of a row holds logical chunk p ^ (row & 7).  Out-of-range rows stream the zero page with step 0.
+    // GEN = false: K % BK == 0 and plain rows - the K loop only bumps pointers.  GEN = true additionally tracks every
+    // chunk's absolute k (zero page past K) and its offset inside the current convolution tap (tap_len >= BK: at most one
+    // tap boundary per slab; crossing it adds tap_stride - tap_len), still without divisions in the loop.
     const T* zero = reinterpret_cast<const T*>(g_zero_page);
     const T* pa[4];
     const T* pw[2];
     int sa[4], sw[2];
+    int ka[GEN ? 4 : 1], kin[GEN ? 4 : 1], kw[GEN ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + i * 512, row = c >> 3, m = m0 + row;
         const int lch = (c & 7) ^ (row & 7);
         pa[i] = zero;
         sa[i] = 0;
+        if constexpr (GEN) {
+            ka[i] = lch * EPC;
+            kin[i] = 0;
+        }
         if (m < M) {
-            pa[i] = (rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda) + lch * EPC;
+            const T* rowp = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+            long ao = lch * EPC;
+            if constexpr (GEN) {
+                if (rm.tap_len > 0) {
+                    const int tap = (lch * EPC) / rm.tap_len;
+                    kin[i] = lch * EPC - tap * rm.tap_len;
+                    ao = (long)tap * rm.tap_stride + kin[i];
+                }
+            }
+            pa[i] = rowp + ao;
             sa[i] = BK;
         }
     }
@@ -289,6 +306,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
         const int lch = (c & 7) ^ (row & 7);
         pw[i] = zero;
         sw[i] = 0;
+        if constexpr (GEN) kw[i] = lch * EPC;
         if (n < N) {
             pw[i] = W + (long)n * rm.ldw + lch * EPC;
             sw[i] = BK;
@@ -299,19 +317,38 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
         unsigned char* base = lds3 + stage * T3_STAGE + wave_base;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+            const T* src = pa[i];
+            if constexpr (GEN) {
+                if (ka[i] >= K) src = zero;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
             pa[i] += sa[i];
+            if constexpr (GEN) {
+                ka[i] += BK;
+                if (rm.tap_len > 0 && sa[i] != 0) {
+                    kin[i] += BK;
+                    if (kin[i] >= rm.tap_len) {
+                        kin[i] -= rm.tap_len;
+                        pa[i] += rm.tap_stride - rm.tap_len;
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
+            const T* src = pw[i];
+            if constexpr (GEN) {
+                if (kw[i] >= K) src = zero;
+                kw[i] += BK;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + T3_A_BYTES + i * 8192), 16, 0, 0);
             pw[i] += sw[i];
         }
     };
 
-    const int nk = K / BK;
+    const int nk = (K + BK - 1) / BK;
     issue(0);
     if (nk > 1) issue(1);
     int stage = 0;
@@ -653,19 +690,24 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SK_MT
 #undef S2S_SK
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
-               g.tap_len == 0 && K % BK3 == 0 && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {
+               (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {
         const int tiles_m = cdiv(M, T3_M), tiles_n = cdiv(N, T3_N);
         constexpr int lds_bytes = T3_NST * T3_STAGE;
+        const bool gen = g.tap_len > 0 || K % BK3 != 0;
         static bool attr_set = false;      // per (T, CT) instantiation; benign race (idempotent)
         if (!attr_set) {
-            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
             attr_set = true;
         }
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-        gemm_tile3_kernel<T, CT><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
-            (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
-            tiles_m, rm);
+        if (gen)
+            gemm_tile3_kernel<T, CT, true><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
+                (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+        else
+            gemm_tile3_kernel<T, CT, false><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
+                (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
@@ -732,5 +774,24 @@ extern "C" int32_t s2s_op_conv1d_tm(void* stream, const void* x, const void* w, 
     g.C = (char*)y + (size_t)y_row0 * Cout * esz; g.ldc = Cout; g.c_bs = (long)y_rows * Cout;
     g.M = B * T_out; g.N = Cout; g.K = ksize * Cin; g.G = T_out;
     g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
+    return s2s::gemm_ex((hipStream_t)stream, g);
+}
+
+/* Causal dilated 1-D convolution over a history-padded time-major buffer, as one GEMM with tap addressing (the codec
+ * decoder's residual-unit convolution):  x: [B][lpad + T][Cin], the lpad >= (ksize-1)*dilation rows before every item hold
+ * its history (zeros at utterance start);  w: [Cout][ksize][Cin];  y: [B][T][Cout],
+ * y[b][t] = bias + sum_j w[:, j, :] . x[b][lpad + t - (ksize-1-j)*dilation]. */
+extern "C" int32_t s2s_op_conv1d_causal_tm(void* stream, const void* x, const void* w, const float* bias, void* y,
+                                           int32_t B, int32_t T, int32_t Cin, int32_t Cout, int32_t ksize,
+                                           int32_t dilation, int32_t lpad, int32_t ab_dtype, int32_t c_dtype, int32_t act) {
+    S2S_REQUIRE(B > 0 && T > 0 && ksize > 0 && dilation > 0 && lpad >= (ksize - 1) * dilation, "conv1d_causal: bad arguments");
+    s2s::GemmArgs g{};
+    const size_t e = ab_dtype == S2S_F32 ? 4 : 2;
+    g.A = (const char*)x + (size_t)(lpad - (ksize - 1) * dilation) * Cin * e; g.lda = Cin; g.a_bs = (long)(lpad + T) * Cin;
+    g.W = w; g.bias = bias;
+    g.C = y; g.ldc = Cout; g.c_bs = (long)T * Cout;
+    g.M = B * T; g.N = Cout; g.K = ksize * Cin; g.G = T;
+    g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
+    if (ksize > 1) { g.tap_len = Cin; g.tap_stride = (long)dilation * Cin; }
     return s2s::gemm_ex((hipStream_t)stream, g);
 }

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_logmel_whisper_tm": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
     "s2s_op_conv1d_tm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "s2s_op_conv1d_causal_tm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "s2s_op_attention": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
                          _i32, _i32, _i32, _vp],
     "s2s_whisper_create": [_vp, _i32, C.POINTER(_vp)],

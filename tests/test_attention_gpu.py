@@ -112,3 +112,31 @@ def test_conv1d_as_gemm(dt, B, T, Cin, Cout, k, stride):
     print(f"conv1d {dt} T{T} {Cin}->{Cout} k{k} s{stride}: {err:.3e}")
     assert err < (2e-5 if dt == torch.float32 else 3e-2)
     assert torch.all(y[:, 0] == 0) and torch.all(y[:, -1] == 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,Cin,Cout,k,dil", [(2, 200, 32, 48, 7, 3),          # small: 128x128 tile kernel, per-slab tap arithmetic
+                                                (4, 16000, 96, 96, 7, 9),        # codec-sized: 256x128 ring kernel, taps straddle K-slabs, K % 64 != 0
+                                                (2, 30000, 192, 128, 7, 1),      # tap_len multiple of the slab
+                                                (3, 20000, 64, 200, 1, 1)])      # pointwise (no taps), ragged N
+def test_causal_dilated_conv_as_gemm(dt, B, T, Cin, Cout, k, dil):
+    """The codec decoder's causal dilated convolution as ONE GEMM with tap addressing over the history-padded buffer."""
+    lib = native.load()
+    lpad = (k - 1) * dil + 2
+    g = torch.Generator().manual_seed(T + Cin + dil)
+    x = torch.randn(B, Cin, T, generator=g).to(dt)
+    hist = torch.randn(B, Cin, lpad, generator=g).to(dt)          # non-zero history rows: they must be read, not assumed zero
+    w = (torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)).to(dt)
+    b = torch.randn(Cout, generator=g)
+    xp = torch.cat([hist, x], dim=2).permute(0, 2, 1).contiguous()                # [B][lpad + T][Cin]
+    y = torch.zeros(B, T, Cout, dtype=dt, device=DEV)
+    xd, wd, bd = xp.to(DEV), w.permute(0, 2, 1).contiguous().to(DEV), b.to(DEV)
+    native.check(lib.s2s_op_conv1d_causal_tm(native.stream_handle(), native.ptr(xd), native.ptr(wd), native.ptr(bd), native.ptr(y),
+                                             B, T, Cin, Cout, k, dil, lpad, native.dtype_code(dt), native.dtype_code(dt), native.ACT_NONE))
+    torch.cuda.synchronize()
+    full = torch.cat([hist, x], dim=2).double()
+    ref = torch.nn.functional.conv1d(full, w.double(), b.double(), dilation=dil)[:, :, lpad - (k - 1) * dil:].permute(0, 2, 1)
+    assert ref.shape == (B, T, Cout)
+    err = (y.double().cpu() - ref).abs().max().item()
+    print(f"causal conv {dt} B{B} T{T} {Cin}->{Cout} k{k} d{dil}: {err:.3e}")
+    assert err < (3e-5 if dt == torch.float32 else 4e-2)
