@@ -64,6 +64,8 @@ def parse():
                                                           "overlaps the STT leg of step i+1 on a second stream/thread, as the session pool does)")
     ap.add_argument("--tts-lanes", type=int, default=3, help="TTS turn-batches in flight at once: each lane is an engine instance (shared weights, own KV "
                     "cache / workspace) on its own thread + HIP stream; the decode kernels are latency-bound, so two lanes overlap on the device")
+    ap.add_argument("--stt-lanes", type=int, default=1, help="STT turn-batches in flight at once (Whisper engine instances sharing the weights, "
+                    "own encoder / KV workspace, thread and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the HIP-event roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
@@ -209,12 +211,15 @@ def main():
         eos = wdims.vocab - 1
         prompt = [[1, 2, 3, 4]] * B
 
-        def run_stt():
+        n_stt = 1 if (args.serial or args.stt_only) else max(1, args.stt_lanes)
+        stt_replicas = [stt] + [WhisperEngine(wdims, None, torch.bfloat16, B, dev, engine_tensors=stt._weights) for _ in range(n_stt - 1)]
+
+        def run_stt(eng=stt):
             feats = torch.empty((B, 3002, wdims.n_mels), dtype=torch.bfloat16, device=dev)
-            native.check(lib.s2s_logmel_whisper_tm(stt.frontend._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0), native.ptr(ns), B,
+            native.check(lib.s2s_logmel_whisper_tm(eng.frontend._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0), native.ptr(ns), B,
                                                    native.ptr(feats), native.S2S_BF16))
-            stt.encode(feats)
-            ids, _ = stt.decode(prompt, eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
+            eng.encode(feats)
+            ids, _ = eng.decode(prompt, eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
             return ids
     else:
         from speech_to_speech_amd.parakeet import ParakeetEngine, convert_parakeet_state_dict
@@ -224,7 +229,9 @@ def main():
         stt = ParakeetEngine(pd, parakeet_state_dict(pd, seed=12, gain=1.0), dtype=torch.bfloat16, max_batch=B, max_seconds=utt_s, device=dev)
         T = int(utt_s * 100) + 1
 
-        def run_stt():
+        stt_replicas = [stt]
+
+        def run_stt(eng=stt):
             feats, nf = stt.frontend.parakeet(pcm, ns, T, out_dtype=torch.bfloat16)
             stt.encode(feats, nf)
             toks, _, _ = stt.tdt_greedy()
@@ -267,6 +274,7 @@ def main():
         following turn-batches' STT legs (and the other lane's TTS leg) run."""
         if args.serial or tts is None:
             return [step() for _ in range(n)]
+        import contextlib
         import queue
         import threading
 
@@ -290,18 +298,38 @@ def main():
 
         ths = [threading.Thread(target=tts_worker, args=(e,)) for e in tts_replicas]
         [t.start() for t in ths]
-        for _ in range(n):
-            t0 = time.perf_counter()
-            ids = run_stt()
-            stage["stt"] += time.perf_counter() - t0
-            while not err:
-                try:
-                    q.put((ids, t0), timeout=1.0)
-                    break
-                except queue.Full:
-                    pass
-            if err:
-                break
+        left = [n]
+        left_lock = threading.Lock()
+
+        def stt_worker(eng, own_stream):
+            try:
+                torch.cuda.set_device(dev)
+                ctx = torch.cuda.stream(torch.cuda.Stream(device=dev)) if own_stream else contextlib.nullcontext()
+                with ctx:
+                    while not err:
+                        with left_lock:
+                            if left[0] <= 0:
+                                return
+                            left[0] -= 1
+                        t0 = time.perf_counter()
+                        ids = run_stt(eng)
+                        with left_lock:
+                            stage["stt"] += time.perf_counter() - t0
+                        while not err:
+                            try:
+                                q.put((ids, t0), timeout=1.0)
+                                break
+                            except queue.Full:
+                                pass
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+
+        if len(stt_replicas) == 1:
+            stt_worker(stt, False)
+        else:
+            sths = [threading.Thread(target=stt_worker, args=(e, True)) for e in stt_replicas]
+            [t.start() for t in sths]
+            [t.join() for t in sths]
         for _ in ths:
             while True:
                 try:
@@ -382,7 +410,7 @@ def main():
                                f"{n_frames} codec frames ({n_frames / 12.5:.2f} s reply) streamed in 8-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames / 12.5,
                    "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
-                   "tts_lanes": len(tts_replicas), "decode_graphs": not args.no_graphs,
+                   "tts_lanes": len(tts_replicas), "stt_lanes": len(stt_replicas), "decode_graphs": not args.no_graphs,
                    "schedule": "serial" if (args.serial or tts is None) else f"pipelined: STT legs back to back on one stream; TTS legs on {len(tts_replicas)} lane(s) (thread + HIP stream each) overlapping the following turn-batches",
                    "parallelism": f"session-pool x{world} (no collectives)"},
         "p50_ttfa_ms": ttfa_ms,

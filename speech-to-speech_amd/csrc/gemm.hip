@@ -491,16 +491,21 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
 // fragments (the fragment-shaped activation loads, not the weight stream, are what saturates the load path at M = 64).
 // GLU = true: W holds [gate rows | up rows] (N each); the workgroup accumulates both for its channels and the
 // epilogue writes silu(gate) * up (SwiGLU fused, output width N).
-template <typename T, typename CT, int MT, int NF, bool GLU>
+// NORM = true (bf16 only): A points at the raw f32 residual rows; the A fragments are converted to bf16 in registers, the
+// rows' sums of squares come out of the same loads (per-wave partials -> LDS), and the combined tile is scaled by
+// rsqrt(mean(x^2) + eps) in the epilogue (RMSNorm with its weight pre-folded into W): no separate norm launch.
+template <typename T, typename CT, int MT, int NF, bool GLU, bool NORM>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm, int ksplit) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, RowMap rm, int ksplit, float rms_eps) {
     constexpr int EPC = MfmaTraits<T>::EPC;          // k per 16-byte load: 8 (bf16) / 4 (f32)
     constexpr int KB = EPC * 4;                      // k consumed per load step by the 4 lane groups: 32 / 16
     constexpr int NS = NF * (GLU ? 2 : 1);           // weight streams per wave
     constexpr int U = 8 / NS;                        // load steps in flight per stream
     constexpr int RS = GLU ? 2 * MT : MT;
     __shared__ float red[8][RS][64][4];
+    __shared__ float red_ss[NORM ? 8 : 1][64];
+    __shared__ float rstd_s[64];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
         A += z1 * rm.a_z1 + z2 * rm.a_z2;
@@ -530,11 +535,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
         wrow[s] = n < N ? W + ((long)n + (s >= NF ? N : 0)) * rm.ldw : nullptr;
     }
     const T* arow[MT];
+    float ss[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + l15;
         arow[i] = nullptr;
-        if (m < M) arow[i] = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+        ss[i] = 0.f;
+        if (m < M) {
+            if constexpr (NORM) arow[i] = reinterpret_cast<const T*>(reinterpret_cast<const float*>(A) + (long)m * lda);
+            else arow[i] = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+        }
     }
     for (int k0 = kbeg; k0 < kend; k0 += U * KB) {
         u32x4_t fw[U][NS];
@@ -558,7 +568,19 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 u32x4_t va = {0u, 0u, 0u, 0u};
-                if (arow[i] && k < kend) va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                if constexpr (NORM) {
+                    if (arow[i] && k < kend) {
+                        const float* ap = reinterpret_cast<const float*>(arow[i]) + ao;
+                        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(ap), x1 = *reinterpret_cast<const f32x4_t*>(ap + 4);
+                        ss[i] += (x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3]) +
+                                 (x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]);
+                        typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+                        const f32x8_t xf = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                        va = __builtin_bit_cast(u32x4_t, __builtin_convertvector(xf, bf16x8_t));
+                    }
+                } else {
+                    if (arow[i] && k < kend) va = *reinterpret_cast<const u32x4_t*>(arow[i] + ao);
+                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if constexpr (sizeof(T) == 2) {
@@ -574,6 +596,24 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
         }
     }
     const bool grouped = rm.G < M;
+    if constexpr (NORM) {
+        // row sums of squares: lanes with the same l15 hold different k chunks of row i*16 + l15 -> combine the 4 lane
+        // groups, then the 8 waves' K slices through LDS
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v = ss[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) red_ss[wave][i * 16 + l15] = v;
+        }
+        __syncthreads();
+        if (tid < MT * 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red_ss[w][tid];
+            rstd_s[tid] = rsqrtf(v / (float)K + rms_eps);
+        }
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         if (f > 0) __syncthreads();
@@ -593,10 +633,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[w][i][l][r];
+            if constexpr (NORM) v *= rstd_s[m];
             if constexpr (GLU) {
                 float u2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) u2 += red[w][MT + i][l][r];
+                if constexpr (NORM) u2 *= rstd_s[m];
                 v = v / (1.0f + expf(-v)) * u2;
             }
             long coff, roff;
@@ -654,16 +696,23 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         int ksplit = 1;
         // few-column residual GEMMs (out / down projections) would leave most CUs idle: split K across workgroups
         const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
-        if (g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 && in_place && !g.glu) {
+        if (g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 && in_place && !g.glu && !g.a_f32_rms) {
             constexpr int KB = MfmaTraits<T>::EPC * 4;
             while (slabs * ksplit < 256 && ksplit < 8 && K / (ksplit * 2) >= 8 * KB) ksplit *= 2;
         }
         dim3 grid(slabs * ksplit, nz);
         ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz * (g.glu ? 2 : 1),
                        ((double)N * K * sizeof(T) * (g.glu ? 2 : 1) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-#define S2S_SK(MTV, NFV, GLUV)                                                                                  \
-    gemm_skinny_kernel<T, CT, MTV, NFV, GLUV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W, g.bias, \
-                                                                     g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, rm, ksplit)
+#define S2S_SK1(MTV, NFV, GLUV, NORMV)                                                                                        \
+    gemm_skinny_kernel<T, CT, MTV, NFV, GLUV, NORMV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, \
+                                                                           (CT*)g.C, g.ldc, M, N, K, g.act, rm, ksplit, g.rms_eps)
+#define S2S_SK(MTV, NFV, GLUV)                                           \
+    do {                                                                 \
+        if constexpr (sizeof(T) == 2) {                                  \
+            if (g.a_f32_rms) { S2S_SK1(MTV, NFV, GLUV, true); break; }   \
+        }                                                                \
+        S2S_SK1(MTV, NFV, GLUV, false);                                  \
+    } while (0)
 #define S2S_SK_MT(NFV, GLUV)                  \
     switch (MT) {                             \
         case 1: S2S_SK(1, NFV, GLUV); break;  \
@@ -689,6 +738,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         }
 #undef S2S_SK_MT
 #undef S2S_SK
+#undef S2S_SK1
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
                (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {
         const int tiles_m = cdiv(M, T3_M), tiles_n = cdiv(N, T3_N);
@@ -732,6 +782,10 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
     S2S_REQUIRE(g.tap_len % epc == 0 && g.tap_stride % epc == 0, "gemm: tap_len / tap_stride must be multiples of %d", epc);
     S2S_REQUIRE(g.ldw % epc == 0 && g.a_z1 % epc == 0 && g.a_z2 % epc == 0 && g.w_z1 % epc == 0 && g.w_z2 % epc == 0,
                 "gemm: ldw / batch strides must be multiples of %d elements", epc);
+    if (g.a_f32_rms)
+        S2S_REQUIRE(g.ab_dtype == S2S_BF16 && g.M <= 64 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && g.rms_eps > 0.f &&
+                        g.residual == nullptr,
+                    "gemm: the RMSNorm-fused path is a bf16 decode (M <= 64) feature over plain f32 rows");
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_F32) return launch_gemm<__hip_bfloat16, float>(st, g);
     if (g.ab_dtype == S2S_F32 && g.c_dtype == S2S_F32) return launch_gemm<float, float>(st, g);

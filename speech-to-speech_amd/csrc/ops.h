@@ -18,6 +18,10 @@ struct GemmArgs {
     float alpha; bool alpha_set;                 // C = act(acc+bias)*alpha + residual (alpha_set false -> 1)
     int tap_len; long tap_stride;                // dilated conv taps: A index k -> (k/tap_len)*tap_stride + k%tap_len
     bool glu;                                    // M <= 64: W = [gate rows | up rows] (N each), C = silu(gate) * up (width N)
+    // Decode-path RMSNorm fusion (bf16 weights, M <= 64): A is the raw f32 residual stream [M][lda]; the kernel rounds it
+    // to bf16 on the fly, accumulates every row's sum of squares from the same loads and scales the output tile by
+    // rsqrt(mean(x^2) + rms_eps).  The norm weight must already be folded into W's columns (W[n][k] * gamma[k]).
+    bool a_f32_rms; float rms_eps;
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,

@@ -12,6 +12,7 @@
 // (dilated) convolution and transposed convolution is ONE GEMM over overlapping rows (no im2col).
 #include "ops.h"
 
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,7 @@ int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char*
 int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
               int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype);
 int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
+int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
                  int dim, int accumulate, const void* addvec, int dtype);
 int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* h, long rows, int Q, int cb, int dim, int dtype);
@@ -54,6 +56,9 @@ struct Stack {
     std::string prefix;      // weight name prefix, e.g. "talker."
     void *kc = nullptr, *vc = nullptr;          // [L][B][max_pos][Hk*D]
     const float *cosT = nullptr, *sinT = nullptr;
+    // bf16 decode path: per layer, the projections that consume a normed input with the RMSNorm weight folded into their
+    // columns (qkv <- ln1, gate/up <- ln2), so that the norm itself runs inside the GEMM (GemmArgs::a_f32_rms)
+    std::vector<void*> qkv_n, gu_n;
 };
 
 struct Tts {
@@ -88,6 +93,8 @@ struct Tts {
     int *frame_dev = nullptr, *min_dev = nullptr;
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
+    std::vector<void*> head_n;         // code-predictor heads with pred.norm folded in (bf16 decode path)
+    std::vector<void*> owned;          // device buffers created at finalize (folded weights)
 };
 
 static const TTensor* tf(const Tts* m, const std::string& n) {
@@ -273,6 +280,31 @@ static int finalize(Tts* m) {
         }
         m->pos_c = ints + 8 * B + 8;
     }
+    if (c.dtype == S2S_BF16 && getenv("S2S_NORM_FUSION") != nullptr) {   // opt-in: measured neutral-to-slower on MI355X
+        int rc;
+        auto fold = [&](const std::string& wname, const std::string& gname, long rows, int K, void** out) -> int {
+            void* buf = nullptr;
+            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)rows * K * e));
+            m->owned.push_back(buf);
+            *out = buf;
+            return fold_norm_weight(nullptr, TP(m, wname), TPF(m, gname), buf, rows, K, c.dtype);
+        };
+        for (Stack* s : {&m->talker, &m->pred}) {
+            const auto& sc = s->c;
+            const long nq = (long)(sc.heads + 2 * sc.kv_heads) * sc.head_dim;
+            s->qkv_n.assign(sc.layers, nullptr);
+            s->gu_n.assign(sc.layers, nullptr);
+            for (int l = 0; l < sc.layers; ++l) {
+                const std::string p = s->prefix + std::to_string(l) + ".";
+                if ((rc = fold(p + "qkv.w", p + "ln1", nq, sc.hidden, &s->qkv_n[l]))) return rc;
+                if ((rc = fold(p + "gu.w", p + "ln2", 2L * sc.ffn, sc.hidden, &s->gu_n[l]))) return rc;
+            }
+        }
+        m->head_n.assign(c.n_groups - 1, nullptr);
+        for (int g = 0; g < c.n_groups - 1; ++g)
+            if ((rc = fold("pred.head." + std::to_string(g) + ".w", "pred.norm", c.codebook, c.p_hidden, &m->head_n[g]))) return rc;
+        S2S_HIP_CHECK(hipDeviceSynchronize());
+    }
     m->finalized = true;
     return S2S_OK;
 }
@@ -291,8 +323,16 @@ static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int 
     int rc;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
-        if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
-        if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+        const bool fuse_norm = M <= 64 && !s.qkv_n.empty();      // decode rows: RMSNorm runs inside the consuming GEMM
+        if (fuse_norm) {
+            GemmArgs q{};
+            q.A = x; q.lda = hid; q.W = s.qkv_n[l]; q.C = m->qkv; q.ldc = nq; q.M = M; q.N = nq; q.K = hid;
+            q.ab_dtype = dt; q.c_dtype = dt; q.act = S2S_ACT_NONE; q.a_f32_rms = true; q.rms_eps = c.eps;
+            if ((rc = gemm_ex(st, q))) return rc;
+        } else {
+            if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
+            if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+        }
         void* kc = at(s.kc, l * cache_layer);
         void* vc = at(s.vc, l * cache_layer);
         if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
@@ -305,11 +345,12 @@ static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int 
         a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
         if ((rc = attn_rows(st, a, dt))) return rc;
         if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
-        if ((rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
-        if (M <= 64) {   // decode: SwiGLU fused into the weight-streaming GEMM's epilogue
+        if (!fuse_norm && (rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
+        if (M <= 64) {   // decode: SwiGLU (and, on the bf16 path, the RMSNorm in front) fused into the weight-streaming GEMM
             GemmArgs gg{};
             gg.A = m->h; gg.lda = hid; gg.W = TP(m, p + "gu.w"); gg.C = m->act; gg.ldc = c.ffn; gg.M = M; gg.N = c.ffn; gg.K = hid;
             gg.ab_dtype = dt; gg.c_dtype = dt; gg.act = S2S_ACT_NONE; gg.glu = true;
+            if (fuse_norm) { gg.A = x; gg.W = s.gu_n[l]; gg.a_f32_rms = true; gg.rms_eps = c.eps; }
             if ((rc = gemm_ex(st, gg))) return rc;
         } else {
             if ((rc = gemm(st, m->h, hid, TP(m, p + "gu.w"), nullptr, nullptr, m->gu, 2 * c.ffn, M, 2 * c.ffn, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
@@ -368,8 +409,15 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         // cached positions before this pass are a host constant: 0, then g + 1 (row g of the constant table)
         if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, m->pos_p + (size_t)g * m->max_batch, g + 2, nullptr))) return rc;
         // last row of every session (second row of the prefill pass) -> norm -> group head
-        if ((rc = rmsnorm_ex(st, m->xp + (size_t)(T_len - 1) * P, (long)T_len * P, TPF(m, "pred.norm"), m->h, nullptr, B, P, c.eps, dt))) return rc;
-        if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if (!m->head_n.empty() && B <= 64) {      // bf16: pred.norm runs inside the head GEMM (row stride T_len * P picks the last row)
+            GemmArgs hg{};
+            hg.A = m->xp + (size_t)(T_len - 1) * P; hg.lda = (long)T_len * P; hg.W = m->head_n[g]; hg.C = m->logits; hg.ldc = CB;
+            hg.M = B; hg.N = CB; hg.K = P; hg.ab_dtype = dt; hg.c_dtype = S2S_F32; hg.act = S2S_ACT_NONE; hg.a_f32_rms = true; hg.rms_eps = c.eps;
+            if ((rc = gemm_ex(st, hg))) return rc;
+        } else {
+            if ((rc = rmsnorm_ex(st, m->xp + (size_t)(T_len - 1) * P, (long)T_len * P, TPF(m, "pred.norm"), m->h, nullptr, B, P, c.eps, dt))) return rc;
+            if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        }
         if ((rc = pred_pick(st, m->logits, CB, m->frame_dev, m->finished, m->codes_out, c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)),
                             m->x, m->pin, m->pin_t, E, B, dt))) return rc;
     }
@@ -439,6 +487,7 @@ extern "C" int32_t s2s_tts_destroy(void* model) {
     if (m->arena) (void)hipFree(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
     if (m->pos_p) (void)hipFree(m->pos_p);
+    for (void* p : m->owned) (void)hipFree(p);
     for (void* p : m->cstate) (void)hipFree(p);
     for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);

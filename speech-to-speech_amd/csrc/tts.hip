@@ -146,6 +146,21 @@ int gather_embed(hipStream_t st, const void* table, const int* ids, int id_strid
     return S2S_OK;
 }
 
+// out[n][k] = W[n][k] * gamma[k]  (RMSNorm weight folded into the consuming projection's input columns)
+template <typename T>
+__global__ void fold_cols_kernel(const T* __restrict__ W, const float* __restrict__ gamma, T* __restrict__ out, long rows, int K) {
+    const long total = rows * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        Elem<T>::st(out + i, Elem<T>::ld(W + i) * gamma[i % K]);
+}
+
+int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype) {
+    const int blocks = (int)std::min<long>(cdiv(rows * K, 256), 8192);
+    S2S_DT(TT, (fold_cols_kernel<TT><<<blocks, 256, 0, st>>>((const TT*)W, gamma, (TT*)out, rows, K)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
 // ---- fused greedy picks of the frame loop ----------------------------------------------------------------
 // block-wide argmax of one logits row with optional suppress masks; ties -> lowest index (torch.argmax)
 __device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
