@@ -117,7 +117,7 @@ def _rand_whisper_sd(dims, g):
     return sd
 
 
-def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=4):
+def cpu_baseline(dims_full, utt_seconds, decode_tokens, layer_sample=24):
     """The CPU oracle (torch-CPU float32 port of the same algorithm) on ONE session's STT leg of the same workload.
 
     Bounded sample: the model is instantiated with `layer_sample` of its (identical-cost) encoder and decoder layers; the
@@ -397,7 +397,16 @@ def main():
                  "kernel_ms_per_step": round(r["ms"] / n_prof, 2),
                  "algorithmic_tflop_per_step": round(r["flops"] / n_prof / 1e12, 3), "algorithmic_gb_per_step": round(r["bytes"] / n_prof / 1e9, 2),
                  "other_families_ms_per_step": {k: round(v["ms"] / n_prof, 2) for k, v in prof.items() if k != dom},
+                 "event_pair_overhead_us_subtracted_per_launch": round(float(lib.s2s_prof_event_overhead_us()), 2),
                  "sampled_over": f"{n_prof} step(s) of the same workload run right after the timed region (stream launches; the timed region replays hipGraphs)"})
+    # HBM traffic of the dominant family from the PMC counters (separate rocprofv3 --pmc passes over the decode-GEMM
+    # microbenchmark, profiles/r01_pmc_skinny.json): measured bytes / algorithmic bytes, applied to this run's bytes per launch
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_skinny.json")
+    if dom == "gemm_skinny" and os.path.exists(pmc_path):
+        ratio = json.load(open(pmc_path))["hbm_traffic_over_algorithmic"]
+        roof["traffic"] = round(ratio * r["bytes"] / max(r["launches"], 1))
+        roof["traffic_note"] = (f"bytes per launch = {ratio:.3f} x algorithmic bytes per launch; ratio from FETCH_SIZE (x2, gfx950) + WRITE_SIZE over "
+                                "the decode-GEMM microbenchmark (profiles/r01_pmc_skinny.json), not collected live")
     ttfa_ms = None if ttfas[0] is None else round(float(np.median(ttfas)) * 1e3, 1)
     line = {
         "metric": "concurrent real-time sessions/GPU; p50 time-to-first-audio (ms), 10s utterance",

@@ -61,6 +61,9 @@ int32_t s2s_device_count(void);
 #define S2S_PROF_NCAT 8
 int32_t s2s_prof_enable(uint32_t category_mask);
 int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches);
+/* Device time of an empty start/stop event pair (median, measured on first collect); s2s_prof_collect subtracts it from
+ * every launch so that the family averages match profiler kernel durations.  0 before the first collect. */
+double s2s_prof_event_overhead_us(void);
 /* The autoregressive loops (TTS codec frames, Whisper decode steps) keep every per-step quantity on the
  * device and replay one captured hipGraph per step.  on = 0 forces plain stream launches (the same kernels,
  * the same results); graphs are also bypassed while kernel timing is enabled.  Default on; the environment

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "s2s_device_count": [],
     "s2s_prof_enable": [C.c_uint32],
     "s2s_graphs_enable": [_i32],
+    "s2s_prof_event_overhead_us": [],
     "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],
     "s2s_frontend_destroy": [_vp],
@@ -108,7 +109,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
              "s2s_parakeet_workspace_bytes": C.c_int64, "s2s_tts_workspace_bytes": C.c_int64,
-             "s2s_codec_samples": C.c_int64}
+             "s2s_codec_samples": C.c_int64, "s2s_prof_event_overhead_us": C.c_double}
 
 
 def load():
