@@ -15,7 +15,83 @@ from ..session_pool import SessionPool
 from ..text import load_tokenizer
 
 logger = logging.getLogger(__name__)
-PROGRESSIVE_WINDOW_S = 15.0
+PROGRESSIVE_WINDOW_S = 15.0      # STT/smart_progressive_streaming.py:44 max_window_size
+SENTENCE_BUFFER_S = 2.0          # :45 sentence_buffer
+SENTENCE_FINAL = (".", "?", "!", "\u3002", "\uff1f", "\uff01")
+
+
+def sentence_segments(tokenizer: Any, ids: list[int], starts_s: list[float], ends_s: list[float]) -> list[dict]:
+    """Token times -> the ``timestamp["segment"]`` list the reference's progressive streamer consumes
+    (STT/smart_progressive_streaming.py:81-84: ``{"segment": text, "start": s, "end": s}``): a segment closes after a token
+    whose text ends with sentence-final punctuation (the NeMo / nano-parakeet segment convention); the tail is one more."""
+    segs, cur = [], []
+    for j, tid in enumerate(ids):
+        cur.append(j)
+        piece = tokenizer.decode([tid]).strip()
+        if piece.endswith(SENTENCE_FINAL):
+            segs.append(cur)
+            cur = []
+    if cur:
+        segs.append(cur)
+    return [{"segment": tokenizer.decode([ids[j] for j in g]).strip(), "start": float(starts_s[g[0]]), "end": float(ends_s[g[-1]])} for g in segs]
+
+
+class PooledParakeetModel:
+    """The ``model`` object STT/smart_progressive_streaming.py:38-57 expects (nano-parakeet's surface):
+    ``transcribe(audio, timestamps=True)`` -> ``.text`` and ``.timestamp["segment"]``, served by the MI355X session pool."""
+
+    def __init__(self, pool: SessionPool, tokenizer: Any, best_effort: bool = False):
+        self.pool, self.tokenizer, self.best_effort = pool, tokenizer, best_effort
+
+    def transcribe(self, audio: Any, timestamps: bool = False) -> Any:
+        from types import SimpleNamespace
+
+        if self.best_effort:
+            res = self.pool.try_transcribe("parakeet", audio, max_queue=self.pool.max_batch)
+            if res is None:
+                raise BlockingIOError("pool busy")
+        else:
+            res = self.pool.transcribe("parakeet", audio)
+        text = self.tokenizer.decode(res["ids"]).strip()
+        if not timestamps:
+            return SimpleNamespace(text=text)
+        ends = res.get("ends_s") or [s + 0.08 for s in res["starts_s"]]
+        return SimpleNamespace(text=text, timestamp={"segment": sentence_segments(self.tokenizer, res["ids"], res["starts_s"], ends)})
+
+
+class SentenceWindow:
+    """Live-partial state of one turn: sentences already fixed + the window still being re-transcribed.  Same policy as
+    STT/smart_progressive_streaming.py:87-157 (transcribe_incremental): transcribe from the end of the last fixed
+    sentence; once that window reaches 15 s and holds more than one sentence, fix every sentence that ends more than 2 s
+    before the window end, move the window start there and transcribe the shorter window again."""
+
+    def __init__(self, model: Any, max_window_s: float = PROGRESSIVE_WINDOW_S, sentence_buffer_s: float = SENTENCE_BUFFER_S):
+        self.model, self.max_window_s, self.sentence_buffer_s = model, max_window_s, sentence_buffer_s
+        self.fixed: list[str] = []
+        self.fixed_end_s = 0.0
+        self.last_len = 0
+
+    def update(self, audio: Any) -> tuple[str, str] | None:
+        """-> (fixed_text, active_text), or None when there is nothing new to transcribe (< 0.5 s or no new samples)."""
+        n = len(audio)
+        if n < 8000 or n == self.last_len:
+            return None
+        self.last_len = n
+        window = audio[int(self.fixed_end_s * 16000):]
+        res = self.model.transcribe(window, timestamps=True)
+        segs = res.timestamp.get("segment", [])
+        dur = len(window) / 16000.0
+        if dur >= self.max_window_s and len(segs) > 1:
+            cutoff, moved = dur - self.sentence_buffer_s, None
+            for sg in segs:
+                if sg["end"] >= cutoff:
+                    break
+                self.fixed.append(sg["segment"].strip())
+                moved = self.fixed_end_s + sg["end"]
+            if moved is not None:
+                self.fixed_end_s = moved
+                res = self.model.transcribe(audio[int(self.fixed_end_s * 16000):], timestamps=True)
+        return " ".join(self.fixed), res.text.strip()
 
 
 def build_parakeet_engine(model_name: str, device: str, compute_type: str, max_batch: int, max_seconds: float):
@@ -42,16 +118,27 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
         self.pool.ensure_engine("parakeet", lambda: build_parakeet_engine(model_name, device, compute_type, max_batch, max_seconds))
+        self._live_model = PooledParakeetModel(self.pool, self.tokenizer, best_effort=True)
+        self._windows: dict[Any, SentenceWindow] = {}
 
     def process(self, vad_audio: Any) -> Iterator[Any]:
         audio = vad_audio.audio
+        windows = self.__dict__.setdefault("_windows", {})
         if vad_audio.mode == "progressive":
-            window = audio[-int(PROGRESSIVE_WINDOW_S * 16000):]
-            res = self.pool.try_transcribe("parakeet", window, max_queue=self.pool.max_batch)
-            if res is None:
+            win = windows.get(vad_audio.turn_id)
+            if win is None:
+                windows.clear()              # one live turn per pipeline unit
+                live = self.__dict__.setdefault("_live_model", PooledParakeetModel(self.pool, self.tokenizer, best_effort=True))
+                win = windows[vad_audio.turn_id] = SentenceWindow(live)
+            try:
+                upd = win.update(audio)
+            except BlockingIOError:
                 return     # busy: skip this partial, exactly like the reference's 10 ms try-lock
-            yield PartialTranscription(text=self.tokenizer.decode(res["ids"]).strip(), turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision)
+            if upd is not None:
+                fixed, active = upd
+                yield PartialTranscription(text=(fixed + " " + active).strip(), turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision)
             return
+        windows.pop(vad_audio.turn_id, None)
         try:
             res = self.pool.transcribe("parakeet", audio)
             text = self.tokenizer.decode(res["ids"]).strip()

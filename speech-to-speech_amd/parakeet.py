@@ -174,10 +174,19 @@ class ParakeetEngine:
                 [f_h[b, : n_h[b]].tolist() for b in range(self._B)])
 
     def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
-        """SessionPool entry point: {"ids": non-blank token ids, "starts_s": start time of each token in seconds}."""
+        """SessionPool entry point: {"ids": non-blank token ids, "starts_s" / "ends_s": start / end time of each token in
+        seconds (encoder frame x 80 ms; end = start + the TDT duration, at least one frame)}."""
         max_len = (self.max_feat_frames - 1) * 160
-        ids, starts = self.transcribe_ids([a[:max_len] if len(a) >= 1280 else np.pad(a, (0, 1280 - len(a))) for a in audios])
-        return [{"ids": i, "starts_s": [f * 0.08 for f in st]} for i, st in zip(ids, starts)]
+        feats, nf, _ = self.features([a[:max_len] if len(a) >= 1280 else np.pad(a, (0, 1280 - len(a))) for a in audios])
+        self.encode(feats, nf)
+        toks, durs, frames = self.tdt_greedy()
+        blank = self.dims.blank
+        out = []
+        for tk, du, fr in zip(toks, durs, frames):
+            keep = [j for j, t in enumerate(tk) if t != blank]
+            out.append({"ids": [tk[j] for j in keep], "starts_s": [fr[j] * 0.08 for j in keep],
+                        "ends_s": [(fr[j] + max(du[j], 1)) * 0.08 for j in keep]})
+        return out
 
     def transcribe_ids(self, audios: Sequence[np.ndarray]):
         """-> per session (non-blank token ids, start frame of each token [x 80 ms])."""

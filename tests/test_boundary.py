@@ -233,3 +233,96 @@ def test_tts_lanes_overlap_turn_batches():
         assert dt < 0.35, f"two 0.2 s batches on two lanes took {dt:.2f} s (serial would be 0.4 s)"
     finally:
         p.shutdown()
+
+
+# ---- live partials: timestamped transcribe + sentence-aware window ---------------------------------------
+class _ScriptedPool:
+    """Stand-in for the session pool: 'transcribes' a window by reading a script of (token id, start_s, end_s) of the whole
+    utterance and returning the tokens that start inside the window (times relative to the window start)."""
+
+    max_batch = 8
+
+    def __init__(self, script, total_samples):
+        self.script, self.total, self.calls = script, total_samples, []
+
+    def transcribe(self, model, audio, **kw):
+        off_s = float(audio[0])                                     # the test audio carries its own offset in seconds
+        dur = len(audio) / 16000.0
+        self.calls.append((round(off_s, 3), round(dur, 3)))
+        toks = [(t, s - off_s, e - off_s) for t, s, e in self.script if off_s <= s < off_s + dur]
+        return {"ids": [t for t, _, _ in toks], "starts_s": [s for _, s, _ in toks], "ends_s": [e for _, _, e in toks]}
+
+    def try_transcribe(self, model, audio, max_queue, **kw):
+        return self.transcribe(model, audio)
+
+
+class _PunctCodec:
+    """ids 0..9 -> words, ids >= 100 -> the word with a full stop."""
+
+    def decode(self, ids):
+        return " ".join(f"w{i % 100}" + ("." if i >= 100 else "") for i in ids)
+
+
+def _ramp_audio(seconds):
+    """audio[i] = i / 16000 so that any slice starts with its own offset in seconds (what _ScriptedPool reads)."""
+    return (np.arange(int(seconds * 16000)) / 16000.0).astype(np.float32)
+
+
+def _script():
+    # one word per second for 24 s, sentence ends at 3.x, 8.x, 13.x, 18.x s
+    return [(i + (100 if i in (3, 8, 13, 18) else 0), i + 0.2, i + 0.6) for i in range(24)]
+
+
+def test_timestamped_transcribe_builds_sentence_segments():
+    from speech_to_speech_amd.handlers.parakeet import PooledParakeetModel
+
+    pool = _ScriptedPool(_script(), 24 * 16000)
+    model = PooledParakeetModel(pool, _PunctCodec())
+    res = model.transcribe(_ramp_audio(10.0), timestamps=True)
+    segs = res.timestamp["segment"]
+    assert [s["segment"] for s in segs] == ["w0 w1 w2 w3.", "w4 w5 w6 w7 w8.", "w9"]
+    assert [round(s["end"], 2) for s in segs] == [3.6, 8.6, 9.6] and round(segs[1]["start"], 2) == 4.2
+    assert res.text == "w0 w1 w2 w3. w4 w5 w6 w7 w8. w9"
+    assert model.transcribe(_ramp_audio(2.0)).text == "w0 w1"
+
+
+def test_sentence_window_fixes_sentences_like_the_reference_streamer():
+    """Growing audio in 0.5 s increments up to 24 s: below 15 s the window is the whole turn; at 15 s the sentences ending
+    before (window - 2 s) are fixed and the window restarts at the last fixed end.  When the reference is present
+    (this container), its own SmartProgressiveStreamingHandler is driven by the same adapter and must agree call by call."""
+    import importlib.util
+    import os
+
+    from speech_to_speech_amd.handlers.parakeet import PooledParakeetModel, SentenceWindow
+
+    ref_path = "/root/reference/src/speech_to_speech/STT/smart_progressive_streaming.py"
+    ref = None
+    if os.path.exists(ref_path):
+        spec = importlib.util.spec_from_file_location("ref_smart_progressive", ref_path)
+        mod = importlib.util.module_from_spec(spec)
+        import sys
+
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        ref = mod.SmartProgressiveStreamingHandler(PooledParakeetModel(_ScriptedPool(_script(), 24 * 16000), _PunctCodec()))
+
+    pool = _ScriptedPool(_script(), 24 * 16000)
+    win = SentenceWindow(PooledParakeetModel(pool, _PunctCodec()))
+    full = _ramp_audio(24.0)
+    seen_fix = False
+    for n in range(8000, len(full) + 1, 8000):
+        got = win.update(full[:n])
+        assert got is not None
+        fixed, active = got
+        if ref is not None:
+            r = ref.transcribe_incremental(full[:n])
+            assert (r.fixed_text, r.active_text) == (fixed, active), f"at {n / 16000:.1f} s"
+        if n / 16000 < 15.0:
+            assert fixed == "" and active.startswith("w0")
+        if fixed:
+            seen_fix = True
+            assert fixed.startswith("w0 w1 w2 w3.") and not active.startswith("w0")
+    assert seen_fix and win.fixed_end_s > 0
+    assert win.update(full) is None                                   # no new samples -> nothing to do
+    # at 15.0 s: window 15 s, cutoff 13 s -> sentences ending at 3.6 and 8.6 are fixed (13.6 is not), restart at 8.6 s
+    assert (0.0, 15.0) in pool.calls and (8.6, 6.4) in pool.calls
