@@ -261,6 +261,217 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnRowsParams p) {
     for (int d = tid; d < D; d += 256) Elem<T>::st(o + d, ((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) * inv);
 }
 
+// ------------------------------------------------------------------------------------
+// Decode STEP attention (one new token per session) with everything in front of it fused: per-head RMSNorm of q and k
+// (optional), rotary embedding at the session's position (optional), the append of the new K / V row to the cache, and
+// the attention itself over cache[jlo .. pos) + the new row (kept in LDS, never re-read from memory).  One workgroup per
+// (head, session); the q heads of a GQA group each rebuild the (tiny) new K row, the group's first head stores it.
+// Same key split / chunk-lane layout as attn_decode_kernel.  Replaces rope_qknorm + kv_append + attn_decode launches.
+// ------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
+    constexpr int EPL = 16 / (int)sizeof(T);
+    constexpr int CH = D / EPL;
+    constexpr int KPI = 64 / CH;
+    constexpr int HALF = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                               // [kv_cap + 8]
+    float* red = smem + p.kv_cap + 8;               // [8] + [4][D]
+    float* sq = red + 8 + 4 * D;                    // [D] scaled, rotated query
+    float* sk = sq + D;                             // [D] new key (values as stored in the cache)
+    float* sv = sk + D;                             // [D] new value
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int group = p.H / p.Hkv, hk = h / group;
+    const int pos = p.pos[b];
+    const T* row = (const T*)p.qkv + (long)b * p.qkv_rs;
+    T* Kc = (T*)p.K + (long)b * p.kv_bs + (long)hk * D;
+    T* Vc = (T*)p.V + (long)b * p.kv_bs + (long)hk * D;
+
+    // ---- new row: wave 0 -> q, wave 1 -> k (same arithmetic as rope_qknorm_kernel), wave 2 -> v ----
+    if (wave < 2) {
+        const T* x = row + (wave == 0 ? (long)h * D : (long)(p.H + hk) * D);
+        const float* w = wave == 0 ? p.qw : p.kw;
+        float a = 0.f, c = 0.f;
+        if (lane < HALF) {
+            a = Elem<T>::ld(x + lane);
+            c = Elem<T>::ld(x + lane + HALF);
+        }
+        if (w) {
+            const float ss = wave_sum(a * a + c * c);
+            const float r = rsqrtf(ss / (float)D + p.eps);
+            if (lane < HALF) {
+                a = a * r * w[lane];
+                c = c * r * w[lane + HALF];
+            }
+        }
+        if (lane < HALF) {
+            float r0 = a, r1 = c;
+            if (p.cosT) {
+                const float cs = p.cosT[(long)pos * HALF + lane], sn = p.sinT[(long)pos * HALF + lane];
+                r0 = a * cs - c * sn;
+                r1 = c * cs + a * sn;
+            }
+            // round through the storage type exactly like the unfused path (q was written back, k goes to the cache)
+            T t0, t1;
+            Elem<T>::st(&t0, r0);
+            Elem<T>::st(&t1, r1);
+            const float f0 = Elem<T>::ld(&t0), f1 = Elem<T>::ld(&t1);
+            if (wave == 0) {
+                sq[lane] = f0 * p.scale;
+                sq[lane + HALF] = f1 * p.scale;
+            } else {
+                sk[lane] = f0;
+                sk[lane + HALF] = f1;
+                if (h % group == 0) {
+                    Kc[(long)pos * p.kv_rs + lane] = t0;
+                    Kc[(long)pos * p.kv_rs + lane + HALF] = t1;
+                }
+            }
+        }
+    } else if (wave == 2) {
+        const T* x = row + (long)(p.H + p.Hkv + hk) * D;
+        for (int d = lane; d < D; d += 64) {
+            const T t = x[d];
+            sv[d] = Elem<T>::ld(&t);
+            if (h % group == 0) Vc[(long)pos * p.kv_rs + d] = t;
+        }
+    }
+    __syncthreads();
+
+    const int jlo = p.window > 0 ? max(0, pos - p.window + 1) : 0;
+    const int nc = pos - jlo;                       // cached keys [jlo, pos); the new key is entry nc
+    const int c = lane % CH, slot = lane / CH;
+    float q[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] = sq[c * EPL + e];
+    const T* Kb = Kc + c * EPL;
+    const T* Vb = Vc + c * EPL;
+    const int per = ((nc + 3) / 4 + KPI - 1) / KPI * KPI;
+    const int w0 = jlo + wave * per, w1 = min(pos, w0 + per);
+
+    float mx = -INFINITY;
+    constexpr int UN = 4;
+    for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
+        u32x4_t kvv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            kvv[u] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (j < w1) kvv[u] = *reinterpret_cast<const u32x4_t*>(Kb + (long)j * p.kv_rs);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            const u32x4_t v = kvv[u];
+            float s = 0.f;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = fmaf(__uint_as_float(v[e] << 16), q[2 * e], s);
+                    s = fmaf(__uint_as_float(v[e] & 0xffff0000u), q[2 * e + 1], s);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(v[e]), q[e], s);
+            }
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (j < w1) {
+                if (c == 0) sc[j - jlo] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+    }
+    // the new key: every wave forms the same dot product from LDS (D <= 128: two elements per lane)
+    float sn = 0.f;
+    for (int d = lane; d < D; d += 64) sn = fmaf(sq[d], sk[d], sn);
+    sn = wave_sum(sn);
+    mx = fmaxf(wave_max(mx), sn);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < nc; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    const float pn = expf(sn - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = ((red[4] + red[5]) + (red[6] + red[7])) + pn;
+    const float inv = 1.0f / sum;
+
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
+        u32x4_t kvv[UN];
+        float pj[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + slot;
+            kvv[u] = (u32x4_t){0u, 0u, 0u, 0u};
+            pj[u] = 0.f;
+            if (j < w1) {
+                kvv[u] = *reinterpret_cast<const u32x4_t*>(Vb + (long)j * p.kv_rs);
+                pj[u] = sc[j - jlo];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const u32x4_t v = kvv[u];
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] = fmaf(pj[u], __uint_as_float(v[e] << 16), acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(pj[u], __uint_as_float(v[e] & 0xffff0000u), acc[2 * e + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pj[u], __uint_as_float(v[e]), acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    float* part = red + 8;     // [4][D]
+    if (slot == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) part[wave * D + c * EPL + e] = acc[e];
+    }
+    __syncthreads();
+    T* o = (T*)p.O + (long)b * p.o_bs + (long)h * D;
+    for (int d = tid; d < D; d += 256)
+        Elem<T>::st(o + d, (((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) + pn * sv[d]) * inv);
+}
+
+template <typename T>
+static int launch_attn_step(hipStream_t st, const AttnStepParams& p) {
+    dim3 grid(p.H, p.B);
+    ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.kv_cap * p.D,
+                   (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_cap * p.D * 2 + (double)p.H * p.D * 2));
+    const size_t lds = sizeof(float) * (size_t)(p.kv_cap + 8 + 8 + 4 * p.D + 3 * p.D);
+    S2S_REQUIRE(lds <= 64 * 1024, "attention step: cache capacity %d too long", p.kv_cap);
+    switch (p.D) {
+        case 32: attn_step_kernel<T, 32><<<grid, 256, lds, st>>>(p); break;
+        case 64: attn_step_kernel<T, 64><<<grid, 256, lds, st>>>(p); break;
+        case 128: attn_step_kernel<T, 128><<<grid, 256, lds, st>>>(p); break;
+        default: return fail(S2S_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32/64/128)", p.D);
+    }
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int attn_step(hipStream_t st, const AttnStepParams& p, int dtype) {
+    S2S_REQUIRE(p.B > 0 && p.H > 0 && p.Hkv > 0 && p.H % p.Hkv == 0 && p.kv_cap > 0 && p.pos, "attention step: bad arguments");
+    return dtype == S2S_BF16 ? launch_attn_step<__hip_bfloat16>(st, p) : launch_attn_step<float>(st, p);
+}
+
 template <typename T>
 static int launch_attn_decode(hipStream_t st, const AttnRowsParams& p) {
     dim3 grid(p.H, p.B);

@@ -59,6 +59,19 @@ struct AttnMfmaParams {
     const int* kv_len; int Tk, Tp, Tq, H, B;
     float scale_log2e;                 // softmax scale * log2(e)
 };
+// One decode step (a single new token per session) of a self-attention layer, from the fused projection row to the output:
+// q/k head RMSNorm + RoPE (both optional), K/V append at pos[b], attention over cache[max(0, pos-window+1) .. pos].
+struct AttnStepParams {
+    const void* qkv; long qkv_rs;      // row b: [q heads | k heads | v heads] x D, model dtype
+    void* K; void* V; long kv_bs, kv_rs;   // cache (b, j, hk, d) at K + b*kv_bs + j*kv_rs + hk*D + d; row pos[b] is written
+    void* O; long o_bs;                // (b, h, d) at O + b*o_bs + h*D + d
+    const float* qw; const float* kw; float eps;       // per-head RMSNorm weights [D] (nullptr: none)
+    const float* cosT; const float* sinT;              // rotary tables [max_pos][D/2] (nullptr: none)
+    const int* pos;                    // int32[B]: tokens already in the cache
+    int B, H, Hkv, D, kv_cap, window;  // kv_cap: cache capacity (LDS sizing); window > 0: sliding window
+    float scale;
+};
+int attn_step(hipStream_t st, const AttnStepParams& p, int dtype);
 int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype);
 int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D);
 int transpose_v(hipStream_t st, const void* V, long v_bs, long v_rs, void* Vt, int B, int H, int D, int Tk,

@@ -309,6 +309,11 @@ static int finalize(Tts* m) {
     return S2S_OK;
 }
 
+static bool fused_attn_step() {
+    static const bool on = getenv("S2S_NO_FUSED_ATTN") == nullptr;   // A/B switch
+    return on;
+}
+
 static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
 static inline const void* at(const void* p, size_t bytes) { return (const char*)p + bytes; }
 
@@ -335,15 +340,27 @@ static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int 
         }
         void* kc = at(s.kc, l * cache_layer);
         void* vc = at(s.vc, l * cache_layer);
-        if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
-                              c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
-        AttnRowsParams a{};
-        a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
-        a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
-        a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
-        a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
-        a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
-        if ((rc = attn_rows(st, a, dt))) return rc;
+        if (T_len == 1 && pos0 && !kv_len_dev && fused_attn_step()) {
+            // decode step: head norms + RoPE + cache append + attention in ONE launch
+            AttnStepParams a{};
+            a.qkv = m->qkv; a.qkv_rs = nq;
+            a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
+            a.O = m->att; a.o_bs = (long)H * D;
+            a.qw = c.qk_norm ? TPF(m, p + "qnorm") : nullptr; a.kw = c.qk_norm ? TPF(m, p + "knorm") : nullptr; a.eps = c.eps;
+            a.cosT = s.cosT; a.sinT = s.sinT; a.pos = pos0;
+            a.B = B; a.H = H; a.Hkv = Hk; a.D = D; a.kv_cap = kv_cap; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+            if ((rc = attn_step(st, a, dt))) return rc;
+        } else {
+            if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
+                                  c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
+            AttnRowsParams a{};
+            a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
+            a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
+            a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
+            a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
+            a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+            if ((rc = attn_rows(st, a, dt))) return rc;
+        }
         if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
         if (!fuse_norm && (rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
         if (M <= 64) {   // decode: SwiGLU (and, on the bf16 path, the RMSNorm in front) fused into the weight-streaming GEMM
