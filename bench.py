@@ -180,11 +180,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal switch for boxes with fewer GPUs than ranks: all ranks share device 0 and rendezvous over gloo, so the
+    # multi-process code path (init, barrier, MAX-reduce, rank-0 line) can be exercised on a 1-GPU box.  Never set by the driver.
+    shared_dev = os.environ.get("S2S_BENCH_SHARE_DEVICE0") == "1"
+    if shared_dev:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = native.load()
@@ -370,7 +378,7 @@ def main():
     prof = {k: native.prof_collect(c) for k, c in cats.items()}
     native.prof_enable()
     stage.update(timed_stage)
-    dt = reduce_step_time(dt, dev)
+    dt = reduce_step_time(dt, torch.device("cpu") if shared_dev else dev)
     if rank != 0:
         return
     step_s = dt / args.steps
@@ -414,7 +422,7 @@ def main():
         "unit": "concurrent real-time sessions, whole job (= sessions x seconds of turn audio [utterance in + reply out] / wall seconds per turn)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.workload.upper()}: {stt_name} + Qwen3-TTS-1.7B dims (random-init weights at true dims), {B} concurrent "
+        "config": {"workload": f"{args.workload.upper()}: {stt_name} + {'Qwen3-TTS test-tiny' if args.workload == 'tiny' else 'Qwen3-TTS-1.7B'} dims (random-init weights at those dims), {B} concurrent "
                                f"{utt_s:g} s sessions batched per GPU, one turn each: STT ({args.decode_tokens if wdims else 'TDT greedy'} tokens) -> echo -> "
                                f"{n_frames} codec frames ({n_frames / 12.5:.2f} s reply) streamed in 8-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames / 12.5,
@@ -435,4 +443,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        try:
+            import torch.distributed as _dist
+
+            if _dist.is_available() and _dist.is_initialized():
+                _dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
