@@ -515,6 +515,7 @@ extern "C" int32_t s2s_tts_destroy(void* model) {
 extern "C" int32_t s2s_tts_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel) {
     Tts* m = (Tts*)model;
     S2S_REQUIRE(m && name && dev_ptr, "tts_set_tensor: null argument");
+    if (m->finalized) return fail(S2S_ERR_STATE, "tts_set_tensor: %s after finalize (captured graphs hold the old pointers)", name);
     S2S_REQUIRE(((uintptr_t)dev_ptr & 15) == 0, "tts_set_tensor: %s is not 16-byte aligned", name);
     m->w[name] = TTensor{dev_ptr, (long)numel};
     return S2S_OK;
