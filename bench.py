@@ -12,9 +12,14 @@ Sessions are the unit of data parallelism: every rank runs its own pool on its o
 no collective on the data path -> "scaling": "weak"; the only cross-rank traffic is the contract's
 barrier + MAX-reduce of the step time.
 
-Prints ONE JSON line (rank 0) incl. `roofline` (the kernel family with the largest share of the timed region, measured
-with HIP events on its own stream inside this process) and `cpu_baseline` (CPU oracle on this node's host cores, bounded
-sample).
+Schedule (default): STT legs back to back on one thread / stream; finished turn-batches go to `--tts-lanes` TTS lanes
+(engine instances sharing the weights; thread + HIP stream each) whose latency-bound decode kernels overlap with each other
+and with the next STT leg on the device.  The TTS frame loop replays a captured hipGraph.  `--serial` runs the legs back to
+back on one stream.
+
+Prints ONE JSON line (rank 0) incl. `roofline` (the kernel family with the largest device time, measured with HIP events on
+its own stream inside this process over one extra step of the same workload right after the timed region - events cannot be
+recorded inside a graph replay) and `cpu_baseline` (CPU oracle on this node's host cores, bounded sample).
 """
 
 from __future__ import annotations
