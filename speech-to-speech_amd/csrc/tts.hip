@@ -162,46 +162,6 @@ int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* ou
 }
 
 // ---- fused greedy picks of the frame loop ----------------------------------------------------------------
-// block-wide argmax of one logits row with optional suppress masks; ties -> lowest index (torch.argmax)
-__device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
-                                                const unsigned char* __restrict__ mask2) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        float x = row[v];
-        if ((mask && mask[v]) || (mask2 && mask2[v])) x = -INFINITY;
-        if (x > best || (x == best && v < bi)) {
-            best = x;
-            bi = v;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) {
-            best = ov;
-            bi = oi;
-        }
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        sv[wave] = best;
-        si[wave] = bi;
-    }
-    __syncthreads();
-    best = sv[0];
-    bi = si[0];
-    for (int w = 1; w < 4; ++w)
-        if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
-            best = sv[w];
-            bi = si[w];
-        }
-    return bi;
-}
-
 // Talker pick (one block per session): code 0 = argmax over the codec vocabulary (specials suppressed; eos too while
 // frame < min_frames), eos / frame bookkeeping, then the inputs that depend on it:
 //   xnext[b] = talker_emb[code0] + pad_embed          (next talker input, residual-group embeddings are added later)

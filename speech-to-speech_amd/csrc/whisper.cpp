@@ -45,9 +45,15 @@ struct Whisper {
     void *y1, *h, *qkv, *vt, *att, *ffn, *enc_out, *cross, *self_k, *self_v;
     float *x, *xd, *logits;
     void *hd, *qkvd, *attd, *ffnd, *qd;
-    int *cur_ids, *pos, *step, *out_ids, *out_len, *finished, *picked, *n_active;
+    int *cur_ids, *pos, *step, *out_ids, *out_len, *finished, *picked;
     int tmax;
-    int* host_flag = nullptr;   // pinned
+    int* host_flag = nullptr;   // pinned, max_batch ints
+    // greedy-decode step as a replayable graph: the step counter, the call's scalars {P, max_new, eos}, the prompt and the
+    // three vocabulary masks live in engine-owned device buffers, so one captured step body per batch size serves every call
+    int *step_dev = nullptr, *params_dev = nullptr, *prompt_buf = nullptr;
+    unsigned char *mask_sup = nullptr, *mask_begin = nullptr, *mask_fill = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, hipGraphExec_t> step_graphs;
 };
 
 static const Tensor* find(const Whisper* m, const std::string& name) {
@@ -157,8 +163,18 @@ static int finalize(Whisper* m) {
     m->qd = base + o_qd; m->ffnd = base + o_ffnd; m->logits = (float*)(base + o_logits);
     int* ints = (int*)(base + o_ints);
     m->cur_ids = ints; m->pos = ints + B; m->step = ints + 2 * B; m->out_len = ints + 3 * B;
-    m->finished = ints + 4 * B; m->picked = ints + 5 * B; m->n_active = ints + 6 * B; m->out_ids = ints + 7 * B;
-    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, 64, 0));
+    m->finished = ints + 4 * B; m->picked = ints + 5 * B; m->out_ids = ints + 7 * B;
+    S2S_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, sizeof(int) * B, 0));
+    {
+        int* ib = nullptr;
+        S2S_HIP_CHECK(hipMalloc((void**)&ib, sizeof(int) * (8 + (size_t)B * m->tmax)));
+        S2S_HIP_CHECK(hipMemset(ib, 0, sizeof(int) * (8 + (size_t)B * m->tmax)));
+        m->step_dev = ib; m->params_dev = ib + 4; m->prompt_buf = ib + 8;
+        unsigned char* mb = nullptr;
+        S2S_HIP_CHECK(hipMalloc((void**)&mb, 3 * (size_t)c.vocab));
+        S2S_HIP_CHECK(hipMemset(mb, 0, 3 * (size_t)c.vocab));
+        m->mask_sup = mb; m->mask_begin = mb + c.vocab; m->mask_fill = mb + 2 * (size_t)c.vocab;
+    }
     m->finalized = true;
     return S2S_OK;
 }
@@ -225,7 +241,7 @@ static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
 }
 
 // one decoder step for B sessions: input ids in m->cur_ids, positions in m->pos
-static int decode_step(Whisper* m, hipStream_t st, int B, int kv_len, bool split_ok) {
+static int decode_step(Whisper* m, hipStream_t st, int B, bool split_ok) {
     const auto& c = m->cfg;
     const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
     const float scale = 1.0f / sqrtf((float)D);
@@ -242,7 +258,9 @@ static int decode_step(Whisper* m, hipStream_t st, int B, int kv_len, bool split
         p.Q = m->qkvd; p.q_bs = 3 * d; p.q_rs = 3 * d;
         p.K = sk; p.V = sv; p.kv_bs = (long)m->tmax * d; p.kv_rs = d;
         p.O = m->attd; p.o_bs = d; p.o_rs = d;
-        p.kv_len_const = kv_len; p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
+        // keys 0 .. pos[b] (the row just appended): constant capacity, per-session causal bound read on the device
+        p.kv_len_const = m->tmax; p.causal = 1; p.causal_off_arr = m->pos;
+        p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
         if ((rc = attn_rows(st, p, dt))) return rc;
         if ((rc = gemm(st, m->attd, d, P(m, lname("dec", l, "o.w")), PF(m, lname("dec", l, "o.b")), m->xd, m->xd, d, B, d, d, dt, S2S_F32, S2S_ACT_NONE, split_ok))) return rc;
         // cross attention
@@ -266,21 +284,31 @@ static int decode_step(Whisper* m, hipStream_t st, int B, int kv_len, bool split
     return S2S_OK;
 }
 
-// after a step: route the selected token (or the forced prompt token) to the next step's input,
-// record generated tokens, track EOS.  One thread per session.
-__global__ void whisper_advance_kernel(const int* __restrict__ picked, const int* __restrict__ prompt, int P,
-                                       int step, int B, int eos, int max_new, int* cur_ids, int* pos, int* stepv,
-                                       int* out_ids, int* out_len, int* finished, int* n_active) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// End of a step, one block per session: greedy pick over the vocabulary (while the prompt is being consumed the
+// prompt-fill mask applies - language detection placeholders -, afterwards the suppress mask, plus the begin-suppress
+// mask on the first generated position), then route the pick (or the forced prompt token) to the next step's input,
+// record generated tokens and track EOS.  The step index and the call's scalars are read from device memory.
+__global__ __launch_bounds__(256) void whisper_pick_advance_kernel(const float* __restrict__ logits, int V,
+                                                                   const unsigned char* __restrict__ mask_sup,
+                                                                   const unsigned char* __restrict__ mask_begin,
+                                                                   const unsigned char* __restrict__ mask_fill,
+                                                                   const int* __restrict__ step_dev, const int* __restrict__ params,
+                                                                   const int* __restrict__ prompt, int* cur_ids, int* pos,
+                                                                   int* out_ids, int* out_len, int* finished) {
+    const int b = blockIdx.x;
+    const int step = *step_dev, P = params[0], max_new = params[1], eos = params[2];
+    const bool in_prompt = step + 1 < P;
+    const int picked = block_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup,
+                                        (!in_prompt && step == P - 1) ? mask_begin : nullptr);
+    if (threadIdx.x != 0) return;
     // `step` is the index of the token just consumed; the next input sits at position step+1
     int next;
-    if (step + 1 < P) {
+    if (in_prompt) {
         next = prompt[b * P + step + 1];
-        if (next < 0) next = picked[b];   // placeholder: take the (masked) argmax, e.g. the language token
+        if (next < 0) next = picked;   // placeholder: take the (masked) argmax, e.g. the language token
         if (next != prompt[b * P + step + 1]) out_ids[b * (max_new + P) + max_new + step + 1] = next;  // report the filled-in prompt token
     } else {
-        next = picked[b];
+        next = picked;
         const int n = out_len[b];
         if (!finished[b]) {
             if (next == eos) {
@@ -294,8 +322,49 @@ __global__ void whisper_advance_kernel(const int* __restrict__ picked, const int
     }
     cur_ids[b] = next;
     pos[b] = step + 1;
-    stepv[b] = step + 1;
-    if (!finished[b]) atomicAdd(n_active, 1);
+}
+
+__global__ void whisper_step_inc_kernel(int* step_dev) { *step_dev += 1; }
+
+__global__ void whisper_set_params_kernel(int* params, int P, int max_new, int eos, int* step_dev) {
+    params[0] = P; params[1] = max_new; params[2] = eos; *step_dev = 0;
+}
+
+// one full greedy step: decoder pass, pick, advance, step counter.  Shape-static -> capturable.
+static int step_body(Whisper* m, hipStream_t st, int B, bool split_ok) {
+    int rc = decode_step(m, st, B, split_ok);
+    if (rc) return rc;
+    whisper_pick_advance_kernel<<<B, 256, 0, st>>>(m->logits, m->cfg.vocab, m->mask_sup, m->mask_begin, m->mask_fill, m->step_dev,
+                                                   m->params_dev, m->prompt_buf, m->cur_ids, m->pos, m->out_ids, m->out_len, m->finished);
+    S2S_LAUNCH_CHECK();
+    whisper_step_inc_kernel<<<1, 1, 0, st>>>(m->step_dev);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+static int step_graph(Whisper* m, int B, bool split_ok, hipGraphExec_t* out) {
+    auto it = m->step_graphs.find(B);
+    if (it != m->step_graphs.end()) {
+        *out = it->second;
+        return S2S_OK;
+    }
+    if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    S2S_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = step_body(m, m->cap_stream, B, split_ok);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    S2S_HIP_CHECK(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2S_HIP_CHECK(ie);
+    m->step_graphs[B] = exec;
+    *out = exec;
+    return S2S_OK;
 }
 
 }  // namespace s2s
@@ -320,6 +389,10 @@ extern "C" int32_t s2s_whisper_destroy(void* model) {
     Whisper* m = (Whisper*)model;
     if (m->arena) (void)hipFree(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
+    if (m->step_dev) (void)hipFree(m->step_dev);
+    if (m->mask_sup) (void)hipFree(m->mask_sup);
+    for (auto& kv : m->step_graphs) (void)hipGraphExecDestroy(kv.second);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return S2S_OK;
 }
@@ -327,6 +400,7 @@ extern "C" int32_t s2s_whisper_destroy(void* model) {
 extern "C" int32_t s2s_whisper_set_tensor(void* model, const char* name, const void* dev_ptr, int64_t numel) {
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m && name && dev_ptr, "whisper_set_tensor: null argument");
+    if (m->finalized) return fail(S2S_ERR_STATE, "whisper_set_tensor: %s after finalize (captured graphs hold the old pointers)", name);
     S2S_REQUIRE(((uintptr_t)dev_ptr & 15) == 0, "whisper_set_tensor: %s is not 16-byte aligned", name);
     m->w[name] = Tensor{dev_ptr, (long)numel};
     return S2S_OK;
@@ -373,32 +447,43 @@ extern "C" int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t 
     S2S_HIP_CHECK(hipMemsetAsync(m->out_len, 0, sizeof(int) * 2 * m->max_batch, st));   // out_len + finished
     S2S_HIP_CHECK(hipMemsetAsync(m->out_ids, 0, sizeof(int) * (size_t)B * row, st));
     S2S_HIP_CHECK(hipMemsetAsync(m->pos, 0, sizeof(int) * 2 * m->max_batch, st));        // pos + step
+    // the call's prompt, masks and scalars move into the engine's own buffers (what the captured step body reads)
+    S2S_HIP_CHECK(hipMemcpyAsync(m->prompt_buf, prompt_dev, sizeof(int) * (size_t)B * P, hipMemcpyDeviceToDevice, st));
+    auto set_mask = [&](unsigned char* dst, const uint8_t* src) -> hipError_t {
+        return src ? hipMemcpyAsync(dst, src, c.vocab, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, c.vocab, st);
+    };
+    S2S_HIP_CHECK(set_mask(m->mask_sup, suppress_dev));
+    S2S_HIP_CHECK(set_mask(m->mask_begin, begin_suppress_dev));
+    S2S_HIP_CHECK(set_mask(m->mask_fill, prompt_fill_mask_dev));
+    whisper_set_params_kernel<<<1, 1, 0, st>>>(m->params_dev, P, max_new_tokens, eos, m->step_dev);
+    S2S_LAUNCH_CHECK();
     // first input = prompt[:,0]
     S2S_HIP_CHECK(hipMemcpy2DAsync(m->cur_ids, sizeof(int), prompt_dev, sizeof(int) * P, sizeof(int), B, hipMemcpyDeviceToDevice, st));
-    int* n_active = m->n_active;
     const int total_steps = P - 1 + max_new_tokens;
     const bool split_ok = c.dtype == S2S_BF16;
+    const bool use_graph = graphs_enabled() && !prof_active();
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        const int rc = step_graph(m, B, split_ok, &exec);
+        if (rc) return rc;
+    }
     for (int s = 0; s < total_steps; ++s) {
-        int rc = decode_step(m, st, B, s + 1, split_ok);
-        if (rc) return rc;
+        if (use_graph) {
+            S2S_HIP_CHECK(hipGraphLaunch(exec, st));
+        } else {
+            const int rc = step_body(m, st, B, split_ok);
+            if (rc) return rc;
+        }
         const bool in_prompt = s + 1 < P;
-        // prompt placeholders are filled from the argmax restricted by prompt_fill_mask (language detection)
-        const unsigned char* mask = in_prompt ? prompt_fill_mask_dev : suppress_dev;
-        const unsigned char* bmask = (!in_prompt && s == P - 1) ? begin_suppress_dev : nullptr;
-        rc = argmax_suppress(st, m->logits, c.vocab, B, c.vocab, mask, bmask, bmask ? m->step : nullptr, s, m->picked, nullptr);
-        if (rc) return rc;
-        S2S_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), st));
-        whisper_advance_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->picked, prompt_dev, P, s, B, eos, max_new_tokens,
-                                                          m->cur_ids, m->pos, m->step, m->out_ids, m->out_len,
-                                                          m->finished, n_active);
-        S2S_LAUNCH_CHECK();
         if (last_logits_dev && s == total_steps - 1)
             S2S_HIP_CHECK(hipMemcpyAsync(last_logits_dev, m->logits, sizeof(float) * (size_t)B * c.vocab, hipMemcpyDeviceToDevice, st));
-        // early exit: poll the active-session count every 8 generated tokens
+        // early exit: poll the finished flags every 8 generated tokens
         if (!in_prompt && s + 1 >= min_steps && ((s - (P - 1)) & 7) == 7 && s + 1 < total_steps) {
-            S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+            S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
             S2S_HIP_CHECK(hipStreamSynchronize(st));
-            if (*m->host_flag == 0) break;
+            bool all = true;
+            for (int b = 0; b < B; ++b) all = all && m->host_flag[b] != 0;
+            if (all) break;
         }
     }
     S2S_HIP_CHECK(hipMemcpyAsync(out_ids_dev, m->out_ids, sizeof(int) * (size_t)B * row, hipMemcpyDeviceToDevice, st));

@@ -91,3 +91,26 @@ def test_eos_and_early_exit(ref):
     ids, _ = eng.decode([[T["sot"], 301, T["transcribe"], T["notimestamps"]]] * 2, T["eos"], 40, suppress=everything_but_eos)
     assert ids == [[], []]
     eng.close()
+
+
+def test_graph_replay_equals_stream_launches(ref):
+    """The captured decode-step graph (default) and plain stream launches give identical ids, incl. the language placeholder
+    filled from the masked argmax, the begin-suppress step and two decode() calls on one engine (graph reuse)."""
+    from speech_to_speech_amd import native
+
+    dims, sd, audios, enc, ids, filled, logits = ref
+    outs = []
+    for graphs in (True, False):
+        native.graphs_enable(graphs)
+        try:
+            eng = WhisperEngine(dims, sd, dtype=torch.float32, max_batch=4)
+            eng.encode(eng.features(audios))
+            prompt = [[T["sot"], -1, T["transcribe"], T["notimestamps"]]] * len(audios)
+            first = eng.decode(prompt, T["eos"], T["max_new"], T["suppress"], T["begin_suppress"], lang_ids=T["lang_ids"])
+            second = eng.decode([list(f) for f in filled], T["eos"], 5, T["suppress"], T["begin_suppress"])
+            outs.append((first, second))
+            eng.close()
+        finally:
+            native.graphs_enable(True)
+    assert outs[0] == outs[1]
+    assert outs[0][0][0] == ids and outs[0][1][0] == [i[:5] for i in ids]
