@@ -88,6 +88,8 @@ class SessionPool:
         self._stats_lock = threading.Lock()
         self._thread = threading.Thread(target=self._run, name=f"s2s-pool-{device}", daemon=True)
         self._lanes: list[threading.Thread] = []
+        self._lane_ready: list[threading.Event] = []
+        self._warm_requested = False
         self._stopping = False
         self._thread.start()
         self._ensure_lanes(self.tts_lanes)
@@ -96,6 +98,7 @@ class SessionPool:
         while len(self._lanes) < max(1, n):
             i = len(self._lanes)
             t = threading.Thread(target=self._run_tts_lane, args=(i,), name=f"s2s-pool-{self.device}-tts{i}", daemon=True)
+            self._lane_ready.append(threading.Event())
             self._lanes.append(t)
             t.start()
         self.tts_lanes = len(self._lanes)
@@ -114,6 +117,14 @@ class SessionPool:
 
     def engine(self, name: str) -> Any:
         return self._engines[name]
+
+    def warm_tts_lanes(self, timeout: float = 300.0) -> None:
+        """Build every lane's engine (replicas share lane 0's weights) and run its warm-up utterance now, so that the first
+        real request does not pay for it - the reference's handlers load and warm up synchronously in setup()
+        (backend_registry.py:206-264; TTS/qwen3_tts_handler.py setup -> model.warmup)."""
+        self._warm_requested = True
+        for ev in list(self._lane_ready):
+            ev.wait(timeout)
 
     # ---- client API (handler threads) -----------------------------------------------------------
     def transcribe(self, model: str, audio: np.ndarray, **options) -> dict:
@@ -229,6 +240,26 @@ class SessionPool:
             pass
         return contextlib.nullcontext()
 
+    def _lane_start(self, lane: int, warm: bool):
+        """-> (engine, entered stream context) of a lane, or (None, None) when the TTS engine cannot be replicated."""
+        try:
+            eng = self._lane_engine(lane)
+        except BaseException as e:  # noqa: BLE001
+            logger.error("TTS lane %d could not build its engine replica: %s", lane, e, exc_info=True)
+            eng = None
+        if eng is None:
+            return None, None
+        ctx = self._lane_stream_ctx()
+        ctx.__enter__()
+        with self._stats_lock:
+            self.stats["tts_lanes_used"] += 1
+        if warm and hasattr(eng, "warmup"):
+            try:
+                eng.warmup()
+            except BaseException as e:  # noqa: BLE001
+                logger.error("TTS lane %d warm-up failed: %s", lane, e, exc_info=True)
+        return eng, ctx
+
     def _run_tts_lane(self, lane: int) -> None:
         eng, ctx = None, None
         while True:
@@ -237,22 +268,20 @@ class SessionPool:
             except queue.Empty:
                 if self._stopping:
                     return
+                if self._warm_requested and eng is None and "tts" in self._engines and not self._lane_ready[lane].is_set():
+                    eng, ctx = self._lane_start(lane, warm=True)
+                    self._lane_ready[lane].set()
+                    if eng is None and lane > 0:
+                        return                       # no replica possible: lane 0 serves everything
                 continue
             if first is _STOP:
                 return
             if eng is None:
-                try:
-                    eng = self._lane_engine(lane)
-                except BaseException as e:  # noqa: BLE001
-                    logger.error("TTS lane %d could not build its engine replica: %s", lane, e, exc_info=True)
-                    eng = None
+                eng, ctx = self._lane_start(lane, warm=False)
+                self._lane_ready[lane].set()
                 if eng is None:                      # hand the request back to the lanes that have an engine and retire
                     self._tts_q.put(first)
                     return
-                ctx = self._lane_stream_ctx()
-                ctx.__enter__()
-                with self._stats_lock:
-                    self.stats["tts_lanes_used"] += 1
             if self.batch_window_s > 0:
                 time.sleep(self.batch_window_s)
             drained = self._drain(self._tts_q, self.max_batch - 1)

@@ -293,6 +293,15 @@ class TTSEngine:
         t = random_tts_engine_tensors(dims, dtype, dev, max_prompt + max_frames, max_codec_frames, seed)
         return cls(dims, None, dtype, max_batch, max_prompt, max_frames, max_codec_frames, None, dev, engine_tensors=t)
 
+    def warmup(self, prefill_len: int = 100, frames: int = 8) -> None:
+        """One throw-away utterance (the reference warms its backend with ``model.warmup(prefill_len=100)`` in setup(),
+        tests/test_qwen3_tts_handler_backend.py:361-377): loads every kernel and captures the single-session frame graph."""
+        n = max(2, min(int(prefill_len), self.max_prompt))
+        f = max(1, min(int(frames), self.max_frames, self.max_codec_frames))
+        prompt = TTSPrompt(np.zeros((n, self.dims.t_hidden), np.float32))
+        for _ in self.stream([prompt], [f], chunk_size=f, min_frames=f):
+            pass
+
     def replica(self) -> "TTSEngine":
         """A second engine instance on the same GPU that shares this one's weight tensors (no copy) and owns only its KV
         caches / workspace / decode graphs - one per TTS lane of the session pool."""

@@ -326,3 +326,25 @@ def test_sentence_window_fixes_sentences_like_the_reference_streamer():
     assert win.update(full) is None                                   # no new samples -> nothing to do
     # at 15.0 s: window 15 s, cutoff 13 s -> sentences ending at 3.6 and 8.6 are fixed (13.6 is not), restart at 8.6 s
     assert (0.0, 15.0) in pool.calls and (8.6, 6.4) in pool.calls
+
+
+def test_warm_tts_lanes_builds_and_warms_every_lane_before_the_first_request():
+    warmed = []
+
+    class WarmTTS(FakeTTSEngine):
+        def replica(self):
+            return WarmTTS()
+
+        def warmup(self, prefill_len=100, frames=8):
+            warmed.append(threading.current_thread().name)
+
+    p = SessionPool("fake:2", max_batch=2, batch_window_ms=1.0, tts_lanes=3)
+    p._engines.update(tts=WarmTTS())
+    try:
+        p.warm_tts_lanes(timeout=5.0)
+        assert p.stats["tts_lanes_used"] == 3 and len(warmed) == 3 and len(set(warmed)) == 3
+        it, _ = p.synthesize(object(), 8)
+        assert len(list(it)) == 3
+        assert len(warmed) == 3                     # serving does not warm again
+    finally:
+        p.shutdown()
