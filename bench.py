@@ -438,6 +438,7 @@ def main():
                    "tts_lanes": len(tts_replicas), "stt_lanes": len(stt_replicas), "decode_graphs": not args.no_graphs,
                    "schedule": "serial" if (args.serial or tts is None) else f"pipelined: STT legs back to back on one stream; TTS legs on {len(tts_replicas)} lane(s) (thread + HIP stream each) overlapping the following turn-batches",
                    "parallelism": f"session-pool x{world} (no collectives)"},
+        "xrt": round(value, 2),          # audio seconds (utterance in + reply out) processed per wall second, whole job
         "p50_ttfa_ms": ttfa_ms,
         "ttfa_note": "all sessions of the pool end their utterance at t=0; TTFA = STT batch + TTS prefill + first 8-frame chunk + codec + resample + D2H",
         "roofline": roof,
