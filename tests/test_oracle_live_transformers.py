@@ -113,3 +113,63 @@ def test_parakeet_unseen_lengths_match_transformers():
         steps = len(toks[b])
         assert g.sequences[b][1 : 1 + steps].tolist() == toks[b]
         assert g.durations[b][1 : 1 + steps].tolist() == durs[b]
+
+
+def test_qwen3_tts_siblings_unseen_dims():
+    """oracle/qwen3_tts.py vs the sibling modules on dimensions outside the fixture: three decoder blocks (x5, x3, x2),
+    GQA 6:2, window 4 < sequence length (the sliding window actually cuts), 6 code groups, a single-frame utterance."""
+    from transformers import Qwen3Config, Qwen3Model
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import (Qwen3OmniMoeCode2WavConfig,
+                                                                                Qwen3OmniMoeTalkerCodePredictorConfig)
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import (
+        Qwen3OmniMoeCode2Wav, Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration)
+
+    from oracle import qwen3_tts as OT
+    from speech_to_speech_amd.synth_weights import Qwen3TTSDims, qwen3_tts_state_dict
+
+    dims = Qwen3TTSDims(t_hidden=96, t_layers=2, t_heads=6, t_kv_heads=2, t_head_dim=16, t_ffn=160, codec_vocab=90, codec_eos=88,
+                        p_hidden=96, p_layers=1, p_heads=4, p_kv_heads=1, p_head_dim=16, p_ffn=96, n_groups=6, codebook=80,   # predictor width ==
+                        # talker width: the sibling has no input projection (that one is a Qwen3-TTS assumption, DESIGN.md section 7)
+                        c_hidden=48, c_layers=2, c_heads=3, c_ffn=64, c_window=4, c_decoder_dim=64, upsample_rates=(5, 3, 2),
+                        upsampling_ratios=(2, 2))
+    sd = qwen3_tts_state_dict(dims, seed=9)
+    g = torch.Generator().manual_seed(4)
+    c = Qwen3OmniMoeCode2WavConfig(codebook_size=dims.codebook, hidden_size=dims.c_hidden, num_attention_heads=dims.c_heads,
+                                   num_key_value_heads=dims.c_heads, intermediate_size=dims.c_ffn, num_hidden_layers=dims.c_layers,
+                                   num_quantizers=dims.n_groups, upsample_rates=list(dims.upsample_rates),
+                                   upsampling_ratios=list(dims.upsampling_ratios), decoder_dim=dims.c_decoder_dim,
+                                   sliding_window=dims.c_window)
+    m = Qwen3OmniMoeCode2Wav(c).eval()
+    m.load_state_dict({k[len("code2wav."):]: v for k, v in sd.items() if k.startswith("code2wav.")}, strict=True)
+    for frames in (1, 11):
+        codes = torch.randint(0, dims.codebook, (2, dims.n_groups, frames), generator=g)
+        with torch.no_grad():
+            ref = m(codes)
+            got = OT.codec_decode(sd, dims.codec_cfg(), codes)
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) < 2e-4, frames
+
+    pc = Qwen3OmniMoeTalkerCodePredictorConfig(vocab_size=dims.codebook, hidden_size=dims.p_hidden, intermediate_size=dims.p_ffn,
+                                               num_hidden_layers=dims.p_layers, num_attention_heads=dims.p_heads,
+                                               num_key_value_heads=dims.p_kv_heads, head_dim=dims.p_head_dim,
+                                               num_code_groups=dims.n_groups, rms_norm_eps=dims.eps)
+    pm = Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration(pc).eval()
+    pm.load_state_dict({k[len("code_predictor."):]: v for k, v in sd.items() if k.startswith("code_predictor.")}, strict=True)
+    ph, e0 = torch.randn(4, dims.p_hidden, generator=g), torch.randn(4, dims.p_hidden, generator=g)
+    with torch.no_grad():
+        r = pm.generate(inputs_embeds=torch.stack([ph, e0], 1), max_new_tokens=dims.n_groups - 1, do_sample=False, return_dict_in_generate=True)
+        codes, _ = OT.code_predictor_greedy(sd, dims.predictor_cfg(), ph, e0, dims.n_groups)
+    assert codes.tolist() == r.sequences.tolist()
+
+    qc = Qwen3Config(vocab_size=dims.codec_vocab, hidden_size=dims.t_hidden, intermediate_size=dims.t_ffn, num_hidden_layers=dims.t_layers,
+                     num_attention_heads=dims.t_heads, num_key_value_heads=dims.t_kv_heads, head_dim=dims.t_head_dim, rms_norm_eps=dims.eps,
+                     rope_parameters={"rope_theta": dims.t_theta, "rope_type": "default"}, attention_bias=False, tie_word_embeddings=False)
+    qm = Qwen3Model(qc).eval()
+    sub = {k[len("talker.model."):]: v for k, v in sd.items() if k.startswith("talker.model.") and "codec_embedding" not in k}
+    sub["embed_tokens.weight"] = sd["talker.model.codec_embedding.weight"]
+    qm.load_state_dict(sub, strict=True)
+    x = torch.randn(3, 7, dims.t_hidden, generator=g)
+    with torch.no_grad():
+        ref = qm(inputs_embeds=x).last_hidden_state
+        h = OT.rms(OT.DecoderStack(sd, "talker.model.", dims.talker_cfg()).forward(x), sd["talker.model.norm.weight"], dims.eps)
+    assert float((h - ref).abs().max()) < 3e-4
