@@ -125,6 +125,39 @@ int32_t s2s_op_gemm(void* stream, const void* A, int64_t lda, const void* W, con
                     const float* residual, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                     int32_t ab_dtype, int32_t c_dtype, int32_t act);
 
+/* s2s_op_gemm with the decode-path switches exposed, so the parity tests reach every variant the engines launch:
+ * flags bit 0: W = [gate rows | up rows] (N each), C = silu(gate) * up (fused SwiGLU, M <= 64);
+ *       bit 1: allow split-K (only taken for an in-place f32 residual, act NONE);
+ *       bit 2: A is the raw f32 residual stream and RMSNorm (its weight pre-folded into W's columns) runs inside the
+ *              kernel with rms_eps (bf16, M <= 64). */
+int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, const float* bias,
+                       const float* residual, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                       int32_t ab_dtype, int32_t c_dtype, int32_t act, int32_t flags, float rms_eps);
+
+/* One decode-step projection of the norm-free decoder layer (csrc/gemm_dec.hip; bf16, M <= 128 sessions, K >= 256, K % 32 == 0):
+ *   acc = A[M,K] @ W[N,K]^T;  out = rstd[m] * acc + bias  with rstd[m] = rsqrt(sum_p ss_in[p*ss_stride + m] * inv_dim + eps)
+ *   when ss_in != NULL (RMSNorm of the raw rows A, its weight pre-folded into W's columns), else out = acc + bias.
+ *   mode 0: C bf16 = act(out)   (glu != 0: W = [gate | up] rows, C = silu(out_gate) * out_up)
+ *   mode 1: C f32  = act(out)
+ *   mode 2: X f32 [M][ldx] += out in place; XB (optional) = bf16 copy of the new rows; ss_out (optional)
+ *           [s2s_op_gemm_dec_parts(M,N,nf)][ss_stride] = per-column-slab partial sums of squares of the new rows
+ *           (the next projection's ss_in).  Deterministic: no atomics, fixed summation order.
+ *   nf: 16-column fragments per workgroup (0 = chosen from the shape).
+ * Replaces the rmsnorm -> linear pairs of the Qwen3 decoder layer (transformers qwen3/modeling_qwen3.py; sibling code
+ * predictor qwen3_omni_moe/modeling_qwen3_omni_moe.py:2250-2620) on the decode path of TTS/qwen3_tts_handler.py:910-1003. */
+int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                        int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
+                        void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
+                        int32_t nf);
+int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t nf);
+/* xb = bf16(x) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
+int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols);
+
+/* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
+ * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */
+int32_t s2s_graph_bench_begin(void** out_stream);
+int32_t s2s_graph_bench_end(int32_t warm, int32_t reps, double* us_per_replay);
+
 /* y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x f32 [rows][cols], y y_dtype */
 int32_t s2s_op_layernorm(void* stream, const float* x, const float* gamma, const float* beta,
                          void* y, int32_t rows, int32_t cols, float eps, int32_t y_dtype);
@@ -296,6 +329,13 @@ int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_de
  * min_total_frames frames; *all_done_host (optional, forces a stream sync) = 1 when every session has ended. */
 int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
                          int32_t* n_frames_dev, int32_t* all_done_host);
+/* Teacher-forced continuation (continuing given codec frames in context; the parity tests' teacher-forced logits): like
+ * s2s_tts_generate, but every code of the n_frames new frames whose entry in forced_codes_dev int32 [B][n_frames][n_groups]
+ * is >= 0 is emitted (and fed back to the code predictor / talker) instead of the greedy pick, and the raw logits of every
+ * pick are copied to logits_dev f32 [B][n_frames][n_groups][vlog] (optional; group 0 rows hold codec_vocab values, groups
+ * 1.. hold codebook values; vlog >= both).  Plain stream launches (no graph replay). */
+int32_t s2s_tts_generate_forced(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, const int32_t* forced_codes_dev,
+                                float* logits_dev, int32_t vlog, int32_t* codes_dev, int32_t* n_frames_dev);
 /* Codec decoder: codes_dev int32 [B][F][n_groups] (the first ctx frames are left context) -> wav_dev f32
  * [B][n_samples], n_samples = s2s_codec_samples(F) - ctx * total_upsample, values clamped to [-1, 1]. */
 int32_t s2s_codec_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, int32_t ctx,

@@ -99,9 +99,10 @@ class DecoderStack:
         return x
 
 
-def code_predictor_greedy(sd, cfg, past_hidden, code0_embed, n_groups):
+def code_predictor_greedy(sd, cfg, past_hidden, code0_embed, n_groups, forced=None, logits_out=None):
     """past_hidden / code0_embed [B, E] -> residual codes int64 [B, n_groups-1] (greedy) and the embeddings
-    (predictor tables) of each generated code [B, n_groups-1, E]."""
+    (predictor tables) of each generated code [B, n_groups-1, E].  forced [B, n_groups-1] (optional): emit these codes
+    instead of the argmax (teacher forcing); logits_out (optional list): receives every group's logits [B, codebook]."""
     p = "code_predictor."
     x = torch.stack([past_hidden, code0_embed], 1)
     if p + "in_proj.weight" in sd:
@@ -112,7 +113,11 @@ def code_predictor_greedy(sd, cfg, past_hidden, code0_embed, n_groups):
         h = stack.forward(x)
         h = rms(h[:, -1], sd[p + "model.norm.weight"], cfg["eps"])
         logits = F.linear(h, sd[p + f"lm_head.{g}.weight"])
+        if logits_out is not None:
+            logits_out.append(logits.clone())
         c = logits.argmax(-1)
+        if forced is not None:
+            c = torch.where(forced[:, g] >= 0, forced[:, g], c)
         codes.append(c)
         e = sd[p + f"model.codec_embedding.{g}.weight"][c]
         embs.append(e)
@@ -123,9 +128,11 @@ def code_predictor_greedy(sd, cfg, past_hidden, code0_embed, n_groups):
 
 
 def talker_generate(sd, tcfg, pcfg, prompt_embeds, n_groups, max_frames, eos_id, suppress=(), trailing=None, pad_embed=None,
-                    min_frames=0):
+                    min_frames=0, forced=None, logits_out=None):
     """Greedy frame loop.  prompt_embeds [B, P, E].  Returns codes int64 [B, frames, n_groups] (a session's rows after
-    its eos frame are filled with -1), n_frames per session."""
+    its eos frame are filled with -1), n_frames per session.  forced int64 [B, frames, n_groups] (optional, entries < 0 keep
+    the greedy pick): teacher forcing; logits_out (optional list): per frame a list of n_groups raw logits tensors
+    (group 0: [B, codec_vocab] BEFORE the suppress / eos masks, groups 1..: [B, codebook])."""
     B = prompt_embeds.shape[0]
     stack = DecoderStack(sd, "talker.model.", tcfg)
     norm_w, head = sd["talker.model.norm.weight"], sd["talker.codec_head.weight"]
@@ -137,16 +144,21 @@ def talker_generate(sd, tcfg, pcfg, prompt_embeds, n_groups, max_frames, eos_id,
     for f in range(max_frames):
         hn = rms(h, norm_w, tcfg["eps"])
         logits = F.linear(hn, head)
+        frame_logits = [logits.clone()] if logits_out is not None else None
         if len(suppress):
             logits[:, list(suppress)] = -math.inf
         if f < min_frames:
             logits[:, eos_id] = -math.inf
         c0 = logits.argmax(-1)
+        if forced is not None:
+            c0 = torch.where(forced[:, f, 0] >= 0, forced[:, f, 0], c0)
         done = done | (c0 == eos_id)
         if bool(done.all()):
             break
         e0 = emb0[c0]
-        rc, re = code_predictor_greedy(sd, pcfg, hn, e0, n_groups)
+        rc, re = code_predictor_greedy(sd, pcfg, hn, e0, n_groups, None if forced is None else forced[:, f, 1:], frame_logits)
+        if logits_out is not None:
+            logits_out.append(frame_logits)
         codes = torch.cat([c0[:, None], rc], 1)
         codes[done] = -1
         out.append(codes)

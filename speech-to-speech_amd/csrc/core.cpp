@@ -130,6 +130,45 @@ extern "C" int32_t s2s_prof_collect(int32_t category, double* total_ms, double* 
     return S2S_OK;
 }
 
+// ---- graph-replay timing of arbitrary op sequences (microbenchmarks: per-kernel cost INSIDE a captured graph) -------------
+static hipStream_t g_bench_stream = nullptr;
+static bool g_bench_capturing = false;
+
+extern "C" int32_t s2s_graph_bench_begin(void** out_stream) {
+    S2S_REQUIRE(out_stream && !g_bench_capturing, "graph_bench_begin: bad state");
+    if (!g_bench_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&g_bench_stream, hipStreamNonBlocking));
+    S2S_HIP_CHECK(hipStreamBeginCapture(g_bench_stream, hipStreamCaptureModeThreadLocal));
+    g_bench_capturing = true;
+    *out_stream = (void*)g_bench_stream;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_graph_bench_end(int32_t warm, int32_t reps, double* us_per_replay) {
+    S2S_REQUIRE(g_bench_capturing && reps >= 1 && us_per_replay, "graph_bench_end: bad state");
+    g_bench_capturing = false;
+    hipGraph_t graph = nullptr;
+    S2S_HIP_CHECK(hipStreamEndCapture(g_bench_stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2S_HIP_CHECK(ie);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    S2S_HIP_CHECK(hipEventCreate(&e0));
+    S2S_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) S2S_HIP_CHECK(hipGraphLaunch(exec, g_bench_stream));
+    S2S_HIP_CHECK(hipEventRecord(e0, g_bench_stream));
+    for (int i = 0; i < reps; ++i) S2S_HIP_CHECK(hipGraphLaunch(exec, g_bench_stream));
+    S2S_HIP_CHECK(hipEventRecord(e1, g_bench_stream));
+    S2S_HIP_CHECK(hipStreamSynchronize(g_bench_stream));
+    float ms = 0.f;
+    S2S_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_replay = (double)ms * 1e3 / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(exec);
+    return S2S_OK;
+}
+
 extern "C" const char* s2s_last_error(void) { return s2s::g_last_error.c_str(); }
 extern "C" int32_t s2s_abi_version(void) { return S2S_ABI_VERSION; }
 extern "C" int32_t s2s_device_count(void) {

@@ -514,8 +514,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
         if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    // blockIdx.x = n-slab * ksplit + k-part: with ksplit > 1 (bf16 serving policy, residual GEMMs with few columns)
-    // several workgroups share a slab and add their partial tiles onto the in-place residual with f32 atomics
+    // blockIdx.x = n-slab * ksplit + k-part (ksplit is 1: every output element is produced by exactly one workgroup)
     const int kpart = blockIdx.x % ksplit;
     const int n0 = (blockIdx.x / ksplit) * 16 * NF;
     const int kblk = ((K + ksplit - 1) / ksplit + KB - 1) / KB * KB;
@@ -651,16 +650,16 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
                 roff = (long)m * rm.ldr;
             }
             CT* cp = C + coff + nn;
-            if (ksplit > 1) {   // C (f32) already holds the residual; act == NONE
-                if constexpr (sizeof(CT) == 4)
-                    atomicAdd(reinterpret_cast<float*>(cp), (v + ((bias && kpart == 0) ? bias[nn] : 0.f)) * rm.alpha);
-                continue;
-            }
             v = apply_act(v + (bias ? bias[nn] : 0.f), act) * rm.alpha;
             if (residual) v += residual[roff + nn];
             Elem<CT>::st(cp, v);
         }
     }
+}
+
+static bool dec_disabled() {
+    static const bool off = getenv("S2S_NO_GEMM_DEC") != nullptr;   // A/B switch: bf16 decode rows on the r1 skinny kernel
+    return off;
 }
 
 static bool tile3_disabled() {
@@ -693,13 +692,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             else NF = N >= 8192 ? 4 : (N >= 2048 ? 2 : 1);
         }
         const int slabs = cdiv(N, 16 * NF);
-        int ksplit = 1;
-        // few-column residual GEMMs (out / down projections) would leave most CUs idle: split K across workgroups
-        const bool in_place = g.residual == (const float*)g.C && rm.r_bs == rm.c_bs && rm.ldr == g.ldc;
-        if (g.allow_splitk && g.act == S2S_ACT_NONE && sizeof(CT) == 4 && in_place && !g.glu && !g.a_f32_rms) {
-            constexpr int KB = MfmaTraits<T>::EPC * 4;
-            while (slabs * ksplit < 256 && ksplit < 8 && K / (ksplit * 2) >= 8 * KB) ksplit *= 2;
-        }
+        const int ksplit = 1;   // split-K (f32 atomics on the residual) was removed: not run-to-run deterministic
         dim3 grid(slabs * ksplit, nz);
         ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz * (g.glu ? 2 : 1),
                        ((double)N * K * sizeof(T) * (g.glu ? 2 : 1) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
@@ -786,6 +779,17 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
         S2S_REQUIRE(g.ab_dtype == S2S_BF16 && g.M <= 64 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && g.rms_eps > 0.f &&
                         g.residual == nullptr,
                     "gemm: the RMSNorm-fused path is a bf16 decode (M <= 64) feature over plain f32 rows");
+    // bf16 decode rows (one per live session): the pipelined weight-streaming kernel of gemm_dec.hip
+    if (g.ab_dtype == S2S_BF16 && g.M <= 128 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && !g.alpha_set && !g.a_f32_rms &&
+        g.K >= 256 && g.K % 32 == 0 && (g.ldw == 0 || g.ldw % 8 == 0) && (g.residual == nullptr || (g.residual == (const float*)g.C && g.c_dtype == S2S_F32 &&
+        (g.ldr == 0 || g.ldr == g.ldc))) && (!g.glu || (g.c_dtype == S2S_BF16 && !g.bias && g.act == S2S_ACT_NONE)) && !dec_disabled()) {
+        DecGemm a{};
+        a.A = (const __hip_bfloat16*)g.A; a.lda = g.lda; a.W = (const __hip_bfloat16*)g.W; a.ldw = g.ldw > 0 ? g.ldw : g.K; a.bias = g.bias;
+        a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act; a.glu = g.glu;
+        if (g.residual) { a.mode = 2; a.X = (float*)g.C; a.ldx = g.ldc; }
+        else { a.mode = g.c_dtype == S2S_BF16 ? 0 : 1; a.C = g.C; a.ldc = g.ldc; }
+        return gemm_dec(st, a);
+    }
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_F32) return launch_gemm<__hip_bfloat16, float>(st, g);
     if (g.ab_dtype == S2S_F32 && g.c_dtype == S2S_F32) return launch_gemm<float, float>(st, g);
@@ -809,6 +813,19 @@ extern "C" int32_t s2s_op_gemm(void* stream, const void* A, int64_t lda, const v
                                int32_t ab_dtype, int32_t c_dtype, int32_t act) {
     return s2s::gemm((hipStream_t)stream, A, (long)lda, W, bias, residual, C, (long)ldc, M, N, K, ab_dtype,
                      c_dtype, act, /*allow_splitk=*/false);
+}
+
+/* s2s_op_gemm with the decode-path switches exposed (parity tests of the fused-SwiGLU / split-K / in-kernel RMSNorm variants):
+ * flags bit 0: W = [gate rows | up rows], C = silu(gate) * up (M <= 64); bit 1: allow split-K (in-place f32 residual only);
+ * bit 2: A is the raw f32 residual stream, RMSNorm (weight folded into W) runs inside the kernel with rms_eps. */
+extern "C" int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, const float* bias,
+                                  const float* residual, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                  int32_t ab_dtype, int32_t c_dtype, int32_t act, int32_t flags, float rms_eps) {
+    s2s::GemmArgs g{};
+    g.A = A; g.lda = (long)lda; g.W = W; g.bias = bias; g.residual = residual; g.C = C; g.ldc = (long)ldc;
+    g.M = M; g.N = N; g.K = K; g.G = 0; g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
+    g.glu = (flags & 1) != 0; g.allow_splitk = (flags & 2) != 0; g.a_f32_rms = (flags & 4) != 0; g.rms_eps = rms_eps;
+    return s2s::gemm_ex((hipStream_t)stream, g);
 }
 
 /* 1-D convolution over a zero-padded time-major buffer, as one GEMM (no im2col):

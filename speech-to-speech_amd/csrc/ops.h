@@ -27,6 +27,28 @@ int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
          const float* residual, void* C, long ldc, int M, int N, int K, int ab_dtype, int c_dtype,
          int act, bool allow_splitk);
+// Decode-step projection (gemm_dec.hip): bf16, M <= 128, K % 32 == 0.  See the file header for the norm-free layer scheme.
+struct DecGemm {
+    const __hip_bfloat16* A; long lda;      // [M][lda]; raw (un-normalised) bf16 rows when ss_in is set
+    const __hip_bfloat16* W; long ldw;      // [N][ldw]; glu: [gate rows | up rows] (N each)
+    const float* bias;                      // [N] or nullptr
+    int M, N, K;
+    // RMS prologue: out = rsqrt(sum_p ss_in[p][m] * inv_dim + eps) * acc  (gamma folded into W's columns)
+    const float* ss_in; int n_parts_in; int ss_stride; float inv_dim; float eps;
+    int ss_rs;                              // GEMM row m reads ss_in[p * ss_stride + m * ss_rs] (0 -> 1)
+    int mode;                               // 0: C bf16, 1: C f32, 2: X += out (f32, in place) + XB (bf16 copy) + ss_out
+    void* C; long ldc; int act;
+    float* X; long ldx; __hip_bfloat16* XB; long ldxb;
+    float* ss_out;                          // [dec_parts(N, nf)][ss_stride] partial sums of squares of the new X rows
+    bool x_overwrite;                       // mode 2: X = out (no read of the old rows): projections that START a residual stream
+    bool glu;                               // C = silu(gate) * up (mode 0)
+    int nf;                                 // 16-column fragments per workgroup (0: chosen from the shape)
+};
+int gemm_dec(hipStream_t st, const DecGemm& a);
+int dec_nf(const DecGemm& a);
+int dec_parts(int N, int NF);               // partial sums gemm_dec writes per row for an N-column residual projection
+int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols);
+
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,
               int cols, float eps, int y_dtype);
 // rows at x + r*x_rs; optional second copy of the normalised rows in f32 (y_f32, contiguous)
@@ -84,6 +106,13 @@ int kv_append(hipStream_t st, const void* src, long src_rs, int k_off, int v_off
 int argmax_suppress(hipStream_t st, const float* logits, long ld, int B, int V, const unsigned char* mask,
                     const unsigned char* begin_mask, const int* step, int begin_step, int* out, float* out_val);
 int cast_f32(hipStream_t st, const float* in, void* out, long n, int dtype);
+
+// teacher forcing / logit capture of the TTS frame loop (tts.hip pick kernels); all null / zero on the serving path
+struct PickDebug {
+    const int* forced;   // [B][max_frames][G] codes to emit instead of the argmax (entries < 0: keep the argmax)
+    float* log;          // [B][n_log][G][Vlog] raw logits of frames f0 .. f0 + n_log - 1
+    int f0, n_log, Vlog;
+};
 
 // conformer.hip
 struct TdtState {

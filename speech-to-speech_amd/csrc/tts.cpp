@@ -27,9 +27,9 @@ int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dt
 int add_int(hipStream_t st, int* p, int v, int n);
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
-                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype);
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg);
 int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype);
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg);
 int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
 int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
@@ -42,6 +42,8 @@ int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, 
 int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype);
 int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
 
+constexpr int DEC_ROWS = 128;   // rows (sessions x new tokens) the norm-free decode path handles per pass
+constexpr int SS_PARTS = 256;   // most column slabs of a residual projection (hidden / 16)
 constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
 
 struct TTensor { const void* ptr; long numel; };
@@ -94,6 +96,12 @@ struct Tts {
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
     std::vector<void*> head_n;         // code-predictor heads with pred.norm folded in (bf16 decode path)
+    // norm-free decode path (gemm_dec.hip): bf16 copy of the residual rows + two partial-sum-of-squares buffers
+    void* xb = nullptr;                // [DEC_ROWS][max hidden] model dtype
+    float *ssA = nullptr, *ssB = nullptr;   // [SS_PARTS][DEC_ROWS]
+    PickDebug dbg{};                   // teacher forcing / logit capture (s2s_tts_generate_forced); null on the serving path
+    int* forced_buf = nullptr;         // [max_batch][max_frames][G], allocated on first forced call
+    int ss_parts_A = 0;                // parts currently valid in ssA (written by the last residual projection / rows_prep)
     std::vector<void*> owned;          // device buffers created at finalize (folded weights)
 };
 
@@ -280,7 +288,15 @@ static int finalize(Tts* m) {
         }
         m->pos_c = ints + 8 * B + 8;
     }
-    if (c.dtype == S2S_BF16 && getenv("S2S_NORM_FUSION") != nullptr) {   // opt-in: measured neutral-to-slower on MI355X
+    if (c.dtype == S2S_BF16 && getenv("S2S_NO_DEC_FUSION") == nullptr && E % 32 == 0 && P % 32 == 0 && E >= 256 && P >= 256 && c.t_ffn % 32 == 0 &&
+        c.p_ffn % 32 == 0 && c.t_ffn >= 256 && c.p_ffn >= 256 && (c.t_heads * c.t_head_dim) % 32 == 0 && (c.p_heads * c.p_head_dim) % 32 == 0 &&
+        c.t_heads * c.t_head_dim >= 256 && c.p_heads * c.p_head_dim >= 256 && E / 16 <= SS_PARTS && P / 16 <= SS_PARTS) {
+        // norm-free decode path: RMSNorm weights folded into the columns of the consuming projections (own copies; the
+        // prefill path keeps the checkpoint's matrices)
+        S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * std::max(E, P) * e));
+        S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * SS_PARTS * DEC_ROWS));
+        S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
+        m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB);
         int rc;
         auto fold = [&](const std::string& wname, const std::string& gname, long rows, int K, void** out) -> int {
             void* buf = nullptr;
@@ -317,63 +333,105 @@ static bool fused_attn_step() {
 static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
 static inline const void* at(const void* p, size_t bytes) { return (const char*)p + bytes; }
 
+static bool dec_fusion_ok(const Tts* m, const Stack& s, int M) {
+    return m->cfg.dtype == S2S_BF16 && M <= DEC_ROWS && !s.qkv_n.empty() && m->xb;
+}
+
+// attention of one stack pass (q/k head norms, RoPE, cache append, softmax(QK^T)V) from m->qkv into m->att
+static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T_len, const int* pos0, int kv_cap, const int* kv_len_dev) {
+    const auto& c = s.c;
+    const int dt = m->cfg.dtype, e = m->esz;
+    const int H = c.heads, Hk = c.kv_heads, D = c.head_dim;
+    const int nq = (H + 2 * Hk) * D, M = B * T_len;
+    const size_t cache_layer = (size_t)m->max_batch * c.max_pos * Hk * D * e;
+    const std::string p = s.prefix + std::to_string(l) + ".";
+    void* kc = at(s.kc, l * cache_layer);
+    void* vc = at(s.vc, l * cache_layer);
+    int rc;
+    if (T_len == 1 && pos0 && !kv_len_dev && fused_attn_step()) {
+        // decode step: head norms + RoPE + cache append + attention in ONE launch
+        AttnStepParams a{};
+        a.qkv = m->qkv; a.qkv_rs = nq;
+        a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
+        a.O = m->att; a.o_bs = (long)H * D;
+        a.qw = c.qk_norm ? TPF(m, p + "qnorm") : nullptr; a.kw = c.qk_norm ? TPF(m, p + "knorm") : nullptr; a.eps = c.eps;
+        a.cosT = s.cosT; a.sinT = s.sinT; a.pos = pos0;
+        a.B = B; a.H = H; a.Hkv = Hk; a.D = D; a.kv_cap = kv_cap; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+        return attn_step(st, a, dt);
+    }
+    if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
+                          c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
+    AttnRowsParams a{};
+    a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
+    a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
+    a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
+    a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
+    a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+    return attn_rows(st, a, dt);
+}
+
+// Norm-free decode pass (bf16, M = B * T_len <= DEC_ROWS rows): five launches per layer.  On entry m->xb / m->ssA must
+// hold the bf16 copy and the partial sums of squares (m->ss_parts_A parts) of the f32 residual rows x; on exit they
+// describe the final rows again (for a head with the final norm folded in).
+static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, int T_len, const int* pos0, int kv_cap) {
+    const auto& c = s.c;
+    const int H = c.heads, Hk = c.kv_heads, D = c.head_dim, hid = c.hidden;
+    const int nq = (H + 2 * Hk) * D, M = B * T_len;
+    int rc;
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = s.prefix + std::to_string(l) + ".";
+        DecGemm q{};
+        q.A = (const __hip_bfloat16*)m->xb; q.lda = hid; q.W = (const __hip_bfloat16*)s.qkv_n[l]; q.ldw = hid; q.M = M; q.N = nq; q.K = hid;
+        q.ss_in = m->ssA; q.n_parts_in = m->ss_parts_A; q.ss_stride = DEC_ROWS; q.inv_dim = 1.0f / (float)hid; q.eps = c.eps;
+        q.mode = 0; q.C = m->qkv; q.ldc = nq; q.act = S2S_ACT_NONE;
+        if ((rc = gemm_dec(st, q))) return rc;
+        if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, nullptr))) return rc;
+        DecGemm o{};
+        o.A = (const __hip_bfloat16*)m->att; o.lda = (long)H * D; o.W = (const __hip_bfloat16*)TP(m, p + "o.w"); o.ldw = (long)H * D;
+        o.M = M; o.N = hid; o.K = H * D; o.mode = 2; o.X = x; o.ldx = hid; o.XB = (__hip_bfloat16*)m->xb; o.ldxb = hid; o.ss_out = m->ssB;
+        o.ss_stride = DEC_ROWS; o.act = S2S_ACT_NONE;
+        if ((rc = gemm_dec(st, o))) return rc;
+        const int parts_o = dec_parts(hid, dec_nf(o));
+        DecGemm g{};
+        g.A = (const __hip_bfloat16*)m->xb; g.lda = hid; g.W = (const __hip_bfloat16*)s.gu_n[l]; g.ldw = hid; g.M = M; g.N = c.ffn; g.K = hid;
+        g.ss_in = m->ssB; g.n_parts_in = parts_o; g.ss_stride = DEC_ROWS; g.inv_dim = 1.0f / (float)hid; g.eps = c.eps;
+        g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.act = S2S_ACT_NONE; g.glu = true;
+        if ((rc = gemm_dec(st, g))) return rc;
+        DecGemm d{};
+        d.A = (const __hip_bfloat16*)m->act; d.lda = c.ffn; d.W = (const __hip_bfloat16*)TP(m, p + "down.w"); d.ldw = c.ffn;
+        d.M = M; d.N = hid; d.K = c.ffn; d.mode = 2; d.X = x; d.ldx = hid; d.XB = (__hip_bfloat16*)m->xb; d.ldxb = hid; d.ss_out = m->ssA;
+        d.ss_stride = DEC_ROWS; d.act = S2S_ACT_NONE;
+        if ((rc = gemm_dec(st, d))) return rc;
+        m->ss_parts_A = dec_parts(hid, dec_nf(d));
+    }
+    return S2S_OK;
+}
+
 // One pass of a decoder stack over T_len new tokens per session.  x: f32 residual rows [B*T_len][hidden].
 // pos0: device int32[B] = tokens already cached per session (nullptr -> 0).  kv_cap: host upper bound of pos0 + T_len.
 static int stack_forward(Tts* m, hipStream_t st, Stack& s, float* x, int B, int T_len, const int* pos0, int kv_cap, const int* kv_len_dev) {
     const auto& c = s.c;
-    const int dt = m->cfg.dtype, e = m->esz;
+    const int dt = m->cfg.dtype;
     const int H = c.heads, Hk = c.kv_heads, D = c.head_dim, hid = c.hidden;
     const int nq = (H + 2 * Hk) * D, M = B * T_len;
-    const size_t cache_layer = (size_t)m->max_batch * c.max_pos * Hk * D * e;
     int rc;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
-        const bool fuse_norm = M <= 64 && !s.qkv_n.empty();      // decode rows: RMSNorm runs inside the consuming GEMM
-        if (fuse_norm) {
-            GemmArgs q{};
-            q.A = x; q.lda = hid; q.W = s.qkv_n[l]; q.C = m->qkv; q.ldc = nq; q.M = M; q.N = nq; q.K = hid;
-            q.ab_dtype = dt; q.c_dtype = dt; q.act = S2S_ACT_NONE; q.a_f32_rms = true; q.rms_eps = c.eps;
-            if ((rc = gemm_ex(st, q))) return rc;
-        } else {
-            if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
-            if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
-        }
-        void* kc = at(s.kc, l * cache_layer);
-        void* vc = at(s.vc, l * cache_layer);
-        if (T_len == 1 && pos0 && !kv_len_dev && fused_attn_step()) {
-            // decode step: head norms + RoPE + cache append + attention in ONE launch
-            AttnStepParams a{};
-            a.qkv = m->qkv; a.qkv_rs = nq;
-            a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
-            a.O = m->att; a.o_bs = (long)H * D;
-            a.qw = c.qk_norm ? TPF(m, p + "qnorm") : nullptr; a.kw = c.qk_norm ? TPF(m, p + "knorm") : nullptr; a.eps = c.eps;
-            a.cosT = s.cosT; a.sinT = s.sinT; a.pos = pos0;
-            a.B = B; a.H = H; a.Hkv = Hk; a.D = D; a.kv_cap = kv_cap; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
-            if ((rc = attn_step(st, a, dt))) return rc;
-        } else {
-            if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
-                                  c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
-            AttnRowsParams a{};
-            a.Q = m->qkv; a.q_bs = (long)T_len * nq; a.q_rs = nq;
-            a.K = kc; a.V = vc; a.kv_bs = (long)c.max_pos * Hk * D; a.kv_rs = (long)Hk * D;
-            a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
-            a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
-            a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
-            if ((rc = attn_rows(st, a, dt))) return rc;
-        }
-        if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
-        if (!fuse_norm && (rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
-        if (M <= 64) {   // decode: SwiGLU (and, on the bf16 path, the RMSNorm in front) fused into the weight-streaming GEMM
+        if ((rc = rmsnorm(st, x, TPF(m, p + "ln1"), m->h, M, hid, c.eps, dt))) return rc;
+        if ((rc = gemm(st, m->h, hid, TP(m, p + "qkv.w"), nullptr, nullptr, m->qkv, nq, M, nq, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
+        if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, kv_len_dev))) return rc;
+        if ((rc = gemm(st, m->att, H * D, TP(m, p + "o.w"), nullptr, x, x, hid, M, hid, H * D, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if ((rc = rmsnorm(st, x, TPF(m, p + "ln2"), m->h, M, hid, c.eps, dt))) return rc;
+        if (M <= 64) {   // decode rows: SwiGLU fused into the weight-streaming GEMM
             GemmArgs gg{};
             gg.A = m->h; gg.lda = hid; gg.W = TP(m, p + "gu.w"); gg.C = m->act; gg.ldc = c.ffn; gg.M = M; gg.N = c.ffn; gg.K = hid;
             gg.ab_dtype = dt; gg.c_dtype = dt; gg.act = S2S_ACT_NONE; gg.glu = true;
-            if (fuse_norm) { gg.A = x; gg.W = s.gu_n[l]; gg.a_f32_rms = true; gg.rms_eps = c.eps; }
             if ((rc = gemm_ex(st, gg))) return rc;
         } else {
             if ((rc = gemm(st, m->h, hid, TP(m, p + "gu.w"), nullptr, nullptr, m->gu, 2 * c.ffn, M, 2 * c.ffn, hid, dt, dt, S2S_ACT_NONE, false))) return rc;
             if ((rc = swiglu(st, m->gu, m->act, M, c.ffn, dt))) return rc;
         }
-        if ((rc = gemm(st, m->act, c.ffn, TP(m, p + "down.w"), nullptr, x, x, hid, M, hid, c.ffn, dt, S2S_F32, S2S_ACT_NONE, dt == S2S_BF16))) return rc;
+        if ((rc = gemm(st, m->act, c.ffn, TP(m, p + "down.w"), nullptr, x, x, hid, M, hid, c.ffn, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
     }
     return S2S_OK;
 }
@@ -407,7 +465,7 @@ static int talker_head(Tts* m, hipStream_t st, int B) {
     // x's hidden rows are consumed (hn); the pick writes the next talker input over them
     return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_dev,
                        m->min_dev, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
-                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, B, dt);
+                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, B, dt, m->dbg);
 }
 
 // run the code predictor for the current frame; the residual groups' embeddings accumulate into the next talker input (m->x)
@@ -418,25 +476,43 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
     for (int g = 0; g < G - 1; ++g) {
         const int T_len = g == 0 ? 2 : 1;     // prefill rows [normed talker hidden, embedding of code 0], then one row per group
         const int M = B * T_len;
+        const bool dec = dec_fusion_ok(m, m->pred, M);
         if (P != E) {
-            if ((rc = gemm(st, m->pin_t, E, TP(m, "pred.in_proj.w"), TPF(m, "pred.in_proj.b"), nullptr, m->xp, P, M, P, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+            if (dec) {   // in_proj starts the predictor's residual rows and emits their bf16 copy + sums of squares in its epilogue
+                DecGemm ip{};
+                ip.A = (const __hip_bfloat16*)m->pin_t; ip.lda = E; ip.W = (const __hip_bfloat16*)TP(m, "pred.in_proj.w"); ip.ldw = E; ip.bias = TPF(m, "pred.in_proj.b");
+                ip.M = M; ip.N = P; ip.K = E; ip.mode = 2; ip.x_overwrite = true; ip.X = m->xp; ip.ldx = P; ip.XB = (__hip_bfloat16*)m->xb; ip.ldxb = P;
+                ip.ss_out = m->ssA; ip.ss_stride = DEC_ROWS; ip.act = S2S_ACT_NONE;
+                if ((rc = gemm_dec(st, ip))) return rc;
+                m->ss_parts_A = dec_parts(P, dec_nf(ip));
+            } else {
+                if ((rc = gemm(st, m->pin_t, E, TP(m, "pred.in_proj.w"), TPF(m, "pred.in_proj.b"), nullptr, m->xp, P, M, P, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+            }
         } else {
             if ((rc = cast_f32(st, m->pin, m->xp, (long)M * E, S2S_F32))) return rc;
+            if (dec) {
+                if ((rc = rows_prep(st, m->xp, P, m->xb, P, m->ssA, M, P))) return rc;
+                m->ss_parts_A = 1;
+            }
         }
         // cached positions before this pass are a host constant: 0, then g + 1 (row g of the constant table)
-        if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, m->pos_p + (size_t)g * m->max_batch, g + 2, nullptr))) return rc;
-        // last row of every session (second row of the prefill pass) -> norm -> group head
-        if (!m->head_n.empty() && B <= 64) {      // bf16: pred.norm runs inside the head GEMM (row stride T_len * P picks the last row)
-            GemmArgs hg{};
-            hg.A = m->xp + (size_t)(T_len - 1) * P; hg.lda = (long)T_len * P; hg.W = m->head_n[g]; hg.C = m->logits; hg.ldc = CB;
-            hg.M = B; hg.N = CB; hg.K = P; hg.ab_dtype = dt; hg.c_dtype = S2S_F32; hg.act = S2S_ACT_NONE; hg.a_f32_rms = true; hg.rms_eps = c.eps;
-            if ((rc = gemm_ex(st, hg))) return rc;
+        const int* pos = m->pos_p + (size_t)g * m->max_batch;
+        if (dec) {
+            if ((rc = stack_forward_dec(m, st, m->pred, m->xp, B, T_len, pos, g + 2))) return rc;
+            // last row of every session -> pred.norm (folded into the head's columns, scale from the down-proj partials) -> group head
+            DecGemm hg{};
+            hg.A = (const __hip_bfloat16*)m->xb + (size_t)(T_len - 1) * P; hg.lda = (long)T_len * P; hg.W = (const __hip_bfloat16*)m->head_n[g]; hg.ldw = P;
+            hg.M = B; hg.N = CB; hg.K = P;
+            hg.ss_in = m->ssA + (T_len - 1); hg.ss_rs = T_len; hg.n_parts_in = m->ss_parts_A; hg.ss_stride = DEC_ROWS; hg.inv_dim = 1.0f / (float)P; hg.eps = c.eps;
+            hg.mode = 1; hg.C = m->logits; hg.ldc = CB; hg.act = S2S_ACT_NONE;
+            if ((rc = gemm_dec(st, hg))) return rc;
         } else {
+            if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, pos, g + 2, nullptr))) return rc;
             if ((rc = rmsnorm_ex(st, m->xp + (size_t)(T_len - 1) * P, (long)T_len * P, TPF(m, "pred.norm"), m->h, nullptr, B, P, c.eps, dt))) return rc;
             if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
         }
         if ((rc = pred_pick(st, m->logits, CB, m->frame_dev, m->finished, m->codes_out, c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)),
-                            m->x, m->pin, m->pin_t, E, B, dt))) return rc;
+                            m->x, m->pin, m->pin_t, E, B, dt, m->dbg))) return rc;
     }
     return S2S_OK;
 }
@@ -449,7 +525,13 @@ static int frame_body(Tts* m, hipStream_t st, int B) {
     if ((rc = talker_head(m, st, B))) return rc;
     if ((rc = predictor_frame(m, st, B))) return rc;
     // kv capacity is the (constant) cache length; the causal bound pos_t[b] + 1 limits the keys actually read
-    if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos, nullptr))) return rc;
+    if (dec_fusion_ok(m, m->talker, B)) {
+        if ((rc = rows_prep(st, m->x, m->cfg.t_hidden, m->xb, m->cfg.t_hidden, m->ssA, B, m->cfg.t_hidden))) return rc;
+        m->ss_parts_A = 1;
+        if ((rc = stack_forward_dec(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos))) return rc;
+    } else {
+        if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos, nullptr))) return rc;
+    }
     return tts_frame_end(st, m->pos_t, m->frame_dev, B);
 }
 
@@ -564,19 +646,17 @@ extern "C" int32_t s2s_tts_prefill(void* model, void* stream, const float* promp
 // produced by THIS call in codes_dev int32 [B][n_frames][G] (-1 after a session's end) and the total number of
 // valid frames so far per session in n_frames_dev.  min_total_frames: eos is suppressed until a session has that
 // many frames.  all_done_host (optional): set to 1 when every session has emitted eos.
-extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
-                                    int32_t* n_frames_dev, int32_t* all_done_host) {
-    Tts* m = (Tts*)model;
+static int32_t tts_generate_impl(Tts* m, hipStream_t st, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev, int32_t* n_frames_dev,
+                                 int32_t* all_done_host, bool allow_graph) {
     S2S_REQUIRE(m && m->finalized && m->cur_B > 0, "tts_generate: prefill first");
     const auto& c = m->cfg;
     S2S_REQUIRE(n_frames >= 1 && m->frames_done + n_frames <= c.max_frames, "tts_generate: frame budget %d exceeded", c.max_frames);
-    hipStream_t st = (hipStream_t)stream;
-    const int B = m->cur_B, E = c.t_hidden, G = c.n_groups;
+    const int B = m->cur_B, G = c.n_groups;
     int rc;
     const int f0 = m->frames_done;
     fill_int_kernel<<<1, 64, 0, st>>>(m->min_dev, min_total_frames, 1);
     S2S_LAUNCH_CHECK();
-    if (graphs_enabled() && !prof_active()) {
+    if (allow_graph && graphs_enabled() && !prof_active()) {
         hipGraphExec_t exec = nullptr;
         if ((rc = frame_graph(m, B, &exec))) return rc;
         for (int f = 0; f < n_frames; ++f) S2S_HIP_CHECK(hipGraphLaunch(exec, st));
@@ -597,6 +677,39 @@ extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames,
         *all_done_host = all;
     }
     return S2S_OK;
+}
+
+extern "C" int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
+                                    int32_t* n_frames_dev, int32_t* all_done_host) {
+    return tts_generate_impl((Tts*)model, (hipStream_t)stream, n_frames, min_total_frames, codes_dev, n_frames_dev, all_done_host, true);
+}
+
+// Teacher-forced continuation (in-context continuation of given codec frames; parity tests): like s2s_tts_generate, but every
+// code of the n_frames new frames whose entry in forced_codes_dev [B][n_frames][G] is >= 0 is emitted (and fed back) instead of
+// the greedy pick, and the raw logits of every pick are copied to logits_dev f32 [B][n_frames][G][vlog] (optional; group 0 rows
+// hold codec_vocab values, the others codebook values; vlog >= max of both).  Runs as plain stream launches (no graph replay).
+extern "C" int32_t s2s_tts_generate_forced(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, const int32_t* forced_codes_dev,
+                                           float* logits_dev, int32_t vlog, int32_t* codes_dev, int32_t* n_frames_dev) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && m->cur_B > 0, "tts_generate_forced: prefill first");
+    const auto& c = m->cfg;
+    S2S_REQUIRE(n_frames >= 1 && m->frames_done + n_frames <= c.max_frames, "tts_generate_forced: frame budget %d exceeded", c.max_frames);
+    S2S_REQUIRE(!logits_dev || vlog >= std::max(c.codec_vocab, c.codebook), "tts_generate_forced: vlog %d too small", vlog);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = m->cur_B, G = c.n_groups;
+    if (forced_codes_dev) {
+        if (!m->forced_buf) {
+            S2S_HIP_CHECK(hipMalloc((void**)&m->forced_buf, sizeof(int) * (size_t)m->max_batch * c.max_frames * G));
+            m->owned.push_back(m->forced_buf);
+        }
+        S2S_HIP_CHECK(hipMemsetAsync(m->forced_buf, 0xff, sizeof(int) * (size_t)m->max_batch * c.max_frames * G, st));
+        S2S_HIP_CHECK(hipMemcpy2DAsync(m->forced_buf + (size_t)m->frames_done * G, sizeof(int) * c.max_frames * G, forced_codes_dev, sizeof(int) * n_frames * G,
+                                       sizeof(int) * n_frames * G, B, hipMemcpyDeviceToDevice, st));
+    }
+    m->dbg = PickDebug{forced_codes_dev ? m->forced_buf : nullptr, logits_dev, m->frames_done, n_frames, vlog};
+    const int32_t rc = tts_generate_impl(m, st, n_frames, min_total_frames, codes_dev, n_frames_dev, nullptr, false);
+    m->dbg = PickDebug{};
+    return rc;
 }
 
 // ---- codec decoder ----------------------------------------------------------------------------------------

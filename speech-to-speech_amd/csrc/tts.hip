@@ -162,6 +162,20 @@ int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* ou
 }
 
 // ---- fused greedy picks of the frame loop ----------------------------------------------------------------
+// Teacher forcing / logit capture (s2s_tts_generate_forced): the emitted code is replaced by forced[b][frame][g] when that is
+// >= 0, and the raw logits row is copied to log[b][frame - f0][g][0 .. V).  Both pointers are null on the serving path.
+__device__ __forceinline__ void pick_debug(const PickDebug& d, const float* __restrict__ row, int V, int b, int frame, int g, int max_frames, int G,
+                                           int& code) {
+    if (d.log && frame >= d.f0 && frame < d.f0 + d.n_log) {
+        float* dst = d.log + (((long)b * d.n_log + (frame - d.f0)) * G + g) * d.Vlog;
+        for (int i = threadIdx.x; i < V; i += blockDim.x) dst[i] = row[i];
+    }
+    if (d.forced) {
+        const int f = d.forced[((long)b * max_frames + frame) * G + g];
+        if (f >= 0) code = f;
+    }
+}
+
 // Talker pick (one block per session): code 0 = argmax over the codec vocabulary (specials suppressed; eos too while
 // frame < min_frames), eos / frame bookkeeping, then the inputs that depend on it:
 //   xnext[b] = talker_emb[code0] + pad_embed          (next talker input, residual-group embeddings are added later)
@@ -173,10 +187,12 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
                                                           int* __restrict__ code0, int* __restrict__ finished, int* __restrict__ n_frames,
                                                           int* __restrict__ codes_out, int max_frames, int G,
                                                           const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
-                                                          float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E) {
+                                                          float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E,
+                                                          PickDebug dbg) {
     const int b = blockIdx.x;
     const int frame = *frame_dev;
-    const int code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
+    int code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
+    pick_debug(dbg, logits + (long)b * V, V, b, frame, 0, max_frames, G, code);
     if (threadIdx.x == 0) {
         int f = finished[b];
         if (!f && code == eos) f = 1;
@@ -203,9 +219,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, const int* __restrict__ frame_dev,
                                                         const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
                                                         int G, int g, const T* __restrict__ emb, float* __restrict__ xnext,
-                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E) {
+                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E, PickDebug dbg) {
     const int b = blockIdx.x;
-    const int code = block_argmax_256(logits + (long)b * V, V, nullptr, nullptr);
+    int code = block_argmax_256(logits + (long)b * V, V, nullptr, nullptr);
+    pick_debug(dbg, logits + (long)b * V, V, b, *frame_dev, g, max_frames, G, code);
     if (threadIdx.x == 0) codes_out[((long)b * max_frames + *frame_dev) * G + g] = finished[b] ? -1 : code;
     const T* row = emb + (long)code * E;
     for (int i = threadIdx.x; i < E; i += 256) {
@@ -224,17 +241,17 @@ __global__ void tts_frame_end_kernel(int* pos_t, int* frame_dev, int B) {
 
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
-                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype) {
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg) {
     S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
-                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E)));
+                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E, dbg)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
 int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype) {
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg) {
     S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
-                                                       pin, (TT*)pin_t, E)));
+                                                       pin, (TT*)pin_t, E, dbg)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

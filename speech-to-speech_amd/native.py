@@ -70,6 +70,13 @@ _SIGNATURES = {
     "s2s_logmel_whisper": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
     "s2s_logmel_parakeet": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp],
     "s2s_op_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32],
+    "s2s_op_gemm_ex": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32],
+    "s2s_op_gemm_dec": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _vp, _i64,
+                        _vp, _i64, _vp, _i32, _i32],
+    "s2s_op_gemm_dec_parts": [_i32, _i32, _i32],
+    "s2s_op_rows_prep": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32],
+    "s2s_graph_bench_begin": [C.POINTER(_vp)],
+    "s2s_graph_bench_end": [_i32, _i32, C.POINTER(C.c_double)],
     "s2s_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_logmel_whisper_tm": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
@@ -100,6 +107,7 @@ _SIGNATURES = {
     "s2s_tts_workspace_bytes": [_vp],
     "s2s_tts_prefill": [_vp, _vp, _vp, _vp, _i32, _i32],
     "s2s_tts_generate": [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
+    "s2s_tts_generate_forced": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "s2s_codec_decode": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32],
     "s2s_codec_samples": [_vp, _i32],
     "s2s_codec_stream_reset": [_vp],

@@ -344,6 +344,21 @@ class TTSEngine:
                                                     native.ptr(nfr), C.byref(done) if check_done else None), "s2s_tts_generate")
         return codes, nfr, bool(done.value)
 
+    def generate_forced(self, forced_codes: torch.Tensor, min_total_frames: int = 0, want_logits: bool = True):
+        """Teacher-forced frames: forced_codes int32 [B][n][G] (entries < 0 keep the greedy pick).  -> (emitted codes int32
+        [B][n][G], logits float32 [B][n][G][V] with V = max(codec_vocab, codebook); group 0 rows hold codec_vocab values)."""
+        B, n, G = forced_codes.shape
+        assert B == self._B and G == self.dims.n_groups and forced_codes.dtype == torch.int32
+        forced = forced_codes.to(self.device).contiguous()
+        V = max(self.dims.codec_vocab, self.dims.codebook)
+        logits = torch.zeros((B, n, G, V), dtype=torch.float32, device=self.device) if want_logits else None
+        codes = torch.empty((B, n, G), dtype=torch.int32, device=self.device)
+        nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_generate_forced(self._h, native.stream_handle(), n, int(min_total_frames), native.ptr(forced), native.ptr(logits), V,
+                                                           native.ptr(codes), native.ptr(nfr)), "s2s_tts_generate_forced")
+        return codes, logits
+
     def codec_samples(self, F: int) -> int:
         return int(self._lib.s2s_codec_samples(self._h, F))
 

@@ -1,0 +1,232 @@
+"""GPU parity of the decode-path projections against float64 references (through the C ABI):
+
+* ``s2s_op_gemm_dec`` (csrc/gemm_dec.hip) - every mode the engines launch, at the benchmarked Qwen3-TTS-1.7B /
+  Whisper-large-v3 widths: RMS-scaled qkv (M=64, N=4096, K=2048), residual projections with bf16 copy + partial sums of
+  squares (N=2048, K=2048 / 6144), fused SwiGLU (N=6144, K=2048), f32 heads with bias / GELU, ragged M / N, every K
+  schedule (single stage K=1024, whole slice K=2048, pipelined K=3072 / 6144, ragged K=1280), nf = 1 / 2, M = 1 .. 128;
+* a whole norm-free layer chain (rows_prep -> qkv -> out-proj -> gate/up -> down) against the rmsnorm -> linear reference;
+* ``s2s_op_gemm_ex``: fused SwiGLU and in-place residual projections at (64, 6144, 2048) / (64, 2048, 6144), bf16 and the
+  exact-f32 policy (skinny kernel NF=2 / GLU variants);
+* run-to-run determinism (bit-identical outputs) of every variant.
+
+Tolerances: inputs are exact bf16 values, products are exact in f32, so the only error is f32 accumulation order
+(<= 2e-4 relative to the row's magnitude) plus, for bf16 outputs, one bf16 rounding (2^-8 relative).
+"""
+
+import ctypes as C
+
+import pytest
+import torch
+
+from speech_to_speech_amd import native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _f64(t):
+    return t.detach().cpu().to(torch.float64)
+
+
+def gemm_dec(A, W, M, N, K, *, bias=None, ss_in=None, n_parts=0, ss_stride=128, inv_dim=0.0, eps=0.0, mode=0, C_out=None, act=0, X=None, XB=None,
+             ss_out=None, glu=False, nf=0, stream=None):
+    lib = native.load()
+    st = native.stream_handle() if stream is None else stream
+    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), A.stride(0), native.ptr(W), W.stride(0), native.ptr(bias), M, N, K, native.ptr(ss_in), n_parts,
+                                     ss_stride, float(inv_dim), float(eps), mode, native.ptr(C_out), 0 if C_out is None else C_out.stride(0), act,
+                                     native.ptr(X), 0 if X is None else X.stride(0), native.ptr(XB), 0 if XB is None else XB.stride(0),
+                                     native.ptr(ss_out), 1 if glu else 0, nf), "s2s_op_gemm_dec")
+
+
+def _act(v, act):
+    if act == native.ACT_GELU:
+        return torch.nn.functional.gelu(v)
+    if act == native.ACT_SILU:
+        return torch.nn.functional.silu(v)
+    if act == native.ACT_RELU:
+        return torch.relu(v)
+    return v
+
+
+SHAPES = [  # M, N, K
+    (64, 4096, 2048), (64, 2048, 2048), (64, 2048, 6144), (64, 4096, 1024), (64, 1024, 3072), (37, 1000, 1280), (1, 3072, 2048),
+    (16, 2048, 1024), (128, 4096, 2048), (100, 1024, 2048), (64, 51866, 1280), (33, 1280, 5120),
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_dec_modes_match_float64(M, N, K, mode):
+    if N > 10000 and mode != 1:
+        pytest.skip("vocabulary-sized N only occurs as an f32 head")
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K + mode)
+    A = _bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    parts = 37
+    ss = (torch.rand(parts, 128, generator=g) * K / parts).to(DEV)
+    inv_dim, eps = 1.0 / K, 1e-6
+    rstd = torch.rsqrt(_f64(ss)[:, :M].sum(0) * inv_dim + eps)
+    ref = (_f64(A) @ _f64(W).T) * rstd[:, None] + _f64(bias)
+    for nf in (1, 2):
+        if M > 64 and nf == 2:
+            continue
+        if mode == 2:
+            X0 = torch.randn(M, N, generator=g).to(DEV)
+            X = X0.clone()
+            XB = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            n_out = native.load().s2s_op_gemm_dec_parts(M, N, nf)
+            sso = torch.full((n_out, 128), -1.0, device=DEV)
+            gemm_dec(A, W, M, N, K, bias=bias, ss_in=ss, n_parts=parts, inv_dim=inv_dim, eps=eps, mode=2, X=X, XB=XB, ss_out=sso, nf=nf)
+            want = ref + _f64(X0)
+            scale = want.abs().max().item()
+            err = (_f64(X) - want).abs().max().item()
+            assert err <= 3e-4 * scale, (nf, err, scale)
+            assert torch.equal(XB, X.to(torch.bfloat16))
+            got_ss = _f64(sso)[:, :M].sum(0)
+            want_ss = (_f64(X) ** 2).sum(1)
+            assert (got_ss - want_ss).abs().max().item() <= 1e-4 * want_ss.max().item()
+            assert n_out == (N + 16 * nf - 1) // (16 * nf) * nf
+            # overwrite flavour (projections that start a residual stream)
+            X2 = torch.full((M, N), 123.0, device=DEV)
+            lib = native.load()
+            # x_overwrite is not exposed on the op (engine-internal); emulate: X = 0 first
+            X2.zero_()
+            gemm_dec(A, W, M, N, K, bias=bias, ss_in=ss, n_parts=parts, inv_dim=inv_dim, eps=eps, mode=2, X=X2, nf=nf)
+            assert (_f64(X2) - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+        else:
+            for act in (native.ACT_NONE, native.ACT_GELU):
+                out = torch.zeros(M, N, dtype=torch.bfloat16 if mode == 0 else torch.float32, device=DEV)
+                gemm_dec(A, W, M, N, K, bias=bias, ss_in=ss, n_parts=parts, inv_dim=inv_dim, eps=eps, mode=mode, C_out=out, act=act, nf=nf)
+                want = _act(ref, act)
+                scale = want.abs().max().item()
+                tol = (3e-4 if mode == 1 else 5e-3) * scale
+                err = (_f64(out) - want).abs().max().item()
+                assert err <= tol, (nf, act, err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 6144, 2048), (64, 3072, 1024), (20, 6144, 2048), (128, 6144, 2048), (7, 1000, 1280)])
+def test_gemm_dec_swiglu_matches_float64(M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(N + K + M)
+    A = _bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = _bf(torch.randn(2 * N, K, generator=g) * K ** -0.5).to(DEV)
+    parts = 128
+    ss = (torch.rand(parts, 128, generator=g) * K / parts).to(DEV)
+    rstd = torch.rsqrt(_f64(ss)[:, :M].sum(0) / K + 1e-6)
+    gate = (_f64(A) @ _f64(W[:N]).T) * rstd[:, None]
+    up = (_f64(A) @ _f64(W[N:]).T) * rstd[:, None]
+    want = torch.nn.functional.silu(gate) * up
+    for nf in (1, 2):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        gemm_dec(A, W, M, N, K, ss_in=ss, n_parts=parts, inv_dim=1.0 / K, eps=1e-6, mode=0, C_out=out, glu=True, nf=nf)
+        err = (_f64(out) - want).abs().max().item()
+        assert err <= 6e-3 * want.abs().max().item(), (nf, err)
+    # without the RMS prologue
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    gemm_dec(A, W, M, N, K, mode=0, C_out=out, glu=True)
+    want = torch.nn.functional.silu(_f64(A) @ _f64(W[:N]).T) * (_f64(A) @ _f64(W[N:]).T)
+    assert (_f64(out) - want).abs().max().item() <= 6e-3 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("M,hid,ffn,heads_dim", [(64, 2048, 6144, 2048), (48, 1024, 3072, 2048), (128, 2048, 6144, 2048)])
+def test_norm_free_layer_chain_matches_rmsnorm_linear_reference(M, hid, ffn, heads_dim):
+    """rows_prep -> qkv(RMS) -> [identity attention] -> out-proj(resid) -> gate/up(RMS, SwiGLU) -> down(resid) vs the float64
+    rmsnorm -> linear -> ... chain on the same bf16 weights (the folded matrices are W * gamma rounded to bf16)."""
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(hid + M)
+    x0 = torch.randn(M, hid, generator=g)
+    g1 = 1.0 + 0.1 * torch.randn(hid, generator=g)
+    g2 = 1.0 + 0.1 * torch.randn(hid, generator=g)
+    Wq = _bf(torch.randn(heads_dim, hid, generator=g) * hid ** -0.5)
+    Wo = _bf(torch.randn(hid, heads_dim, generator=g) * heads_dim ** -0.5)
+    Wgu = _bf(torch.randn(2 * ffn, hid, generator=g) * hid ** -0.5)
+    Wd = _bf(torch.randn(hid, ffn, generator=g) * ffn ** -0.5)
+    Wq_n, Wgu_n = _bf(Wq.float() * g1), _bf(Wgu.float() * g2)
+    eps = 1e-6
+
+    def rms(v, w):
+        return v * torch.rsqrt((v ** 2).mean(-1, keepdim=True) + eps) * w
+
+    # float64 reference with the engine's rounding points (bf16 activations between projections)
+    x = x0.double()
+    q = _bf((_bf(x.float()).double() @ _f64(Wq_n).T * torch.rsqrt((x ** 2).mean(-1, keepdim=True) + eps)).float()).double()
+    x = x + q @ _f64(Wo).T
+    gu = _bf(x.float()).double() @ _f64(Wgu_n).T * torch.rsqrt((x ** 2).mean(-1, keepdim=True) + eps)
+    act = _bf((torch.nn.functional.silu(gu[:, :ffn]) * gu[:, ffn:]).float()).double()
+    x_ref = x + act @ _f64(Wd).T
+    # and the textbook chain (norm weight applied to the activations): the fold changes only bf16 rounding
+    xt = x0.double()
+    qt = _bf(rms(xt, g1.double()).float()).double() @ _f64(Wq).T
+    xt = xt + _bf(qt.float()).double() @ _f64(Wo).T
+    gut = _bf(rms(xt, g2.double()).float()).double() @ _f64(Wgu).T
+    xt = xt + _bf((torch.nn.functional.silu(gut[:, :ffn]) * gut[:, ffn:]).float()).double() @ _f64(Wd).T
+
+    X = x0.clone().to(DEV)
+    XB = torch.zeros(M, hid, dtype=torch.bfloat16, device=DEV)
+    ssA = torch.zeros(256, 128, device=DEV)
+    ssB = torch.zeros(256, 128, device=DEV)
+    native.check(lib.s2s_op_rows_prep(native.stream_handle(), native.ptr(X), hid, native.ptr(XB), hid, native.ptr(ssA), M, hid), "rows_prep")
+    qkv = torch.zeros(M, heads_dim, dtype=torch.bfloat16, device=DEV)
+    gemm_dec(XB, Wq_n.to(DEV), M, heads_dim, hid, ss_in=ssA, n_parts=1, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv)
+    gemm_dec(qkv, Wo.to(DEV), M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB)
+    parts_o = lib.s2s_op_gemm_dec_parts(M, hid, 0)
+    a = torch.zeros(M, ffn, dtype=torch.bfloat16, device=DEV)
+    gemm_dec(XB, Wgu_n.to(DEV), M, ffn, hid, ss_in=ssB, n_parts=parts_o, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True)
+    gemm_dec(a, Wd.to(DEV), M, hid, ffn, mode=2, X=X, XB=XB, ss_out=ssA)
+    err = (_f64(X) - x_ref).abs().max().item()
+    err_t = (_f64(X) - xt).abs().max().item()
+    scale = x_ref.abs().max().item()
+    print(f"layer chain M={M} hid={hid}: max|err| vs same-rounding reference {err:.3e}, vs textbook chain {err_t:.3e} (|x| max {scale:.2f})")
+    assert err <= 2e-2 * scale          # a bf16 rounding of an intermediate can flip by one ulp: ~2^-8 relative, propagated
+    assert err_t <= 4e-2 * scale
+
+
+def test_gemm_dec_is_deterministic():
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 64, 2048, 6144
+    A = _bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    outs = []
+    for _ in range(3):
+        X = torch.ones(M, N, device=DEV)
+        sso = torch.zeros(256, 128, device=DEV)
+        gemm_dec(A, W, M, N, K, mode=2, X=X, ss_out=sso)
+        outs.append((X.clone(), sso.clone()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,flags", [(64, 6144, 2048, 1), (64, 2048, 6144, 2), (64, 2048, 2048, 2), (40, 3072, 1024, 1), (64, 1024, 3072, 2)])
+def test_gemm_ex_swiglu_and_residual_variants(M, N, K, flags, dtype):
+    """s2s_op_gemm_ex at the Qwen3-TTS-1.7B widths vs float64: fused SwiGLU (flag 1) and the in-place f32 residual
+    projection that used to take the split-K path (flag 2; split-K with f32 atomics was removed - the result must be
+    run-to-run identical).  bfloat16 rows are served by gemm_dec, float32 rows (the exact-f32 parity policy) by the
+    skinny kernel's NF=2 / fused-SwiGLU variants."""
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    A = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    rows = 2 * N if flags & 1 else N
+    W = (torch.randn(rows, K, generator=g) * K ** -0.5).to(dtype).to(DEV)
+    code = native.dtype_code(dtype)
+    rel_out = 6e-3 if dtype == torch.bfloat16 else 2e-5
+    if flags & 1:
+        out = torch.zeros(M, N, dtype=dtype, device=DEV)
+        native.check(lib.s2s_op_gemm_ex(native.stream_handle(), native.ptr(A), K, native.ptr(W), None, None, native.ptr(out), N, M, N, K,
+                                        code, code, 0, flags, 0.0), "gemm_ex")
+        want = torch.nn.functional.silu(_f64(A) @ _f64(W[:N]).T) * (_f64(A) @ _f64(W[N:]).T)
+        assert (_f64(out) - want).abs().max().item() <= rel_out * want.abs().max().item()
+    else:
+        res = torch.randn(M, N, generator=g).to(DEV)
+        outs = []
+        for _ in range(3):
+            X = res.clone()
+            native.check(lib.s2s_op_gemm_ex(native.stream_handle(), native.ptr(A), K, native.ptr(W), None, native.ptr(X), native.ptr(X), N, M, N, K,
+                                            code, native.S2S_F32, 0, flags, 0.0), "gemm_ex")
+            outs.append(X)
+        want = _f64(res) + _f64(A) @ _f64(W).T
+        assert (_f64(outs[0]) - want).abs().max().item() <= (3e-4 if dtype == torch.bfloat16 else 2e-5) * want.abs().max().item()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "residual GEMM is not run-to-run deterministic"

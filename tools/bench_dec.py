@@ -1,0 +1,149 @@
+"""Decode-path microbenchmarks INSIDE a captured hipGraph (development aid; not part of the graded bench).
+
+A python loop of ctypes launches is host-bound (>5 us per call), which hid the real per-kernel cost in round 1
+(tools/bench_ops.py).  Here every measured sequence is captured once (s2s_graph_bench_begin / _end) and replayed, so the
+numbers are device time per kernel including the in-graph kernel boundary.
+
+    python tools/bench_dec.py floor            trivial-kernel boundary cost inside a graph
+    python tools/bench_dec.py gemm             single decode GEMMs, weights cycled through > 256 MB (HBM, not MALL)
+    python tools/bench_dec.py layer [M]        norm-free decoder layer chains (talker 2048/6144 x 28, predictor 1024/3072 x 5 x 15)
+Set S2S_NO_GEMM_DEC=1 to time the r1 skinny kernel behind s2s_op_gemm_ex on the same shapes (`gemm` / `layer-old`).
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from speech_to_speech_amd import native
+
+lib = native.load()
+dev = "cuda:0"
+
+
+def graph_time(fn, warm=3, reps=20):
+    st = C.c_void_p()
+    native.check(lib.s2s_graph_bench_begin(C.byref(st)), "begin")
+    n = fn(st.value)
+    us = C.c_double()
+    native.check(lib.s2s_graph_bench_end(warm, reps, C.byref(us)), "end")
+    return us.value, n
+
+
+def dec(st, A, W, M, N, K, *, ss=None, parts=0, mode=0, Cb=None, X=None, XB=None, sso=None, glu=False, nf=0, bias=None):
+    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), A.stride(0), native.ptr(W), W.stride(0), native.ptr(bias), M, N, K, native.ptr(ss), parts, 128,
+                                     1.0 / K, 1e-6, mode, native.ptr(Cb), 0 if Cb is None else Cb.stride(0), 0, native.ptr(X), 0 if X is None else X.stride(0),
+                                     native.ptr(XB), 0 if XB is None else XB.stride(0), native.ptr(sso), 1 if glu else 0, nf), "gemm_dec")
+
+
+def floor():
+    x = torch.randn(4, 256, device=dev)
+    xb = torch.zeros(4, 256, dtype=torch.bfloat16, device=dev)
+    ss = torch.zeros(128, device=dev)
+
+    def fn(st):
+        for _ in range(200):
+            native.check(lib.s2s_op_rows_prep(st, native.ptr(x), 256, native.ptr(xb), 256, native.ptr(ss), 4, 256), "prep")
+        return 200
+
+    us, n = graph_time(fn)
+    print(f"trivial kernel (rows_prep 4x256) inside a graph: {us / n:.2f} us per launch")
+
+
+def gemm_shapes(M):
+    return [("t.qkv", M, 4096, 2048, 0, False), ("t.o", M, 2048, 2048, 2, False), ("t.gu", M, 6144, 2048, 0, True), ("t.down", M, 2048, 6144, 2, False),
+            ("p.qkv", M, 4096, 1024, 0, False), ("p.o", M, 1024, 2048, 2, False), ("p.gu", M, 3072, 1024, 0, True), ("p.down", M, 1024, 3072, 2, False),
+            ("t.head", M, 3072, 2048, 1, False), ("p.head", M, 2048, 1024, 1, False), ("w.qkv", M, 3840, 1280, 0, False), ("w.fc1", M, 5120, 1280, 0, False),
+            ("w.fc2", M, 1280, 5120, 2, False), ("w.logits", M, 51866, 1280, 1, False)]
+
+
+def gemm(M=64):
+    old = os.environ.get("S2S_NO_GEMM_DEC") is not None
+    for name, M_, N, K, mode, glu in gemm_shapes(M):
+        rows = 2 * N if glu else N
+        wbytes = rows * K * 2
+        nbuf = max(2, min(64, int(400e6 // wbytes) + 1))
+        Ws = [(torch.randn(rows, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(nbuf)]
+        A = torch.randn(M_, K, device=dev).to(torch.bfloat16)
+        ss = torch.rand(128, 128, device=dev)
+        Cb = torch.zeros(M_, N, dtype=torch.bfloat16 if mode == 0 else torch.float32, device=dev)
+        X = torch.zeros(M_, N, device=dev)
+        XB = torch.zeros(M_, N, dtype=torch.bfloat16, device=dev)
+        sso = torch.zeros(256, 128, device=dev)
+        res = []
+        for nf in ((0,) if old else (1, 2)):
+            if M_ > 64 and nf == 2:
+                continue
+
+            def fn(st):
+                for W in Ws:
+                    if old:
+                        flags = 1 if glu else 0
+                        native.check(lib.s2s_op_gemm_ex(st, native.ptr(A), K, native.ptr(W), None, native.ptr(X) if mode == 2 else None,
+                                                        native.ptr(X) if mode == 2 else native.ptr(Cb), N, M_, N, K, native.S2S_BF16,
+                                                        native.S2S_F32 if mode else native.S2S_BF16, 0, flags, 0.0), "gemm_ex")
+                    elif mode == 2:
+                        dec(st, A, W, M_, N, K, mode=2, X=X, XB=XB, sso=sso, nf=nf)
+                    else:
+                        dec(st, A, W, M_, N, K, ss=ss, parts=128, mode=mode, Cb=Cb, glu=glu, nf=nf)
+                return len(Ws)
+
+            us, n = graph_time(fn)
+            res.append(f"nf={nf}: {us / n:6.2f} us {wbytes / (us / n * 1e-6) / 1e12:5.2f} TB/s")
+        print(f"{name:9s} M={M_:3d} N={N:6d} K={K:5d} {wbytes / 1e6:6.1f} MB x{nbuf:2d}  " + "   ".join(res))
+
+
+def layer(M=64, old=False):
+    for tag, hid, ffn, nq, hd, L, steps in (("talker", 2048, 6144, 4096, 2048, 28, 1), ("predictor", 1024, 3072, 4096, 2048, 5, 15)):
+        def w(r, c):
+            return (torch.randn(r, c, device=dev) * c ** -0.5).to(torch.bfloat16)
+
+        Wq = [w(nq, hid) for _ in range(L)]
+        Wo = [w(hid, hd) for _ in range(L)]
+        Wg = [w(2 * ffn, hid) for _ in range(L)]
+        Wd = [w(hid, ffn) for _ in range(L)]
+        X = torch.randn(M, hid, device=dev) * 0.1
+        XB = X.to(torch.bfloat16)
+        H = torch.zeros(M, hid, dtype=torch.bfloat16, device=dev)
+        g = torch.ones(hid, device=dev)
+        ssA = torch.ones(256, 128, device=dev)
+        ssB = torch.ones(256, 128, device=dev)
+        qkv = torch.zeros(M, nq, dtype=torch.bfloat16, device=dev)
+        act = torch.zeros(M, ffn, dtype=torch.bfloat16, device=dev)
+        parts = lib.s2s_op_gemm_dec_parts(M, hid, 0)
+
+        def fn(st):
+            for _ in range(steps):
+                for l in range(L):
+                    if old:
+                        native.check(lib.s2s_op_rmsnorm(st, native.ptr(X), native.ptr(g), native.ptr(H), M, hid, 1e-6, native.S2S_BF16), "norm")
+                        native.check(lib.s2s_op_gemm_ex(st, native.ptr(H), hid, native.ptr(Wq[l]), None, None, native.ptr(qkv), nq, M, nq, hid, 1, 1, 0, 0, 0.0), "q")
+                        native.check(lib.s2s_op_gemm_ex(st, native.ptr(qkv), nq, native.ptr(Wo[l]), None, native.ptr(X), native.ptr(X), hid, M, hid, hd, 1, 0, 0, 0, 0.0), "o")
+                        native.check(lib.s2s_op_rmsnorm(st, native.ptr(X), native.ptr(g), native.ptr(H), M, hid, 1e-6, native.S2S_BF16), "norm")
+                        native.check(lib.s2s_op_gemm_ex(st, native.ptr(H), hid, native.ptr(Wg[l]), None, None, native.ptr(act), ffn, M, ffn, hid, 1, 1, 0, 1, 0.0), "g")
+                        native.check(lib.s2s_op_gemm_ex(st, native.ptr(act), ffn, native.ptr(Wd[l]), None, native.ptr(X), native.ptr(X), hid, M, hid, ffn, 1, 0, 0, 0, 0.0), "d")
+                    else:
+                        dec(st, XB, Wq[l], M, nq, hid, ss=ssA, parts=parts, mode=0, Cb=qkv)
+                        dec(st, qkv, Wo[l], M, hid, hd, mode=2, X=X, XB=XB, sso=ssB)
+                        dec(st, XB, Wg[l], M, ffn, hid, ss=ssB, parts=parts, mode=0, Cb=act, glu=True)
+                        dec(st, act, Wd[l], M, hid, ffn, mode=2, X=X, XB=XB, sso=ssA)
+            return steps * L
+
+        us, n = graph_time(fn, warm=2, reps=10)
+        wb = (nq * hid + hid * hd + 2 * ffn * hid + hid * ffn) * 2
+        print(f"{tag:9s} layer chain M={M} ({'r1: 2 norms + 4 skinny GEMMs' if old else '4 gemm_dec, no norms'}; attention not included): {us / n:7.2f} us per layer, "
+              f"{wb / 1e6:.1f} MB weights -> {wb / (us / n * 1e-6) / 1e12:.2f} TB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    if which in ("all", "floor"):
+        floor()
+    if which in ("all", "gemm"):
+        gemm(M)
+    if which in ("all", "layer"):
+        layer(M, old=False)
+    if which in ("layer-old",):
+        layer(M, old=True)
