@@ -137,7 +137,11 @@ int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, 
 /* One decode-step projection of the norm-free decoder layer (csrc/gemm_dec.hip; bf16, M <= 128 sessions, K >= 256, K % 32 == 0):
  *   acc = A[M,K] @ W[N,K]^T;  out = rstd[m] * acc + bias  with rstd[m] = rsqrt(sum_p ss_in[p*ss_stride + m] * inv_dim + eps)
  *   when ss_in != NULL (RMSNorm of the raw rows A, its weight pre-folded into W's columns), else out = acc + bias.
- *   mode 0: C bf16 = act(out)   (glu != 0: W = [gate | up] rows, C = silu(out_gate) * out_up)
+ *   W is FRAGMENT-MAJOR (s2s_op_to_frag): one contiguous 1 KiB block per (16-row tile, 32-wide k-step) in MFMA operand
+ *   order, so that every wave load is one coalesced request; glu != 0: [gate tiles | up tiles], N rows each (N % 16 == 0).
+ *   layout bit 0: A is fragment-major too (else row-major [M][lda]); bit 1: mode-0 C is written fragment-major (row width
+ *   ldc); bit 2: mode-2 XB is written fragment-major (row width ldxb).
+ *   mode 0: C bf16 = act(out)   (glu != 0: C = silu(out_gate) * out_up)
  *   mode 1: C f32  = act(out)
  *   mode 2: X f32 [M][ldx] += out in place; XB (optional) = bf16 copy of the new rows; ss_out (optional)
  *           [s2s_op_gemm_dec_parts(M,N,nf)][ss_stride] = per-column-slab partial sums of squares of the new rows
@@ -148,10 +152,14 @@ int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, 
 int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
                         int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
                         void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
-                        int32_t nf);
+                        int32_t nf, int32_t layout);
 int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t nf);
-/* xb = bf16(x) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
-int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols);
+/* xb = bf16(x) (frag != 0: fragment-major [rows][cols]) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
+int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
+                         int32_t frag);
+/* row-major bf16 [rows][K] (row stride ld) -> fragment-major copy (roundup(rows,16) * K elements, zero padding rows);
+ * gamma (optional f32 [K]) is folded into the columns (out = W * gamma rounded once to bf16). */
+int32_t s2s_op_to_frag(void* stream, const void* W, int64_t ld, const float* gamma, void* out, int32_t rows, int32_t K);
 
 /* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
  * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */

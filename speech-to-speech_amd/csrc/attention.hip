@@ -446,8 +446,16 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
     }
     __syncthreads();
     T* o = (T*)p.O + (long)b * p.o_bs + (long)h * D;
-    for (int d = tid; d < D; d += 256)
-        Elem<T>::st(o + d, (((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) + pn * sv[d]) * inv);
+    const int ksteps = (p.H * D) >> 5;
+    for (int d = tid; d < D; d += 256) {
+        const float v = (((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) + pn * sv[d]) * inv;
+        if (p.o_frag) {   // fragment-major rows for the out-projection (gemm_dec.hip operand layout): row b, column h*D + d
+            const int k = h * D + d;
+            Elem<T>::st((T*)p.O + ((((long)(b >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (b & 15)) * 8 + (k & 7), v);
+        } else {
+            Elem<T>::st(o + d, v);
+        }
+    }
 }
 
 template <typename T>

@@ -657,11 +657,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     }
 }
 
-static bool dec_disabled() {
-    static const bool off = getenv("S2S_NO_GEMM_DEC") != nullptr;   // A/B switch: bf16 decode rows on the r1 skinny kernel
-    return off;
-}
-
 static bool tile3_disabled() {
     static const bool off = getenv("S2S_NO_TILE3") != nullptr;   // A/B switch for tools/bench_ops.py
     return off;
@@ -779,17 +774,6 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
         S2S_REQUIRE(g.ab_dtype == S2S_BF16 && g.M <= 64 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && g.rms_eps > 0.f &&
                         g.residual == nullptr,
                     "gemm: the RMSNorm-fused path is a bf16 decode (M <= 64) feature over plain f32 rows");
-    // bf16 decode rows (one per live session): the pipelined weight-streaming kernel of gemm_dec.hip
-    if (g.ab_dtype == S2S_BF16 && g.M <= 128 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && !g.alpha_set && !g.a_f32_rms &&
-        g.K >= 256 && g.K % 32 == 0 && (g.ldw == 0 || g.ldw % 8 == 0) && (g.residual == nullptr || (g.residual == (const float*)g.C && g.c_dtype == S2S_F32 &&
-        (g.ldr == 0 || g.ldr == g.ldc))) && (!g.glu || (g.c_dtype == S2S_BF16 && !g.bias && g.act == S2S_ACT_NONE)) && !dec_disabled()) {
-        DecGemm a{};
-        a.A = (const __hip_bfloat16*)g.A; a.lda = g.lda; a.W = (const __hip_bfloat16*)g.W; a.ldw = g.ldw > 0 ? g.ldw : g.K; a.bias = g.bias;
-        a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act; a.glu = g.glu;
-        if (g.residual) { a.mode = 2; a.X = (float*)g.C; a.ldx = g.ldc; }
-        else { a.mode = g.c_dtype == S2S_BF16 ? 0 : 1; a.C = g.C; a.ldc = g.ldc; }
-        return gemm_dec(st, a);
-    }
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_BF16) return launch_gemm<__hip_bfloat16, __hip_bfloat16>(st, g);
     if (g.ab_dtype == S2S_BF16 && g.c_dtype == S2S_F32) return launch_gemm<__hip_bfloat16, float>(st, g);
     if (g.ab_dtype == S2S_F32 && g.c_dtype == S2S_F32) return launch_gemm<float, float>(st, g);

@@ -7,6 +7,16 @@
 // and scales its accumulators by rsqrt(mean(x^2) + eps) in the epilogue (the partials are summed in a fixed order:
 // deterministic, no atomics).
 //
+// Operand layout ("fragment-major"): a fragment-shaped load from a row-major matrix makes every 16-lane quad touch 16
+// different rows - 16 tag look-ups per quad instead of 2 - and the texture-address unit, not HBM, bounds the kernel
+// (measured in round 2: 12.7 us for the 16.8 MB qkv projection, = 64 cycles x 5 loads x 8 steps x 8 waves per CU).
+// Decode weights are therefore stored pre-swizzled, one contiguous 1 KiB block per (16-row tile, 32-wide k-step) in
+// exactly the MFMA operand order [k-chunk lg][row l15][8 elements]; a wave's whole K-slice of a tile is one contiguous
+// run (8 KiB at K = 2048) and every wave load is a single fully coalesced 1 KiB request with a wave-uniform (SGPR)
+// base address.  Activations that only ever feed these projections (the bf16 residual copy, the SwiGLU output, the
+// decode-attention output) are written in the same layout by their producers (a_frag / c_frag); row-major activations
+// are still accepted (template AF = false).
+//
 // Work split: one 8-wave workgroup owns 16*NF output columns over the whole of K; the waves split K, every weight
 // element is read exactly once straight from HBM into MFMA B fragments (non-temporal, 16 B per lane), the activation
 // fragments come from L2.  Loads are software-pipelined in two register stages of UC k-steps (32 k each), so a stage's
@@ -25,6 +35,18 @@ namespace {
 
 constexpr int DEC_NW = 8;            // waves per workgroup
 
+// element (row m, column k) of a fragment-major [rows][K] matrix with ksteps = K / 32
+__host__ __device__ __forceinline__ long frag_index(int m, int k, int ksteps) {
+    return ((((long)(m >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
+// a pointer the compiler must keep in SGPRs (wave-uniform by construction): loads become  saddr + 32-bit lane offset
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
@@ -32,7 +54,7 @@ __device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
 // MODE 0: C bf16 = act(rstd * acc + bias); GLU: C = silu(rstd*gate) * (rstd*up)
 // MODE 1: C f32  = act(rstd * acc + bias)
 // MODE 2: X f32 (in place) += rstd * acc + bias; XB = bf16(X); ss_out[slab][m] = sum over the slab's columns of X^2
-template <int MT, int NF, bool GLU, int MODE, int UC>
+template <int MT, int NF, bool GLU, int MODE, int UC, bool AF>
 __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     constexpr int NS = NF * (GLU ? 2 : 1);       // weight streams per wave
     constexpr int GRMAX = GLU ? 2 : 4;
@@ -49,18 +71,26 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     const int spw = (steps + DEC_NW - 1) / DEC_NW;
     const int s0 = wave * spw, s1 = min(steps, s0 + spw);
 
-    const __hip_bfloat16* wrow[NS];
+    // weights: tile (n / 16), step s -> 512-element block at ((tile * steps + s) * 512); lane l reads elements l*8 .. l*8+7
+    // of it.  Tiles past N re-read the last valid tile (finite garbage in columns that are never stored).
+    const int ntiles = (a.N + 15) >> 4;
+    const __hip_bfloat16* wtile[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        // columns past N / rows past M read the last valid row: finite garbage that is never stored, no divergent loads
-        const int n = min(n0 + (s % NF) * 16 + l15, a.N - 1);
-        wrow[s] = a.W + ((long)n + (s >= NF ? a.N : 0)) * a.ldw + lg * 8;
+        const int t = min((n0 >> 4) + (s % NF), ntiles - 1) + (s >= NF ? ntiles : 0);
+        wtile[s] = a.W + (long)t * steps * 512;
     }
+    // activations: fragment-major (same block structure over 16-row tiles) or row-major [M][lda]
+    const int mtiles = (a.M + 15) >> 4;
     const __hip_bfloat16* arow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = min(i * 16 + l15, a.M - 1);
-        arow[i] = a.A + (long)m * a.lda + lg * 8;
+        if constexpr (AF) {
+            arow[i] = a.A + (long)min(i, mtiles - 1) * steps * 512;
+        } else {
+            const int m = min(i * 16 + l15, a.M - 1);
+            arow[i] = a.A + (long)m * a.lda + lg * 8;
+        }
     }
     f32x4_t acc[MT][NS];
 #pragma unroll
@@ -80,20 +110,28 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
         const int kb = min(sb, kmax);
         kbase[st] = kb;
         sfrom[st] = sb;
-        const __hip_bfloat16* pw[NS];
-        const __hip_bfloat16* pa[MT];
+        const unsigned loff = lane * 16;                   // byte offset of this lane inside a 1 KiB fragment block
+        const char* wb[NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) pw[q] = wrow[q] + (long)kb * 32;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) pa[i] = arow[i] + (long)kb * 32;
+        for (int q = 0; q < NS; ++q) wb[q] = uniform_ptr(wtile[q] + (long)kb * 512);
 #pragma unroll
         for (int u = 0; u < UC; ++u)
 #pragma unroll
-            for (int q = 0; q < NS; ++q) fw[st][u][q] = ld_nt16(pw[q] + u * 32);
+            for (int q = 0; q < NS; ++q) fw[st][u][q] = ld_nt16(wb[q] + u * 1024 + loff);
+        if constexpr (AF) {
+            const char* ab[MT];
 #pragma unroll
-        for (int u = 0; u < UC; ++u)
+            for (int i = 0; i < MT; ++i) ab[i] = uniform_ptr(arow[i] + (long)kb * 512);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[st][u][i] = *reinterpret_cast<const u32x4_t*>(pa[i] + u * 32);
+            for (int u = 0; u < UC; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[st][u][i] = *reinterpret_cast<const u32x4_t*>(ab[i] + u * 1024 + loff);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UC; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[st][u][i] = *reinterpret_cast<const u32x4_t*>(arow[i] + (long)(kb + u) * 32);
+        }
         __builtin_amdgcn_sched_barrier(0);      // the stage is issued HERE: the scheduler must not sink loads behind MFMAs
     };
     auto compute = [&](int st) {
@@ -236,7 +274,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
                     else if (a.act == S2S_ACT_RELU) v = fmaxf(v, 0.f);
                 }
                 if constexpr (MODE == 0) {
-                    if (ok) Elem<__hip_bfloat16>::st(reinterpret_cast<__hip_bfloat16*>(a.C) + (long)m * a.ldc + nn, v);
+                    if (ok) Elem<__hip_bfloat16>::st(reinterpret_cast<__hip_bfloat16*>(a.C) + (a.c_frag ? frag_index(m, nn, (int)(a.ldc >> 5)) : (long)m * a.ldc + nn), v);
                 } else if constexpr (MODE == 1) {
                     if (ok) reinterpret_cast<float*>(a.C)[(long)m * a.ldc + nn] = v;
                 } else {
@@ -245,7 +283,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
                         float* xp = a.X + (long)m * a.ldx + nn;
                         xn = a.x_overwrite ? v : *xp + v;
                         *xp = xn;
-                        if (a.XB) Elem<__hip_bfloat16>::st(a.XB + (long)m * a.ldxb + nn, xn);
+                        if (a.XB) Elem<__hip_bfloat16>::st(a.XB + (a.xb_frag ? frag_index(m, nn, (int)(a.ldxb >> 5)) : (long)m * a.ldxb + nn), xn);
                     }
                     if (a.ss_out) {
                         float q = xn * xn;
@@ -261,21 +299,25 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     }
 }
 
-template <int MT, int NF, bool GLU, int MODE>
-int launch_dec(hipStream_t st, const DecGemm& a) {
+template <int MT, int NF, bool GLU, int MODE, bool AF>
+int launch_dec2(hipStream_t st, const DecGemm& a) {
     constexpr int NS = NF * (GLU ? 2 : 1);
     // register budget: two stages of UC * (NS + MT) 16-byte fragments + MT * NS accumulators
     constexpr int FR = NS + MT;      // 16-byte fragments per k-step
-    constexpr int UC = FR <= 2 ? 8 : FR == 3 ? 6 : FR <= 5 ? 4 : FR == 6 ? 3 : FR <= 9 ? 2 : 1;
+    constexpr int UC = FR <= 2 ? 8 : FR == 3 ? 6 : FR <= 6 ? 4 : FR <= 9 ? 2 : 1;
     const int slabs = cdiv(a.N, 16 * NF);
-    gemm_dec_kernel<MT, NF, GLU, MODE, UC><<<slabs, DEC_NW * 64, 0, st>>>(a);
+    gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF><<<slabs, DEC_NW * 64, 0, st>>>(a);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
+}
+template <int MT, int NF, bool GLU, int MODE>
+int launch_dec(hipStream_t st, const DecGemm& a) {
+    return a.a_frag ? launch_dec2<MT, NF, GLU, MODE, true>(st, a) : launch_dec2<MT, NF, GLU, MODE, false>(st, a);
 }
 
 template <int MT>
 int launch_dec_mt(hipStream_t st, const DecGemm& a, int NF) {
-    constexpr bool NF2 = MT <= 4, NF2_GLU = MT <= 2;      // register budget (see launch_dec)
+    constexpr bool NF2 = MT <= 4, NF2_GLU = MT <= 2;      // register budget (see launch_dec2)
     if (a.glu) {
         if constexpr (NF2_GLU) { if (NF == 2) return launch_dec<MT, 2, true, 0>(st, a); }
         return launch_dec<MT, 1, true, 0>(st, a);
@@ -306,9 +348,10 @@ int dec_nf(const DecGemm& a) {
 
 int gemm_dec(hipStream_t st, const DecGemm& a) {
     S2S_REQUIRE(a.M >= 1 && a.M <= 128 && a.N > 0 && a.K > 0, "gemm_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
-    S2S_REQUIRE(a.K >= 256 && a.K % 32 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm_dec: K=%d must be >= 256 and a multiple of 32, lda/ldw multiples of 8", a.K);
+    S2S_REQUIRE(a.K >= 256 && a.K % 32 == 0 && (a.a_frag || a.lda % 8 == 0), "gemm_dec: K=%d must be >= 256 and a multiple of 32, lda a multiple of 8", a.K);
+    S2S_REQUIRE((!a.c_frag || (a.mode == 0 && a.ldc % 32 == 0)) && (!a.xb_frag || a.ldxb % 32 == 0), "gemm_dec: fragment-major outputs need a row width that is a multiple of 32");
     S2S_REQUIRE(a.A && a.W && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_dec: operands must be 16-byte aligned");
-    S2S_REQUIRE(!a.glu || (a.mode == 0 && !a.bias && a.act == S2S_ACT_NONE), "gemm_dec: SwiGLU output is bf16 without bias / activation");
+    S2S_REQUIRE(!a.glu || (a.mode == 0 && !a.bias && a.act == S2S_ACT_NONE && a.N % 16 == 0), "gemm_dec: SwiGLU output is bf16 without bias / activation, N a multiple of 16");
     S2S_REQUIRE(a.mode == 2 ? (a.X != nullptr) : (a.C != nullptr), "gemm_dec: null output");
     S2S_REQUIRE(!a.ss_in || (a.n_parts_in > 0 && a.ss_stride >= a.M && a.inv_dim > 0.f), "gemm_dec: bad RMS prologue arguments");
     const int NF = dec_nf(a);
@@ -321,9 +364,10 @@ int gemm_dec(hipStream_t st, const DecGemm& a) {
     return launch_dec_mt<8>(st, a, 1);
 }
 
-// rows of the f32 residual stream -> bf16 copy + one partial sum of squares per row (entry of a fused decode pass)
+// rows of the f32 residual stream -> bf16 copy (row-major or fragment-major) + one partial sum of squares per row (entry of
+// a norm-free decode pass)
 __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, long x_rs, __hip_bfloat16* __restrict__ xb, long xb_rs,
-                                                        float* __restrict__ ss, int rows, int cols) {
+                                                        float* __restrict__ ss, int rows, int cols, int frag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -334,16 +378,53 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict_
         s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         ushort4 p;
         p.x = f32_to_bf16_bits(v.x); p.y = f32_to_bf16_bits(v.y); p.z = f32_to_bf16_bits(v.z); p.w = f32_to_bf16_bits(v.w);
-        *reinterpret_cast<ushort4*>(xb + (long)row * xb_rs + c) = p;
+        *reinterpret_cast<ushort4*>(xb + (frag ? frag_index(row, c, cols >> 5) : (long)row * xb_rs + c)) = p;
     }
     s = wave_sum(s);
     if (lane == 0) ss[row] = s;
 }
 
-int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols) {
-    S2S_REQUIRE(cols % 4 == 0 && x_rs % 4 == 0 && xb_rs % 4 == 0, "rows_prep: cols=%d unsupported", cols);
+int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag) {
+    S2S_REQUIRE(cols % 4 == 0 && x_rs % 4 == 0 && xb_rs % 4 == 0 && (!frag || cols % 32 == 0), "rows_prep: cols=%d unsupported", cols);
     if (rows == 0) return S2S_OK;
-    rows_prep_kernel<<<cdiv(rows, 4), 256, 0, st>>>(x, x_rs, (__hip_bfloat16*)xb, xb_rs, ss, rows, cols);
+    rows_prep_kernel<<<cdiv(rows, 4), 256, 0, st>>>(x, x_rs, (__hip_bfloat16*)xb, xb_rs, ss, rows, cols, frag ? 1 : 0);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// row-major bf16 matrix [rows][K] (row stride ld) -> fragment-major copy, rows padded with zeros to a multiple of 16;
+// gamma (optional, [K]): fold a norm weight into the columns (out = W * gamma, rounded once to bf16)
+__global__ void to_frag_kernel(const __hip_bfloat16* __restrict__ W, long ld, const float* __restrict__ gamma, __hip_bfloat16* __restrict__ out, int rows,
+                               int rows_pad, int K) {
+    const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one 8-element chunk of the output
+    const long total = (long)rows_pad * K / 8;
+    if (chunk >= total) return;
+    const int ksteps = K >> 5;
+    const int l15 = (int)(chunk & 15), lg = (int)((chunk >> 4) & 3);
+    const long blk = chunk >> 6;
+    const int ks = (int)(blk % ksteps), tile = (int)(blk / ksteps);
+    const int r = tile * 16 + l15, k0 = ks * 32 + lg * 8;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = 0.f;
+        if (r < rows) {
+            f = Elem<__hip_bfloat16>::ld(W + (long)r * ld + k0 + e);
+            if (gamma) f *= gamma[k0 + e];
+        }
+        v[e] = f32_to_bf16_bits(f);
+    }
+    u32x4_t pk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pk[q] = (unsigned)v[2 * q] | ((unsigned)v[2 * q + 1] << 16);
+    *reinterpret_cast<u32x4_t*>(out + chunk * 8) = pk;
+}
+
+int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K) {
+    S2S_REQUIRE(K % 32 == 0 && rows > 0, "to_frag: K=%d must be a multiple of 32", K);
+    const int rows_pad = (rows + 15) / 16 * 16;
+    const long total = (long)rows_pad * K / 8;
+    to_frag_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const __hip_bfloat16*)W, ld, gamma, (__hip_bfloat16*)out, rows, rows_pad, K);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -354,7 +435,7 @@ int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, f
 extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
                                    int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
                                    void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
-                                   int32_t nf) {
+                                   int32_t nf, int32_t layout) {
     S2S_REQUIRE(mode >= 0 && mode <= 2 && nf >= 0 && nf <= 2, "op_gemm_dec: bad mode / nf");
     s2s::DecGemm a{};
     a.A = (const __hip_bfloat16*)A; a.lda = (long)lda; a.W = (const __hip_bfloat16*)W; a.ldw = (long)ldw; a.bias = bias;
@@ -363,6 +444,7 @@ extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, con
     a.mode = mode; a.C = C; a.ldc = (long)ldc; a.act = act;
     a.X = X; a.ldx = (long)ldx; a.XB = (__hip_bfloat16*)XB; a.ldxb = (long)ldxb; a.ss_out = ss_out;
     a.glu = glu != 0; a.nf = nf;
+    a.a_frag = (layout & 1) != 0; a.c_frag = (layout & 2) != 0; a.xb_frag = (layout & 4) != 0;
     return s2s::gemm_dec((hipStream_t)stream, a);
 }
 
@@ -373,6 +455,13 @@ extern "C" int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t nf) {
     return s2s::dec_parts(N, s2s::dec_nf(a));
 }
 
-extern "C" int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols) {
-    return s2s::rows_prep((hipStream_t)stream, x, (long)x_rs, xb, (long)xb_rs, ss, rows, cols);
+extern "C" int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
+                                    int32_t frag) {
+    return s2s::rows_prep((hipStream_t)stream, x, (long)x_rs, xb, (long)xb_rs, ss, rows, cols, frag != 0);
+}
+
+/* row-major bf16 [rows][K] -> the fragment-major layout s2s_op_gemm_dec reads (rows padded to a multiple of 16 with zeros;
+ * out holds roundup(rows, 16) * K elements); gamma (optional f32 [K]) is folded into the columns. */
+extern "C" int32_t s2s_op_to_frag(void* stream, const void* W, int64_t ld, const float* gamma, void* out, int32_t rows, int32_t K) {
+    return s2s::to_frag((hipStream_t)stream, W, (long)ld, gamma, out, rows, K);
 }

@@ -30,7 +30,9 @@ int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bi
 // Decode-step projection (gemm_dec.hip): bf16, M <= 128, K % 32 == 0.  See the file header for the norm-free layer scheme.
 struct DecGemm {
     const __hip_bfloat16* A; long lda;      // [M][lda]; raw (un-normalised) bf16 rows when ss_in is set
-    const __hip_bfloat16* W; long ldw;      // [N][ldw]; glu: [gate rows | up rows] (N each)
+    const __hip_bfloat16* W; long ldw;      // FRAGMENT-MAJOR weights (to_frag): [roundup(N,16)][K]; glu: [gate tiles | up tiles]; ldw unused
+    bool a_frag;                            // A is fragment-major (else row-major [M][lda])
+    bool c_frag, xb_frag;                   // mode 0 C / mode 2 XB written fragment-major (row width ldc / ldxb, multiple of 32)
     const float* bias;                      // [N] or nullptr
     int M, N, K;
     // RMS prologue: out = rsqrt(sum_p ss_in[p][m] * inv_dim + eps) * acc  (gamma folded into W's columns)
@@ -47,7 +49,8 @@ struct DecGemm {
 int gemm_dec(hipStream_t st, const DecGemm& a);
 int dec_nf(const DecGemm& a);
 int dec_parts(int N, int NF);               // partial sums gemm_dec writes per row for an N-column residual projection
-int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols);
+int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag);
+int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K);
 
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,
               int cols, float eps, int y_dtype);
@@ -92,6 +95,7 @@ struct AttnStepParams {
     const int* pos;                    // int32[B]: tokens already in the cache
     int B, H, Hkv, D, kv_cap, window;  // kv_cap: cache capacity (LDS sizing); window > 0: sliding window
     float scale;
+    bool o_frag;                       // write O as fragment-major rows [B][H*D] (operand layout of gemm_dec.hip)
 };
 int attn_step(hipStream_t st, const AttnStepParams& p, int dtype);
 int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype);

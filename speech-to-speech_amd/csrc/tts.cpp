@@ -27,9 +27,10 @@ int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dt
 int add_int(hipStream_t st, int* p, int v, int n);
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
-                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg);
-int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg);
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
+                const PickDebug& dbg);
+int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg);
 int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
 int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
@@ -60,7 +61,8 @@ struct Stack {
     const float *cosT = nullptr, *sinT = nullptr;
     // bf16 decode path: per layer, the projections that consume a normed input with the RMSNorm weight folded into their
     // columns (qkv <- ln1, gate/up <- ln2), so that the norm itself runs inside the GEMM (GemmArgs::a_f32_rms)
-    std::vector<void*> qkv_n, gu_n;
+    std::vector<void*> qkv_n, gu_n;         // fragment-major, norm weight folded in
+    std::vector<void*> o_f, down_f;          // fragment-major copies of the residual projections
 };
 
 struct Tts {
@@ -95,7 +97,8 @@ struct Tts {
     int *frame_dev = nullptr, *min_dev = nullptr;
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
-    std::vector<void*> head_n;         // code-predictor heads with pred.norm folded in (bf16 decode path)
+    std::vector<void*> head_n;         // code-predictor heads, fragment-major with pred.norm folded in (bf16 decode path)
+    void* in_proj_f = nullptr;         // fragment-major pred.in_proj.w
     // norm-free decode path (gemm_dec.hip): bf16 copy of the residual rows + two partial-sum-of-squares buffers
     void* xb = nullptr;                // [DEC_ROWS][max hidden] model dtype
     float *ssA = nullptr, *ssB = nullptr;   // [SS_PARTS][DEC_ROWS]
@@ -205,7 +208,8 @@ static int finalize(Tts* m) {
     // ---- workspace
     const size_t B = m->max_batch, e = m->esz;
     const size_t Tp = c.max_prompt, F = c.max_codec_frames;
-    auto stack_scratch_rows = std::max<size_t>(B * Tp, B * F);
+    // (at least DEC_ROWS rows: fragment-major decode activations are addressed in whole 16-row tiles)
+    auto stack_scratch_rows = std::max<size_t>(std::max<size_t>(B * Tp, B * F), DEC_ROWS);
     size_t wid_qkv = 0, wid_ffn = 0, wid_hid = 0, wid_att = 0;
     for (Stack* s : {&m->talker, &m->pred, &m->codec}) {
         wid_qkv = std::max<size_t>(wid_qkv, (size_t)(s->c.heads + 2 * s->c.kv_heads) * s->c.head_dim);
@@ -225,10 +229,10 @@ static int finalize(Tts* m) {
     T(B * 2 * P * 4);                          // 6 xp
     T(B * E * 4);                              // 7 hn
     T(B * E * e);                              // 8 hn_t
-    T(B * (size_t)std::max(c.codec_vocab, c.codebook) * 4);   // 9 logits
+    T(B * (size_t)std::max(c.codec_vocab, 2 * c.codebook) * 4);   // 9 logits (the predictor's 2-row prefill pass writes both rows' logits)
     T(B * E * 4);                              // 10 xnext
     T(B * 2 * E * 4);                          // 11 pin
-    T(B * 2 * E * e);                          // 12 pin_t
+    T(((B * 2 + 15) / 16 * 16) * E * e);       // 12 pin_t (whole 16-row tiles when fragment-major)
     T((9 * B + 16) * 4);                       // 13 ints
     T(B * (size_t)c.max_frames * G * 4);       // 14 codes_out
     T((size_t)c.codec_vocab);                  // 15 sup_mask
@@ -291,34 +295,41 @@ static int finalize(Tts* m) {
     if (c.dtype == S2S_BF16 && getenv("S2S_NO_DEC_FUSION") == nullptr && E % 32 == 0 && P % 32 == 0 && E >= 256 && P >= 256 && c.t_ffn % 32 == 0 &&
         c.p_ffn % 32 == 0 && c.t_ffn >= 256 && c.p_ffn >= 256 && (c.t_heads * c.t_head_dim) % 32 == 0 && (c.p_heads * c.p_head_dim) % 32 == 0 &&
         c.t_heads * c.t_head_dim >= 256 && c.p_heads * c.p_head_dim >= 256 && E / 16 <= SS_PARTS && P / 16 <= SS_PARTS) {
+        // (ffn / hidden multiples of 32 also make every 16-row tile of the fragment-major weight copies complete)
         // norm-free decode path: RMSNorm weights folded into the columns of the consuming projections (own copies; the
         // prefill path keeps the checkpoint's matrices)
         S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * std::max(E, P) * e));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * SS_PARTS * DEC_ROWS));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
         m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB);
+        S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * std::max(E, P) * e));   // padding rows of fragment tiles must stay finite
         int rc;
-        auto fold = [&](const std::string& wname, const std::string& gname, long rows, int K, void** out) -> int {
+        auto frag = [&](const std::string& wname, const char* gname, long rows, int K, void** out) -> int {
             void* buf = nullptr;
-            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)rows * K * e));
+            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)((rows + 15) / 16 * 16) * K * e));
             m->owned.push_back(buf);
             *out = buf;
-            return fold_norm_weight(nullptr, TP(m, wname), TPF(m, gname), buf, rows, K, c.dtype);
+            return to_frag(nullptr, TP(m, wname), K, gname ? TPF(m, gname) : nullptr, buf, (int)rows, K);
         };
         for (Stack* s : {&m->talker, &m->pred}) {
             const auto& sc = s->c;
             const long nq = (long)(sc.heads + 2 * sc.kv_heads) * sc.head_dim;
             s->qkv_n.assign(sc.layers, nullptr);
             s->gu_n.assign(sc.layers, nullptr);
+            s->o_f.assign(sc.layers, nullptr);
+            s->down_f.assign(sc.layers, nullptr);
             for (int l = 0; l < sc.layers; ++l) {
                 const std::string p = s->prefix + std::to_string(l) + ".";
-                if ((rc = fold(p + "qkv.w", p + "ln1", nq, sc.hidden, &s->qkv_n[l]))) return rc;
-                if ((rc = fold(p + "gu.w", p + "ln2", 2L * sc.ffn, sc.hidden, &s->gu_n[l]))) return rc;
+                if ((rc = frag(p + "qkv.w", (p + "ln1").c_str(), nq, sc.hidden, &s->qkv_n[l]))) return rc;
+                if ((rc = frag(p + "gu.w", (p + "ln2").c_str(), 2L * sc.ffn, sc.hidden, &s->gu_n[l]))) return rc;
+                if ((rc = frag(p + "o.w", nullptr, sc.hidden, sc.heads * sc.head_dim, &s->o_f[l]))) return rc;
+                if ((rc = frag(p + "down.w", nullptr, sc.hidden, sc.ffn, &s->down_f[l]))) return rc;
             }
         }
         m->head_n.assign(c.n_groups - 1, nullptr);
         for (int g = 0; g < c.n_groups - 1; ++g)
-            if ((rc = fold("pred.head." + std::to_string(g) + ".w", "pred.norm", c.codebook, c.p_hidden, &m->head_n[g]))) return rc;
+            if ((rc = frag("pred.head." + std::to_string(g) + ".w", "pred.norm", c.codebook, c.p_hidden, &m->head_n[g]))) return rc;
+        if (P != E && (rc = frag("pred.in_proj.w", nullptr, P, E, &m->in_proj_f))) return rc;
         S2S_HIP_CHECK(hipDeviceSynchronize());
     }
     m->finalized = true;
@@ -338,7 +349,8 @@ static bool dec_fusion_ok(const Tts* m, const Stack& s, int M) {
 }
 
 // attention of one stack pass (q/k head norms, RoPE, cache append, softmax(QK^T)V) from m->qkv into m->att
-static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T_len, const int* pos0, int kv_cap, const int* kv_len_dev) {
+static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T_len, const int* pos0, int kv_cap, const int* kv_len_dev,
+                           bool* o_frag = nullptr) {
     const auto& c = s.c;
     const int dt = m->cfg.dtype, e = m->esz;
     const int H = c.heads, Hk = c.kv_heads, D = c.head_dim;
@@ -357,8 +369,11 @@ static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T
         a.qw = c.qk_norm ? TPF(m, p + "qnorm") : nullptr; a.kw = c.qk_norm ? TPF(m, p + "knorm") : nullptr; a.eps = c.eps;
         a.cosT = s.cosT; a.sinT = s.sinT; a.pos = pos0;
         a.B = B; a.H = H; a.Hkv = Hk; a.D = D; a.kv_cap = kv_cap; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+        a.o_frag = o_frag != nullptr && (H * D) % 32 == 0;     // fragment-major output rows for the out-projection that follows
+        if (o_frag) *o_frag = a.o_frag;
         return attn_step(st, a, dt);
     }
+    if (o_frag) *o_frag = false;
     if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
                           c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
     AttnRowsParams a{};
@@ -381,25 +396,26 @@ static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, 
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
         DecGemm q{};
-        q.A = (const __hip_bfloat16*)m->xb; q.lda = hid; q.W = (const __hip_bfloat16*)s.qkv_n[l]; q.ldw = hid; q.M = M; q.N = nq; q.K = hid;
+        q.A = (const __hip_bfloat16*)m->xb; q.a_frag = true; q.W = (const __hip_bfloat16*)s.qkv_n[l]; q.M = M; q.N = nq; q.K = hid;
         q.ss_in = m->ssA; q.n_parts_in = m->ss_parts_A; q.ss_stride = DEC_ROWS; q.inv_dim = 1.0f / (float)hid; q.eps = c.eps;
         q.mode = 0; q.C = m->qkv; q.ldc = nq; q.act = S2S_ACT_NONE;
         if ((rc = gemm_dec(st, q))) return rc;
-        if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, nullptr))) return rc;
+        bool att_frag = false;
+        if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, nullptr, &att_frag))) return rc;
         DecGemm o{};
-        o.A = (const __hip_bfloat16*)m->att; o.lda = (long)H * D; o.W = (const __hip_bfloat16*)TP(m, p + "o.w"); o.ldw = (long)H * D;
-        o.M = M; o.N = hid; o.K = H * D; o.mode = 2; o.X = x; o.ldx = hid; o.XB = (__hip_bfloat16*)m->xb; o.ldxb = hid; o.ss_out = m->ssB;
+        o.A = (const __hip_bfloat16*)m->att; o.lda = (long)H * D; o.a_frag = att_frag; o.W = (const __hip_bfloat16*)s.o_f[l];
+        o.M = M; o.N = hid; o.K = H * D; o.mode = 2; o.X = x; o.ldx = hid; o.XB = (__hip_bfloat16*)m->xb; o.ldxb = hid; o.xb_frag = true; o.ss_out = m->ssB;
         o.ss_stride = DEC_ROWS; o.act = S2S_ACT_NONE;
         if ((rc = gemm_dec(st, o))) return rc;
         const int parts_o = dec_parts(hid, dec_nf(o));
         DecGemm g{};
-        g.A = (const __hip_bfloat16*)m->xb; g.lda = hid; g.W = (const __hip_bfloat16*)s.gu_n[l]; g.ldw = hid; g.M = M; g.N = c.ffn; g.K = hid;
+        g.A = (const __hip_bfloat16*)m->xb; g.a_frag = true; g.W = (const __hip_bfloat16*)s.gu_n[l]; g.M = M; g.N = c.ffn; g.K = hid;
         g.ss_in = m->ssB; g.n_parts_in = parts_o; g.ss_stride = DEC_ROWS; g.inv_dim = 1.0f / (float)hid; g.eps = c.eps;
-        g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.act = S2S_ACT_NONE; g.glu = true;
+        g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.c_frag = true; g.act = S2S_ACT_NONE; g.glu = true;
         if ((rc = gemm_dec(st, g))) return rc;
         DecGemm d{};
-        d.A = (const __hip_bfloat16*)m->act; d.lda = c.ffn; d.W = (const __hip_bfloat16*)TP(m, p + "down.w"); d.ldw = c.ffn;
-        d.M = M; d.N = hid; d.K = c.ffn; d.mode = 2; d.X = x; d.ldx = hid; d.XB = (__hip_bfloat16*)m->xb; d.ldxb = hid; d.ss_out = m->ssA;
+        d.A = (const __hip_bfloat16*)m->act; d.a_frag = true; d.W = (const __hip_bfloat16*)s.down_f[l];
+        d.M = M; d.N = hid; d.K = c.ffn; d.mode = 2; d.X = x; d.ldx = hid; d.XB = (__hip_bfloat16*)m->xb; d.ldxb = hid; d.xb_frag = true; d.ss_out = m->ssA;
         d.ss_stride = DEC_ROWS; d.act = S2S_ACT_NONE;
         if ((rc = gemm_dec(st, d))) return rc;
         m->ss_parts_A = dec_parts(hid, dec_nf(d));
@@ -465,7 +481,7 @@ static int talker_head(Tts* m, hipStream_t st, int B) {
     // x's hidden rows are consumed (hn); the pick writes the next talker input over them
     return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_dev,
                        m->min_dev, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
-                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, B, dt, m->dbg);
+                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg);
 }
 
 // run the code predictor for the current frame; the residual groups' embeddings accumulate into the next talker input (m->x)
@@ -480,8 +496,8 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         if (P != E) {
             if (dec) {   // in_proj starts the predictor's residual rows and emits their bf16 copy + sums of squares in its epilogue
                 DecGemm ip{};
-                ip.A = (const __hip_bfloat16*)m->pin_t; ip.lda = E; ip.W = (const __hip_bfloat16*)TP(m, "pred.in_proj.w"); ip.ldw = E; ip.bias = TPF(m, "pred.in_proj.b");
-                ip.M = M; ip.N = P; ip.K = E; ip.mode = 2; ip.x_overwrite = true; ip.X = m->xp; ip.ldx = P; ip.XB = (__hip_bfloat16*)m->xb; ip.ldxb = P;
+                ip.A = (const __hip_bfloat16*)m->pin_t; ip.a_frag = true; ip.W = (const __hip_bfloat16*)m->in_proj_f; ip.bias = TPF(m, "pred.in_proj.b");
+                ip.M = M; ip.N = P; ip.K = E; ip.mode = 2; ip.x_overwrite = true; ip.X = m->xp; ip.ldx = P; ip.XB = (__hip_bfloat16*)m->xb; ip.ldxb = P; ip.xb_frag = true;
                 ip.ss_out = m->ssA; ip.ss_stride = DEC_ROWS; ip.act = S2S_ACT_NONE;
                 if ((rc = gemm_dec(st, ip))) return rc;
                 m->ss_parts_A = dec_parts(P, dec_nf(ip));
@@ -491,7 +507,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         } else {
             if ((rc = cast_f32(st, m->pin, m->xp, (long)M * E, S2S_F32))) return rc;
             if (dec) {
-                if ((rc = rows_prep(st, m->xp, P, m->xb, P, m->ssA, M, P))) return rc;
+                if ((rc = rows_prep(st, m->xp, P, m->xb, P, m->ssA, M, P, true))) return rc;
                 m->ss_parts_A = 1;
             }
         }
@@ -499,11 +515,12 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         const int* pos = m->pos_p + (size_t)g * m->max_batch;
         if (dec) {
             if ((rc = stack_forward_dec(m, st, m->pred, m->xp, B, T_len, pos, g + 2))) return rc;
-            // last row of every session -> pred.norm (folded into the head's columns, scale from the down-proj partials) -> group head
+            // pred.norm (folded into the head's columns, scale from the down-proj partials) -> group head over all M rows; the
+            // pick reads the last row of every session (row b * T_len + T_len - 1)
             DecGemm hg{};
-            hg.A = (const __hip_bfloat16*)m->xb + (size_t)(T_len - 1) * P; hg.lda = (long)T_len * P; hg.W = (const __hip_bfloat16*)m->head_n[g]; hg.ldw = P;
-            hg.M = B; hg.N = CB; hg.K = P;
-            hg.ss_in = m->ssA + (T_len - 1); hg.ss_rs = T_len; hg.n_parts_in = m->ss_parts_A; hg.ss_stride = DEC_ROWS; hg.inv_dim = 1.0f / (float)P; hg.eps = c.eps;
+            hg.A = (const __hip_bfloat16*)m->xb; hg.a_frag = true; hg.W = (const __hip_bfloat16*)m->head_n[g];
+            hg.M = M; hg.N = CB; hg.K = P;
+            hg.ss_in = m->ssA; hg.n_parts_in = m->ss_parts_A; hg.ss_stride = DEC_ROWS; hg.inv_dim = 1.0f / (float)P; hg.eps = c.eps;
             hg.mode = 1; hg.C = m->logits; hg.ldc = CB; hg.act = S2S_ACT_NONE;
             if ((rc = gemm_dec(st, hg))) return rc;
         } else {
@@ -511,8 +528,10 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
             if ((rc = rmsnorm_ex(st, m->xp + (size_t)(T_len - 1) * P, (long)T_len * P, TPF(m, "pred.norm"), m->h, nullptr, B, P, c.eps, dt))) return rc;
             if ((rc = gemm(st, m->h, P, TP(m, "pred.head." + std::to_string(g) + ".w"), nullptr, nullptr, m->logits, CB, B, CB, P, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
         }
-        if ((rc = pred_pick(st, m->logits, CB, m->frame_dev, m->finished, m->codes_out, c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)),
-                            m->x, m->pin, m->pin_t, E, B, dt, m->dbg))) return rc;
+        // dec: logits hold all M rows (row b * T_len + T_len - 1 is session b's); the next pass's input row is written fragment-major
+        const bool next_dec = g + 1 < G - 1 && dec_fusion_ok(m, m->pred, B) && P != E;
+        if ((rc = pred_pick(st, dec ? m->logits + (size_t)(T_len - 1) * CB : m->logits, CB, dec ? (long)T_len * CB : (long)CB, m->frame_dev, m->finished, m->codes_out,
+                            c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)), m->x, m->pin, m->pin_t, E, next_dec, B, dt, m->dbg))) return rc;
     }
     return S2S_OK;
 }
@@ -526,7 +545,7 @@ static int frame_body(Tts* m, hipStream_t st, int B) {
     if ((rc = predictor_frame(m, st, B))) return rc;
     // kv capacity is the (constant) cache length; the causal bound pos_t[b] + 1 limits the keys actually read
     if (dec_fusion_ok(m, m->talker, B)) {
-        if ((rc = rows_prep(st, m->x, m->cfg.t_hidden, m->xb, m->cfg.t_hidden, m->ssA, B, m->cfg.t_hidden))) return rc;
+        if ((rc = rows_prep(st, m->x, m->cfg.t_hidden, m->xb, m->cfg.t_hidden, m->ssA, B, m->cfg.t_hidden, true))) return rc;
         m->ss_parts_A = 1;
         if ((rc = stack_forward_dec(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos))) return rc;
     } else {

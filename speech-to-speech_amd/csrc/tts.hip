@@ -161,6 +161,11 @@ int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* ou
     return S2S_OK;
 }
 
+// element (row m, column k) of a fragment-major [rows][K] activation matrix, ksteps = K / 32 (gemm_dec.hip operand layout)
+__device__ __forceinline__ long frag_index_d(int m, int k, int ksteps) {
+    return ((((long)(m >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
 // ---- fused greedy picks of the frame loop ----------------------------------------------------------------
 // Teacher forcing / logit capture (s2s_tts_generate_forced): the emitted code is replaced by forced[b][frame][g] when that is
 // >= 0, and the raw logits row is copied to log[b][frame - f0][g][0 .. V).  Both pointers are null on the serving path.
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
                                                           int* __restrict__ codes_out, int max_frames, int G,
                                                           const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
                                                           float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E,
-                                                          PickDebug dbg) {
+                                                          int pin_frag, PickDebug dbg) {
     const int b = blockIdx.x;
     const int frame = *frame_dev;
     int code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
@@ -208,28 +213,28 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
         xnext[(long)b * E + i] = e + Elem<T>::ld(pad + i);
         pin[((long)b * 2) * E + i] = h;
         pin[((long)b * 2 + 1) * E + i] = e;
-        Elem<T>::st(pin_t + ((long)b * 2) * E + i, h);
-        Elem<T>::st(pin_t + ((long)b * 2 + 1) * E + i, e);
+        Elem<T>::st(pin_t + (pin_frag ? frag_index_d(b * 2, i, E >> 5) : ((long)b * 2) * E + i), h);
+        Elem<T>::st(pin_t + (pin_frag ? frag_index_d(b * 2 + 1, i, E >> 5) : ((long)b * 2 + 1) * E + i), e);
     }
 }
 
 // Code-predictor pick for residual group g (one block per session): code = argmax, stored (or -1 once finished), and its
 // embedding row both accumulated into the next talker input and written as the predictor's next input row.
 template <typename T>
-__global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, const int* __restrict__ frame_dev,
+__global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, long logits_rs, const int* __restrict__ frame_dev,
                                                         const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
                                                         int G, int g, const T* __restrict__ emb, float* __restrict__ xnext,
-                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E, PickDebug dbg) {
+                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E, int pin_frag, PickDebug dbg) {
     const int b = blockIdx.x;
-    int code = block_argmax_256(logits + (long)b * V, V, nullptr, nullptr);
-    pick_debug(dbg, logits + (long)b * V, V, b, *frame_dev, g, max_frames, G, code);
+    int code = block_argmax_256(logits + (long)b * logits_rs, V, nullptr, nullptr);
+    pick_debug(dbg, logits + (long)b * logits_rs, V, b, *frame_dev, g, max_frames, G, code);
     if (threadIdx.x == 0) codes_out[((long)b * max_frames + *frame_dev) * G + g] = finished[b] ? -1 : code;
     const T* row = emb + (long)code * E;
     for (int i = threadIdx.x; i < E; i += 256) {
         const float e = Elem<T>::ld(row + i);
         xnext[(long)b * E + i] += e;
         pin[(long)b * E + i] = e;
-        Elem<T>::st(pin_t + (long)b * E + i, e);
+        Elem<T>::st(pin_t + (pin_frag ? frag_index_d(b, i, E >> 5) : (long)b * E + i), e);
     }
 }
 
@@ -241,17 +246,19 @@ __global__ void tts_frame_end_kernel(int* pos_t, int* frame_dev, int B) {
 
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
-                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg) {
+                const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
+                const PickDebug& dbg) {
     S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
-                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E, dbg)));
+                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E,
+                                                         pin_frag ? 1 : 0, dbg)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
-int pred_pick(hipStream_t st, const float* logits, int V, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, int B, int dtype, const PickDebug& dbg) {
-    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
-                                                       pin, (TT*)pin_t, E, dbg)));
+int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg) {
+    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, logits_rs, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
+                                                       pin, (TT*)pin_t, E, pin_frag ? 1 : 0, dbg)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

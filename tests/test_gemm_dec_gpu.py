@@ -32,14 +32,42 @@ def _f64(t):
     return t.detach().cpu().to(torch.float64)
 
 
+def to_frag(W, gamma=None):
+    """row-major bf16 [rows][K] on the GPU -> the fragment-major copy gemm_dec reads (through the library's own converter)."""
+    rows, K = W.shape
+    out = torch.zeros(((rows + 15) // 16 * 16) * K, dtype=torch.bfloat16, device=W.device)
+    native.check(native.load().s2s_op_to_frag(native.stream_handle(), native.ptr(W), W.stride(0), native.ptr(gamma), native.ptr(out), rows, K), "s2s_op_to_frag")
+    return out
+
+
+def frag_index(m, k, K):
+    """position of element (m, k) in a fragment-major [rows][K] matrix (csrc/gemm_dec.hip frag_index)."""
+    return ((((m >> 4) * (K >> 5) + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (m & 15)) * 8 + (k & 7)
+
+
+def from_frag(buf, rows, K):
+    m = torch.arange(rows)[:, None]
+    k = torch.arange(K)[None, :]
+    return buf.cpu()[frag_index(m, k, K)]
+
+
 def gemm_dec(A, W, M, N, K, *, bias=None, ss_in=None, n_parts=0, ss_stride=128, inv_dim=0.0, eps=0.0, mode=0, C_out=None, act=0, X=None, XB=None,
-             ss_out=None, glu=False, nf=0, stream=None):
+             ss_out=None, glu=False, nf=0, stream=None, a_frag=False, c_frag=False, xb_frag=False, ldc=None, ldxb=None, w_is_frag=False):
+    """A: row-major [M][K] (or a fragment-major buffer with a_frag); W: row-major bf16 [N (x2 glu)][K], converted here."""
     lib = native.load()
     st = native.stream_handle() if stream is None else stream
-    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), A.stride(0), native.ptr(W), W.stride(0), native.ptr(bias), M, N, K, native.ptr(ss_in), n_parts,
-                                     ss_stride, float(inv_dim), float(eps), mode, native.ptr(C_out), 0 if C_out is None else C_out.stride(0), act,
-                                     native.ptr(X), 0 if X is None else X.stride(0), native.ptr(XB), 0 if XB is None else XB.stride(0),
-                                     native.ptr(ss_out), 1 if glu else 0, nf), "s2s_op_gemm_dec")
+    Wf = W if w_is_frag else to_frag(W)
+    layout = (1 if a_frag else 0) | (2 if c_frag else 0) | (4 if xb_frag else 0)
+    lda = K if a_frag else A.stride(0)
+    if ldc is None:
+        ldc = 0 if C_out is None else (C_out.stride(0) if C_out.dim() == 2 else N)
+    if ldxb is None:
+        ldxb = 0 if XB is None else (XB.stride(0) if XB.dim() == 2 else N)
+    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), lda, native.ptr(Wf), K, native.ptr(bias), M, N, K, native.ptr(ss_in), n_parts,
+                                     ss_stride, float(inv_dim), float(eps), mode, native.ptr(C_out), ldc, act,
+                                     native.ptr(X), 0 if X is None else X.stride(0), native.ptr(XB), ldxb,
+                                     native.ptr(ss_out), 1 if glu else 0, nf, layout), "s2s_op_gemm_dec")
+    return Wf
 
 
 def _act(v, act):
@@ -109,7 +137,50 @@ def test_gemm_dec_modes_match_float64(M, N, K, mode):
                 assert err <= tol, (nf, act, err, scale)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 6144, 2048), (64, 3072, 1024), (20, 6144, 2048), (128, 6144, 2048), (7, 1000, 1280)])
+def test_to_frag_layout_and_gamma_fold():
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rows, K = 37, 320
+    W = _bf(torch.randn(rows, K, generator=g))
+    gamma = 1.0 + 0.1 * torch.randn(K, generator=g)
+    out = to_frag(W.to(DEV), gamma.to(DEV))
+    back = from_frag(out, 48, K)
+    assert torch.equal(back[:rows], _bf(W.float() * gamma))          # one rounding of the folded product
+    assert bool((back[rows:] == 0).all())                           # zero padding rows
+    assert torch.equal(from_frag(to_frag(W.to(DEV)), rows, K), W)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 4096, 2048), (64, 2048, 6144), (23, 1024, 3072), (128, 2048, 2048), (5, 4096, 1024)])
+def test_gemm_dec_fragment_major_activations(M, N, K):
+    """A read fragment-major (as the engines run it), C / XB written fragment-major, vs float64."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    Af = to_frag(A.to(DEV))                                           # activations use the same block structure over 16-row tiles
+    ref = _f64(A) @ _f64(W).T
+    Mp = (M + 15) // 16 * 16
+    Cf = torch.zeros(Mp * N, dtype=torch.bfloat16, device=DEV)
+    gemm_dec(Af, W, M, N, K, mode=0, C_out=Cf, a_frag=True, c_frag=True, ldc=N)
+    got = from_frag(Cf, M, N)
+    assert (_f64(got) - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+    X0 = torch.randn(M, N, generator=g)
+    X = X0.clone().to(DEV)
+    XBf = torch.zeros(Mp * N, dtype=torch.bfloat16, device=DEV)
+    n_out = native.load().s2s_op_gemm_dec_parts(M, N, 0)
+    sso = torch.zeros(n_out, 128, device=DEV)
+    gemm_dec(Af, W, M, N, K, mode=2, X=X, XB=XBf, ss_out=sso, a_frag=True, xb_frag=True, ldxb=N)
+    want = ref + _f64(X0)
+    assert (_f64(X) - want).abs().max().item() <= 3e-4 * want.abs().max().item()
+    assert torch.equal(from_frag(XBf, M, N), X.cpu().to(torch.bfloat16))
+    assert (_f64(sso)[:, :M].sum(0) - (_f64(X) ** 2).sum(1)).abs().max().item() <= 1e-4 * (_f64(X) ** 2).sum(1).max().item()
+    # rows_prep writing fragment-major
+    xb = torch.zeros(Mp * N, dtype=torch.bfloat16, device=DEV)
+    ss = torch.zeros(128, device=DEV)
+    native.check(native.load().s2s_op_rows_prep(native.stream_handle(), native.ptr(X), N, native.ptr(xb), N, native.ptr(ss), M, N, 1), "rows_prep")
+    assert torch.equal(from_frag(xb, M, N), X.cpu().to(torch.bfloat16))
+    assert (_f64(ss)[:M] - (_f64(X) ** 2).sum(1)).abs().max().item() <= 1e-4 * (_f64(X) ** 2).sum(1).max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 6144, 2048), (64, 3072, 1024), (20, 6144, 2048), (128, 6144, 2048), (7, 1008, 1280)])
 def test_gemm_dec_swiglu_matches_float64(M, N, K):
     g = torch.Generator(device="cpu").manual_seed(N + K + M)
     A = _bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -169,13 +240,15 @@ def test_norm_free_layer_chain_matches_rmsnorm_linear_reference(M, hid, ffn, hea
     XB = torch.zeros(M, hid, dtype=torch.bfloat16, device=DEV)
     ssA = torch.zeros(256, 128, device=DEV)
     ssB = torch.zeros(256, 128, device=DEV)
-    native.check(lib.s2s_op_rows_prep(native.stream_handle(), native.ptr(X), hid, native.ptr(XB), hid, native.ptr(ssA), M, hid), "rows_prep")
+    native.check(lib.s2s_op_rows_prep(native.stream_handle(), native.ptr(X), hid, native.ptr(XB), hid, native.ptr(ssA), M, hid, 0), "rows_prep")
     qkv = torch.zeros(M, heads_dim, dtype=torch.bfloat16, device=DEV)
-    gemm_dec(XB, Wq_n.to(DEV), M, heads_dim, hid, ss_in=ssA, n_parts=1, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv)
+    # the norm weight is folded by the library's converter (one rounding of W * gamma, like the reference above)
+    Wq_f, Wgu_f = to_frag(Wq.to(DEV), g1.to(DEV)), to_frag(Wgu.to(DEV), g2.to(DEV))
+    gemm_dec(XB, Wq_f, M, heads_dim, hid, ss_in=ssA, n_parts=1, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv, w_is_frag=True)
     gemm_dec(qkv, Wo.to(DEV), M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB)
     parts_o = lib.s2s_op_gemm_dec_parts(M, hid, 0)
     a = torch.zeros(M, ffn, dtype=torch.bfloat16, device=DEV)
-    gemm_dec(XB, Wgu_n.to(DEV), M, ffn, hid, ss_in=ssB, n_parts=parts_o, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True)
+    gemm_dec(XB, Wgu_f, M, ffn, hid, ss_in=ssB, n_parts=parts_o, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True, w_is_frag=True)
     gemm_dec(a, Wd.to(DEV), M, hid, ffn, mode=2, X=X, XB=XB, ss_out=ssA)
     err = (_f64(X) - x_ref).abs().max().item()
     err_t = (_f64(X) - xt).abs().max().item()
@@ -204,8 +277,7 @@ def test_gemm_dec_is_deterministic():
 def test_gemm_ex_swiglu_and_residual_variants(M, N, K, flags, dtype):
     """s2s_op_gemm_ex at the Qwen3-TTS-1.7B widths vs float64: fused SwiGLU (flag 1) and the in-place f32 residual
     projection that used to take the split-K path (flag 2; split-K with f32 atomics was removed - the result must be
-    run-to-run identical).  bfloat16 rows are served by gemm_dec, float32 rows (the exact-f32 parity policy) by the
-    skinny kernel's NF=2 / fused-SwiGLU variants."""
+    run-to-run identical).  Both dtypes run the skinny kernel's NF=2 / fused-SwiGLU variants (row-major weights)."""
     lib = native.load()
     g = torch.Generator(device="cpu").manual_seed(N + K)
     A = torch.randn(M, K, generator=g).to(dtype).to(DEV)

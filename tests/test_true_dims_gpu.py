@@ -28,7 +28,7 @@ from speech_to_speech_amd.synth_weights import (ParakeetDims, Qwen3TTSDims, Whis
 
 pytestmark = pytest.mark.gpu
 
-BF16_LOGIT_TOL = 0.12        # max |logit_engine - logit_oracle| allowed, as a fraction of the step's logit standard deviation
+BF16_LOGIT_TOL = 0.08        # max |logit_engine - logit_oracle| allowed, as a fraction of the step's logit standard deviation
 
 
 # ------------------------------------------------------------------------------------------------ Qwen3-TTS 1.7B widths
@@ -36,6 +36,11 @@ BF16_LOGIT_TOL = 0.12        # max |logit_engine - logit_oracle| allowed, as a f
 def tts_ref():
     dims = Qwen3TTSDims(t_layers=2, p_layers=2, c_layers=2)       # every width at the 1.7B value
     sd = qwen3_tts_state_dict(dims, seed=11)
+    # at 1536 decoder channels the unit-gain synthetic conv stack saturates the output clamp (|wav| mean 0.7, measured), which
+    # turns every sub-ulp difference into a +-1 flip; damp the decoder convolutions so the waveform sits inside [-1, 1]
+    for k in sd:
+        if k.startswith("code2wav.decoder.") and k.endswith("conv.weight") and sd[k].shape[0] > 1:
+            sd[k] = sd[k] * 0.8
     g = torch.Generator().manual_seed(5)
     prompts = [torch.randn(n, dims.t_hidden, generator=g) for n in (7, 4, 9, 6)]
     pad = torch.randn(dims.t_hidden, generator=g) * 0.5
@@ -111,7 +116,7 @@ def test_tts_bf16_teacher_forced_logits_at_true_widths(tts_ref, B):
         w = eng.codec_decode(codes[:2].to(torch.int32).to(eng.device).contiguous(), 0).cpu()
         d = (w - wav).abs()
         print(f"bf16 codec waveform at true widths: max_abs_err {d.max():.3e} mean_abs_err {d.mean():.3e} (|wav| mean {wav.abs().mean():.3f})")
-        assert d.max() < 1.5e-1 and d.mean() < 2.5e-2
+        assert d.max() < 0.25 * max(wav.abs().max().item(), 1e-3) and d.mean() < 0.06 * wav.abs().mean().item()
     eng.close()
 
 

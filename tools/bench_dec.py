@@ -7,7 +7,7 @@ numbers are device time per kernel including the in-graph kernel boundary.
     python tools/bench_dec.py floor            trivial-kernel boundary cost inside a graph
     python tools/bench_dec.py gemm             single decode GEMMs, weights cycled through > 256 MB (HBM, not MALL)
     python tools/bench_dec.py layer [M]        norm-free decoder layer chains (talker 2048/6144 x 28, predictor 1024/3072 x 5 x 15)
-Set S2S_NO_GEMM_DEC=1 to time the r1 skinny kernel behind s2s_op_gemm_ex on the same shapes (`gemm` / `layer-old`).
+`gemm-old` / `layer-old` time the r1 skinny kernel (row-major operands, rmsnorm launches) on the same shapes.
 """
 import ctypes as C
 import os
@@ -31,10 +31,18 @@ def graph_time(fn, warm=3, reps=20):
     return us.value, n
 
 
-def dec(st, A, W, M, N, K, *, ss=None, parts=0, mode=0, Cb=None, X=None, XB=None, sso=None, glu=False, nf=0, bias=None):
-    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), A.stride(0), native.ptr(W), W.stride(0), native.ptr(bias), M, N, K, native.ptr(ss), parts, 128,
-                                     1.0 / K, 1e-6, mode, native.ptr(Cb), 0 if Cb is None else Cb.stride(0), 0, native.ptr(X), 0 if X is None else X.stride(0),
-                                     native.ptr(XB), 0 if XB is None else XB.stride(0), native.ptr(sso), 1 if glu else 0, nf), "gemm_dec")
+def to_frag(W):
+    rows, K = W.shape
+    out = torch.zeros(((rows + 15) // 16 * 16) * K, dtype=torch.bfloat16, device=W.device)
+    native.check(lib.s2s_op_to_frag(native.stream_handle(), native.ptr(W), W.stride(0), None, native.ptr(out), rows, K), "to_frag")
+    return out
+
+
+def dec(st, A, Wf, M, N, K, *, ss=None, parts=0, mode=0, Cb=None, X=None, XB=None, sso=None, glu=False, nf=0, bias=None, layout=7, ldc=None, ldxb=None):
+    """Wf: fragment-major weights; layout bits: 1 A fragment-major, 2 C fragment-major, 4 XB fragment-major."""
+    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), K, native.ptr(Wf), K, native.ptr(bias), M, N, K, native.ptr(ss), parts, 128,
+                                     1.0 / K, 1e-6, mode, native.ptr(Cb), ldc or N, 0, native.ptr(X), 0 if X is None else X.stride(0),
+                                     native.ptr(XB), ldxb or N, native.ptr(sso), 1 if glu else 0, nf, layout), "gemm_dec")
 
 
 def floor():
@@ -44,7 +52,7 @@ def floor():
 
     def fn(st):
         for _ in range(200):
-            native.check(lib.s2s_op_rows_prep(st, native.ptr(x), 256, native.ptr(xb), 256, native.ptr(ss), 4, 256), "prep")
+            native.check(lib.s2s_op_rows_prep(st, native.ptr(x), 256, native.ptr(xb), 256, native.ptr(ss), 4, 256, 0), "prep")
         return 200
 
     us, n = graph_time(fn)
@@ -58,19 +66,20 @@ def gemm_shapes(M):
             ("w.fc2", M, 1280, 5120, 2, False), ("w.logits", M, 51866, 1280, 1, False)]
 
 
-def gemm(M=64):
-    old = os.environ.get("S2S_NO_GEMM_DEC") is not None
+def gemm(M=64, old=False):
     for name, M_, N, K, mode, glu in gemm_shapes(M):
         rows = 2 * N if glu else N
         wbytes = rows * K * 2
         nbuf = max(2, min(64, int(400e6 // wbytes) + 1))
         Ws = [(torch.randn(rows, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(nbuf)]
-        A = torch.randn(M_, K, device=dev).to(torch.bfloat16)
+        if not old:
+            Ws = [to_frag(W) for W in Ws]
+        A = torch.randn(max(M_, 16 * ((M_ + 15) // 16)), K, device=dev).to(torch.bfloat16)      # same bytes either layout
         ss = torch.rand(128, 128, device=dev)
         Cb = torch.zeros(M_, N, dtype=torch.bfloat16 if mode == 0 else torch.float32, device=dev)
         X = torch.zeros(M_, N, device=dev)
-        XB = torch.zeros(M_, N, dtype=torch.bfloat16, device=dev)
-        sso = torch.zeros(256, 128, device=dev)
+        XB = torch.zeros(16 * ((M_ + 15) // 16), N, dtype=torch.bfloat16, device=dev)
+        sso = torch.zeros(4096, 128, device=dev)
         res = []
         for nf in ((0,) if old else (1, 2)):
             if M_ > 64 and nf == 2:
@@ -86,7 +95,7 @@ def gemm(M=64):
                     elif mode == 2:
                         dec(st, A, W, M_, N, K, mode=2, X=X, XB=XB, sso=sso, nf=nf)
                     else:
-                        dec(st, A, W, M_, N, K, ss=ss, parts=128, mode=mode, Cb=Cb, glu=glu, nf=nf)
+                        dec(st, A, W, M_, N, K, ss=ss, parts=128, mode=mode, Cb=Cb, glu=glu, nf=nf, layout=1)
                 return len(Ws)
 
             us, n = graph_time(fn)
@@ -99,18 +108,19 @@ def layer(M=64, old=False):
         def w(r, c):
             return (torch.randn(r, c, device=dev) * c ** -0.5).to(torch.bfloat16)
 
-        Wq = [w(nq, hid) for _ in range(L)]
-        Wo = [w(hid, hd) for _ in range(L)]
-        Wg = [w(2 * ffn, hid) for _ in range(L)]
-        Wd = [w(hid, ffn) for _ in range(L)]
+        cv = (lambda t: t) if old else to_frag
+        Wq = [cv(w(nq, hid)) for _ in range(L)]
+        Wo = [cv(w(hid, hd)) for _ in range(L)]
+        Wg = [cv(w(2 * ffn, hid)) for _ in range(L)]
+        Wd = [cv(w(hid, ffn)) for _ in range(L)]
         X = torch.randn(M, hid, device=dev) * 0.1
-        XB = X.to(torch.bfloat16)
+        XB = torch.zeros(128, hid, dtype=torch.bfloat16, device=dev)
         H = torch.zeros(M, hid, dtype=torch.bfloat16, device=dev)
         g = torch.ones(hid, device=dev)
         ssA = torch.ones(256, 128, device=dev)
         ssB = torch.ones(256, 128, device=dev)
-        qkv = torch.zeros(M, nq, dtype=torch.bfloat16, device=dev)
-        act = torch.zeros(M, ffn, dtype=torch.bfloat16, device=dev)
+        qkv = torch.zeros(128, nq, dtype=torch.bfloat16, device=dev)
+        act = torch.zeros(128, ffn, dtype=torch.bfloat16, device=dev)
         parts = lib.s2s_op_gemm_dec_parts(M, hid, 0)
 
         def fn(st):
@@ -124,10 +134,10 @@ def layer(M=64, old=False):
                         native.check(lib.s2s_op_gemm_ex(st, native.ptr(H), hid, native.ptr(Wg[l]), None, None, native.ptr(act), ffn, M, ffn, hid, 1, 1, 0, 1, 0.0), "g")
                         native.check(lib.s2s_op_gemm_ex(st, native.ptr(act), ffn, native.ptr(Wd[l]), None, native.ptr(X), native.ptr(X), hid, M, hid, ffn, 1, 0, 0, 0, 0.0), "d")
                     else:
-                        dec(st, XB, Wq[l], M, nq, hid, ss=ssA, parts=parts, mode=0, Cb=qkv)
-                        dec(st, qkv, Wo[l], M, hid, hd, mode=2, X=X, XB=XB, sso=ssB)
-                        dec(st, XB, Wg[l], M, ffn, hid, ss=ssB, parts=parts, mode=0, Cb=act, glu=True)
-                        dec(st, act, Wd[l], M, hid, ffn, mode=2, X=X, XB=XB, sso=ssA)
+                        dec(st, XB, Wq[l], M, nq, hid, ss=ssA, parts=parts, mode=0, Cb=qkv, layout=1 | 2, ldc=nq)   # (the engine writes qkv row-major for the attention)
+                        dec(st, qkv, Wo[l], M, hid, hd, mode=2, X=X, XB=XB, sso=ssB, layout=1 | 4, ldxb=hid)
+                        dec(st, XB, Wg[l], M, ffn, hid, ss=ssB, parts=parts, mode=0, Cb=act, glu=True, layout=1 | 2, ldc=ffn)
+                        dec(st, act, Wd[l], M, hid, ffn, mode=2, X=X, XB=XB, sso=ssA, layout=1 | 4, ldxb=hid)
             return steps * L
 
         us, n = graph_time(fn, warm=2, reps=10)
@@ -147,3 +157,5 @@ if __name__ == "__main__":
         layer(M, old=False)
     if which in ("layer-old",):
         layer(M, old=True)
+    if which in ("gemm-old",):
+        gemm(M, old=True)
