@@ -189,21 +189,26 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
             }
         }
     };
-    // Three straight-line schedules (separate code, so each one's wait counts and register assignment are exact):
+    // Three straight-line schedules (separate code, so each one's wait counts and register assignment are exact).  When the
+    // registers allow it, BOTH stages are issued before the row-scale partials are reduced (their wait would otherwise delay
+    // the second stage's issue by an L2 round trip).
+    constexpr bool EARLY = 2 * UC * (NS + MT) * 4 + MT * NS * 4 + RH * RP <= 216;
     if (s1 - s0 <= UC) {                 // short slice (e.g. K = 1024): a single stage holds it, nothing is re-read
         load(0, s0);
         rms_parts();
         compute(0);
     } else if (s1 - s0 <= 2 * UC) {      // the whole slice is in flight at once (K = 2048)
         load(0, s0);
+        if constexpr (!EARLY) rms_parts();
         load(1, s0 + UC);
-        rms_parts();
+        if constexpr (EARLY) rms_parts();
         compute(0);
         compute(1);
     } else {                             // long slice: two stages in flight, refilled behind the MFMAs
         load(0, s0);
+        if constexpr (!EARLY) rms_parts();
         load(1, s0 + UC);
-        rms_parts();
+        if constexpr (EARLY) rms_parts();
         int sb = s0;
         do {
             compute(0);

@@ -93,7 +93,7 @@ def gemm(M=64, old=False):
                                                         native.ptr(X) if mode == 2 else native.ptr(Cb), N, M_, N, K, native.S2S_BF16,
                                                         native.S2S_F32 if mode else native.S2S_BF16, 0, flags, 0.0), "gemm_ex")
                     elif mode == 2:
-                        dec(st, A, W, M_, N, K, mode=2, X=X, XB=XB, sso=sso, nf=nf)
+                        dec(st, A, W, M_, N, K, mode=2, X=X, XB=XB, sso=sso, nf=nf, layout=5)
                     else:
                         dec(st, A, W, M_, N, K, ss=ss, parts=128, mode=mode, Cb=Cb, glu=glu, nf=nf, layout=1)
                 return len(Ws)
