@@ -11,7 +11,7 @@ from threading import Event
 from time import perf_counter
 from typing import Any, Iterator
 
-from .messages import (PIPELINE_END, SESSION_END, AudioOutput, EndOfResponse, PartialTranscription, PipelineControlMessage,
+from .messages import (PIPELINE_END, SESSION_END, AudioOutput, EndOfResponse, PartialTranscription, PipelineControlMessage, PipelineEvent,
                        Transcription, TTSInput, is_control_message)
 
 logger = logging.getLogger(__name__)
@@ -78,6 +78,11 @@ class BaseHandler:
             if isinstance(item, PipelineControlMessage):
                 continue
             if not self.should_process_input(item):
+                continue
+            # response events share the TTS queue with their audio: forwarding them here preserves the model's exact
+            # text / tool / audio order (reference baseHandler.py:139-143)
+            if isinstance(item, PipelineEvent):
+                self.queue_out.put(item)
                 continue
             start = perf_counter()
             try:

@@ -88,6 +88,33 @@ class AudioOutput(PipelineMessage):
     cleanup_only: bool = False
 
 
+class AssistantTextPart(BaseModel):
+    """One ordered assistant text part (reference pipeline/messages.py:94-98)."""
+
+    type: Literal["text"] = "text"
+    text: str
+
+
+class PipelineEvent(BaseModel):
+    """Base of the protocol-neutral events the realtime router consumes (reference pipeline/events.py:23-33).  They share
+    the TTS queue with their audio; handlers forward them untouched so text / tool / audio order is preserved."""
+
+    type: str
+
+
+class AssistantOutputEvent(PipelineEvent):
+    """Ordered assistant output awaiting API-specific serialisation (reference pipeline/events.py:105-131; only the
+    fields the TTS handler reads)."""
+
+    type: Literal["assistant_text"] = "assistant_text"
+    parts: list = Field(default_factory=list)
+    text: str = ""
+    turn_id: str | None = None
+    turn_revision: int | None = None
+    cancel_generation: int | None = None
+    response_key: str | None = Field(default=None, exclude=True, repr=False)
+
+
 AUDIO_RESPONSE_DONE: Final[bytes] = b"__RESPONSE_DONE__"
 PIPELINE_END: Final[bytes] = b"END"
 

@@ -258,7 +258,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnRowsParams p) {
     }
     __syncthreads();
     T* o = (T*)p.O + (long)b * p.o_bs + (long)h * D;
-    for (int d = tid; d < D; d += 256) Elem<T>::st(o + d, ((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) * inv);
+    const int ksteps = (p.H * D) >> 5;
+    for (int d = tid; d < D; d += 256) {
+        const float v = ((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) * inv;
+        if (p.o_frag) {   // fragment-major rows [B][H*D] for the projection that follows (gemm_dec.hip operand layout)
+            const int k = h * D + d;
+            Elem<T>::st((T*)p.O + ((((long)(b >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (b & 15)) * 8 + (k & 7), v);
+        } else {
+            Elem<T>::st(o + d, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -534,6 +543,7 @@ int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype) {
     if (p.kv_len_const <= 0) return fail(S2S_ERR_ARG, "attention: kv_len_const must be > 0");
     if (p.Tq == 1 && !p.bias && p.kv_len_const >= 64)
         return dtype == S2S_BF16 ? launch_attn_decode<__hip_bfloat16>(st, p) : launch_attn_decode<float>(st, p);
+    S2S_REQUIRE(!p.o_frag, "attention: fragment-major output is a decode-kernel (Tq = 1, >= 64 keys) feature");
     return dtype == S2S_BF16 ? launch_attn_rows<__hip_bfloat16>(st, p) : launch_attn_rows<float>(st, p);
 }
 

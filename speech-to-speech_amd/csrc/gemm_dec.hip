@@ -54,7 +54,7 @@ __device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
 // MODE 0: C bf16 = act(rstd * acc + bias); GLU: C = silu(rstd*gate) * (rstd*up)
 // MODE 1: C f32  = act(rstd * acc + bias)
 // MODE 2: X f32 (in place) += rstd * acc + bias; XB = bf16(X); ss_out[slab][m] = sum over the slab's columns of X^2
-template <int MT, int NF, bool GLU, int MODE, int UC, bool AF>
+template <int MT, int NF, bool GLU, int MODE, int UC, bool AF, bool NT>
 __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     constexpr int NS = NF * (GLU ? 2 : 1);       // weight streams per wave
     constexpr int GRMAX = GLU ? 2 : 4;
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
 #pragma unroll
         for (int u = 0; u < UC; ++u)
 #pragma unroll
-            for (int q = 0; q < NS; ++q) fw[st][u][q] = ld_nt16(wb[q] + u * 1024 + loff);
+            for (int q = 0; q < NS; ++q) {
+                if constexpr (NT) fw[st][u][q] = ld_nt16(wb[q] + u * 1024 + loff);      // streamed once: do not displace cached lines
+                else fw[st][u][q] = *reinterpret_cast<const u32x4_t*>(wb[q] + u * 1024 + loff);   // re-read every step: keep in L2 / MALL
+            }
         if constexpr (AF) {
             const char* ab[MT];
 #pragma unroll
@@ -304,16 +307,28 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     }
 }
 
-template <int MT, int NF, bool GLU, int MODE, bool AF>
-int launch_dec2(hipStream_t st, const DecGemm& a) {
+// loaded k-steps per wave for a slice of T steps with stages of UC: everything past T is re-read and masked
+static inline int dec_loaded_steps(int T, int UC) { return T <= UC ? UC : (T + 2 * UC - 1) / (2 * UC) * (2 * UC); }
+
+template <int MT, int NF, bool GLU, int MODE, bool AF, bool NT>
+int launch_dec3(hipStream_t st, const DecGemm& a) {
     constexpr int NS = NF * (GLU ? 2 : 1);
     // register budget: two stages of UC * (NS + MT) 16-byte fragments + MT * NS accumulators
     constexpr int FR = NS + MT;      // 16-byte fragments per k-step
     constexpr int UC = FR <= 2 ? 8 : FR == 3 ? 6 : FR <= 6 ? 4 : FR <= 9 ? 2 : 1;
+    constexpr int UC_ALT = FR == 2 ? 6 : (FR == 5 ? 3 : UC);      // second stage depth for slices UC does not divide (K = 3072)
     const int slabs = cdiv(a.N, 16 * NF);
-    gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF><<<slabs, DEC_NW * 64, 0, st>>>(a);
+    const int T = cdiv(a.K >> 5, DEC_NW);
+    if (UC_ALT != UC && dec_loaded_steps(T, UC_ALT) < dec_loaded_steps(T, UC))
+        gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT><<<slabs, DEC_NW * 64, 0, st>>>(a);
+    else
+        gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF, NT><<<slabs, DEC_NW * 64, 0, st>>>(a);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
+}
+template <int MT, int NF, bool GLU, int MODE, bool AF>
+int launch_dec2(hipStream_t st, const DecGemm& a) {
+    return a.w_cached ? launch_dec3<MT, NF, GLU, MODE, AF, false>(st, a) : launch_dec3<MT, NF, GLU, MODE, AF, true>(st, a);
 }
 template <int MT, int NF, bool GLU, int MODE>
 int launch_dec(hipStream_t st, const DecGemm& a) {
@@ -449,7 +464,7 @@ extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, con
     a.mode = mode; a.C = C; a.ldc = (long)ldc; a.act = act;
     a.X = X; a.ldx = (long)ldx; a.XB = (__hip_bfloat16*)XB; a.ldxb = (long)ldxb; a.ss_out = ss_out;
     a.glu = glu != 0; a.nf = nf;
-    a.a_frag = (layout & 1) != 0; a.c_frag = (layout & 2) != 0; a.xb_frag = (layout & 4) != 0;
+    a.a_frag = (layout & 1) != 0; a.c_frag = (layout & 2) != 0; a.xb_frag = (layout & 4) != 0; a.w_cached = (layout & 8) != 0;
     return s2s::gemm_dec((hipStream_t)stream, a);
 }
 

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         OutT* __restrict__ y, int rows, int cols,
-                                                        float eps, long x_rs, float* __restrict__ y_f32) {
+                                                        float eps, long x_rs, float* __restrict__ y_f32, int y_frag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -69,7 +69,12 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                 p.y = f32_to_bf16_bits(o1);
                 p.z = f32_to_bf16_bits(o2);
                 p.w = f32_to_bf16_bits(o3);
-                reinterpret_cast<ushort4*>(yr)[c] = p;
+                if (y_frag) {   // fragment-major rows (gemm_dec.hip operand layout): 4 consecutive columns stay inside one 8-element chunk
+                    const int k = c * 4;
+                    *reinterpret_cast<ushort4*>(y + ((((long)(row >> 4) * (cols >> 5) + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (row & 15)) * 8 + (k & 7)) = p;
+                } else {
+                    reinterpret_cast<ushort4*>(yr)[c] = p;
+                }
             }
             if (y_f32) reinterpret_cast<float4*>(y_f32 + (long)row * cols)[c] = make_float4(o0, o1, o2, o3);
         }
@@ -77,13 +82,15 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 }
 
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,
-              int cols, float eps, int y_dtype) {
+              int cols, float eps, int y_dtype, bool y_frag) {
     S2S_REQUIRE(cols % 4 == 0 && cols <= NORM_MAX_V4 * 256, "layernorm: cols=%d unsupported", cols);
+    S2S_REQUIRE(!y_frag || (y_dtype == S2S_BF16 && cols % 32 == 0), "layernorm: fragment-major output needs bf16 and cols %% 32 == 0");
     if (rows == 0) return S2S_OK;
     if (y_dtype == S2S_F32)
-        norm_rows_kernel<float, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (float*)y, rows, cols, eps, cols, nullptr);
+        norm_rows_kernel<float, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (float*)y, rows, cols, eps, cols, nullptr, 0);
     else
-        norm_rows_kernel<__hip_bfloat16, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (__hip_bfloat16*)y, rows, cols, eps, cols, nullptr);
+        norm_rows_kernel<__hip_bfloat16, false><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, beta, (__hip_bfloat16*)y, rows, cols, eps, cols, nullptr,
+                                                                               y_frag ? 1 : 0);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -93,9 +100,9 @@ int rmsnorm_ex(hipStream_t st, const float* x, long x_rs, const float* gamma, vo
     S2S_REQUIRE(cols % 4 == 0 && cols <= NORM_MAX_V4 * 256 && x_rs % 4 == 0, "rmsnorm: cols=%d unsupported", cols);
     if (rows == 0) return S2S_OK;
     if (y_dtype == S2S_F32)
-        norm_rows_kernel<float, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (float*)y, rows, cols, eps, x_rs, y_f32);
+        norm_rows_kernel<float, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (float*)y, rows, cols, eps, x_rs, y_f32, 0);
     else
-        norm_rows_kernel<__hip_bfloat16, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (__hip_bfloat16*)y, rows, cols, eps, x_rs, y_f32);
+        norm_rows_kernel<__hip_bfloat16, true><<<cdiv(rows, 4), 256, 0, st>>>(x, gamma, nullptr, (__hip_bfloat16*)y, rows, cols, eps, x_rs, y_f32, 0);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -110,7 +117,7 @@ int rmsnorm(hipStream_t st, const float* x, const float* gamma, void* y, int row
 extern "C" int32_t s2s_op_layernorm(void* stream, const float* x, const float* gamma, const float* beta,
                                     void* y, int32_t rows, int32_t cols, float eps, int32_t y_dtype) {
     S2S_REQUIRE(y_dtype == S2S_F32 || y_dtype == S2S_BF16, "bad y_dtype");
-    return s2s::layernorm((hipStream_t)stream, x, gamma, beta, y, rows, cols, eps, y_dtype);
+    return s2s::layernorm((hipStream_t)stream, x, gamma, beta, y, rows, cols, eps, y_dtype, false);
 }
 extern "C" int32_t s2s_op_rmsnorm(void* stream, const float* x, const float* gamma, void* y, int32_t rows,
                                   int32_t cols, float eps, int32_t y_dtype) {

@@ -32,6 +32,8 @@ struct DecGemm {
     const __hip_bfloat16* A; long lda;      // [M][lda]; raw (un-normalised) bf16 rows when ss_in is set
     const __hip_bfloat16* W; long ldw;      // FRAGMENT-MAJOR weights (to_frag): [roundup(N,16)][K]; glu: [gate tiles | up tiles]; ldw unused
     bool a_frag;                            // A is fragment-major (else row-major [M][lda])
+    bool w_cached;                          // weights are re-read every step of a loop (code predictor): plain loads that stay in L2 / the
+                                            // Infinity Cache; default (false): non-temporal streaming loads
     bool c_frag, xb_frag;                   // mode 0 C / mode 2 XB written fragment-major (row width ldc / ldxb, multiple of 32)
     const float* bias;                      // [N] or nullptr
     int M, N, K;
@@ -53,7 +55,7 @@ int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, f
 int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K);
 
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,
-              int cols, float eps, int y_dtype);
+              int cols, float eps, int y_dtype, bool y_frag = false);   // y_frag: bf16 rows written fragment-major (gemm_dec.hip)
 // rows at x + r*x_rs; optional second copy of the normalised rows in f32 (y_f32, contiguous)
 int rmsnorm_ex(hipStream_t st, const float* x, long x_rs, const float* gamma, void* y, float* y_f32, int rows, int cols, float eps,
                int y_dtype);
@@ -74,6 +76,7 @@ struct AttnRowsParams {
     const int* causal_off_arr;   // optional int32[B]: per-session offset (tokens already in the cache) instead of causal_off
     int window;          // >0: additionally j > t + causal_off - window
     float scale;
+    bool o_frag;         // Tq == 1 decode kernel only: write O as fragment-major rows [B][H*D] (gemm_dec.hip operand layout)
 };
 struct AttnMfmaParams {
     const __hip_bfloat16* Q; long q_bs, q_rs;

@@ -392,31 +392,32 @@ static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, 
     const auto& c = s.c;
     const int H = c.heads, Hk = c.kv_heads, D = c.head_dim, hid = c.hidden;
     const int nq = (H + 2 * Hk) * D, M = B * T_len;
+    const bool cached = &s == &m->pred;      // the code predictor's matrices are re-read 15 times per frame: keep them in L2 / MALL
     int rc;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
         DecGemm q{};
         q.A = (const __hip_bfloat16*)m->xb; q.a_frag = true; q.W = (const __hip_bfloat16*)s.qkv_n[l]; q.M = M; q.N = nq; q.K = hid;
         q.ss_in = m->ssA; q.n_parts_in = m->ss_parts_A; q.ss_stride = DEC_ROWS; q.inv_dim = 1.0f / (float)hid; q.eps = c.eps;
-        q.mode = 0; q.C = m->qkv; q.ldc = nq; q.act = S2S_ACT_NONE;
+        q.mode = 0; q.C = m->qkv; q.ldc = nq; q.act = S2S_ACT_NONE; q.w_cached = cached;
         if ((rc = gemm_dec(st, q))) return rc;
         bool att_frag = false;
         if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, nullptr, &att_frag))) return rc;
         DecGemm o{};
         o.A = (const __hip_bfloat16*)m->att; o.lda = (long)H * D; o.a_frag = att_frag; o.W = (const __hip_bfloat16*)s.o_f[l];
         o.M = M; o.N = hid; o.K = H * D; o.mode = 2; o.X = x; o.ldx = hid; o.XB = (__hip_bfloat16*)m->xb; o.ldxb = hid; o.xb_frag = true; o.ss_out = m->ssB;
-        o.ss_stride = DEC_ROWS; o.act = S2S_ACT_NONE;
+        o.ss_stride = DEC_ROWS; o.act = S2S_ACT_NONE; o.w_cached = cached;
         if ((rc = gemm_dec(st, o))) return rc;
         const int parts_o = dec_parts(hid, dec_nf(o));
         DecGemm g{};
         g.A = (const __hip_bfloat16*)m->xb; g.a_frag = true; g.W = (const __hip_bfloat16*)s.gu_n[l]; g.M = M; g.N = c.ffn; g.K = hid;
         g.ss_in = m->ssB; g.n_parts_in = parts_o; g.ss_stride = DEC_ROWS; g.inv_dim = 1.0f / (float)hid; g.eps = c.eps;
-        g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.c_frag = true; g.act = S2S_ACT_NONE; g.glu = true;
+        g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.c_frag = true; g.act = S2S_ACT_NONE; g.glu = true; g.w_cached = cached;
         if ((rc = gemm_dec(st, g))) return rc;
         DecGemm d{};
         d.A = (const __hip_bfloat16*)m->act; d.a_frag = true; d.W = (const __hip_bfloat16*)s.down_f[l];
         d.M = M; d.N = hid; d.K = c.ffn; d.mode = 2; d.X = x; d.ldx = hid; d.XB = (__hip_bfloat16*)m->xb; d.ldxb = hid; d.xb_frag = true; d.ss_out = m->ssA;
-        d.ss_stride = DEC_ROWS; d.act = S2S_ACT_NONE;
+        d.ss_stride = DEC_ROWS; d.act = S2S_ACT_NONE; d.w_cached = cached;
         if ((rc = gemm_dec(st, d))) return rc;
         m->ss_parts_A = dec_parts(hid, dec_nf(d));
     }
@@ -498,7 +499,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
                 DecGemm ip{};
                 ip.A = (const __hip_bfloat16*)m->pin_t; ip.a_frag = true; ip.W = (const __hip_bfloat16*)m->in_proj_f; ip.bias = TPF(m, "pred.in_proj.b");
                 ip.M = M; ip.N = P; ip.K = E; ip.mode = 2; ip.x_overwrite = true; ip.X = m->xp; ip.ldx = P; ip.XB = (__hip_bfloat16*)m->xb; ip.ldxb = P; ip.xb_frag = true;
-                ip.ss_out = m->ssA; ip.ss_stride = DEC_ROWS; ip.act = S2S_ACT_NONE;
+                ip.ss_out = m->ssA; ip.ss_stride = DEC_ROWS; ip.act = S2S_ACT_NONE; ip.w_cached = true;
                 if ((rc = gemm_dec(st, ip))) return rc;
                 m->ss_parts_A = dec_parts(P, dec_nf(ip));
             } else {
@@ -521,7 +522,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
             hg.A = (const __hip_bfloat16*)m->xb; hg.a_frag = true; hg.W = (const __hip_bfloat16*)m->head_n[g];
             hg.M = M; hg.N = CB; hg.K = P;
             hg.ss_in = m->ssA; hg.n_parts_in = m->ss_parts_A; hg.ss_stride = DEC_ROWS; hg.inv_dim = 1.0f / (float)P; hg.eps = c.eps;
-            hg.mode = 1; hg.C = m->logits; hg.ldc = CB; hg.act = S2S_ACT_NONE;
+            hg.mode = 1; hg.C = m->logits; hg.ldc = CB; hg.act = S2S_ACT_NONE; hg.w_cached = true;
             if ((rc = gemm_dec(st, hg))) return rc;
         } else {
             if ((rc = stack_forward(m, st, m->pred, m->xp, B, T_len, pos, g + 2, nullptr))) return rc;

@@ -54,6 +54,9 @@ struct Whisper {
     unsigned char *mask_sup = nullptr, *mask_begin = nullptr, *mask_fill = nullptr;
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> step_graphs;
+    // bf16 decode path on the fragment-major weight-streaming kernel (gemm_dec.hip): own pre-swizzled copies of the decoder matrices
+    std::map<std::string, void*> fragw;
+    std::vector<void*> owned;
 };
 
 static const Tensor* find(const Whisper* m, const std::string& name) {
@@ -144,12 +147,13 @@ static int finalize(Whisper* m) {
     const size_t o_cross = a.take((size_t)c.dec_layers * B * T * 2 * d * e);
     const size_t o_sk = a.take((size_t)c.dec_layers * B * m->tmax * d * e);
     const size_t o_sv = a.take((size_t)c.dec_layers * B * m->tmax * d * e);
+    const size_t B16 = (B + 15) / 16 * 16;            // fragment-major decode activations are addressed in whole 16-row tiles
     const size_t o_xd = a.take(B * d * 4);
-    const size_t o_hd = a.take(B * d * e);
+    const size_t o_hd = a.take(B16 * d * e);
     const size_t o_qkvd = a.take(B * 3 * d * e);
-    const size_t o_attd = a.take(B * d * e);
+    const size_t o_attd = a.take(B16 * d * e);
     const size_t o_qd = a.take(B * d * e);
-    const size_t o_ffnd = a.take(B * (size_t)c.ffn * e);
+    const size_t o_ffnd = a.take(B16 * (size_t)c.ffn * e);
     const size_t o_logits = a.take(B * (size_t)c.vocab * 4);
     const size_t o_ints = a.take((size_t)(B * (8 + m->tmax)) * 4);
     m->arena_bytes = a.off;
@@ -174,6 +178,22 @@ static int finalize(Whisper* m) {
         S2S_HIP_CHECK(hipMalloc((void**)&mb, 3 * (size_t)c.vocab));
         S2S_HIP_CHECK(hipMemset(mb, 0, 3 * (size_t)c.vocab));
         m->mask_sup = mb; m->mask_begin = mb + c.vocab; m->mask_fill = mb + 2 * (size_t)c.vocab;
+    }
+    if (c.dtype == S2S_BF16 && getenv("S2S_NO_DEC_FUSION") == nullptr && d % 32 == 0 && c.ffn % 32 == 0 && d >= 256 && c.ffn >= 256 && c.dec_layers > 0) {
+        auto frag = [&](const std::string& name, long rows, int K) -> int {
+            void* buf = nullptr;
+            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)((rows + 15) / 16 * 16) * K * e));
+            m->owned.push_back(buf);
+            m->fragw[name] = buf;
+            return to_frag(nullptr, P(m, name), K, nullptr, buf, (int)rows, K);
+        };
+        for (int l = 0; l < c.dec_layers; ++l) {
+            if ((rc = frag(lname("dec", l, "qkv.w"), 3 * d, (int)d)) || (rc = frag(lname("dec", l, "o.w"), d, (int)d)) || (rc = frag(lname("dec", l, "cq.w"), d, (int)d)) ||
+                (rc = frag(lname("dec", l, "co.w"), d, (int)d)) || (rc = frag(lname("dec", l, "fc1.w"), c.ffn, (int)d)) || (rc = frag(lname("dec", l, "fc2.w"), d, c.ffn)))
+                return rc;
+        }
+        if ((rc = frag("dec.tok", c.vocab, (int)d))) return rc;
+        S2S_HIP_CHECK(hipDeviceSynchronize());
     }
     m->finalized = true;
     return S2S_OK;
@@ -240,8 +260,59 @@ static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
     return S2S_OK;
 }
 
+// decode-step projection on the fragment-major weight-streaming kernel: C = act(A W^T + b) (bf16 / f32) or X += A W^T + b
+static int dec_proj(Whisper* m, hipStream_t st, const void* A, const std::string& w, const float* bias, int B, int N, int K, int mode, void* C,
+                    bool c_frag, int act, float* X) {
+    DecGemm a{};
+    a.A = (const __hip_bfloat16*)A; a.a_frag = true; a.W = (const __hip_bfloat16*)m->fragw.at(w); a.bias = bias;
+    a.M = B; a.N = N; a.K = K; a.mode = mode; a.C = C; a.ldc = N; a.c_frag = c_frag; a.act = act; a.X = X; a.ldx = N;
+    return gemm_dec(st, a);
+}
+
+// one decoder step for B sessions on the bf16 serving path: LayerNorm rows, attention outputs and the GELU activations are
+// written fragment-major by their producers, every projection streams pre-swizzled weights (gemm_dec.hip)
+static int decode_step_dec(Whisper* m, hipStream_t st, int B) {
+    const auto& c = m->cfg;
+    const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
+    const float scale = 1.0f / sqrtf((float)D);
+    int rc;
+    if ((rc = embed(st, m->cur_ids, m->pos, P(m, "dec.tok"), P(m, "dec.pos"), m->xd, B, d, 1.0f, dt))) return rc;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        void* sk = at(m->self_k, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* sv = at(m->self_v, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln1.g")), PF(m, lname("dec", l, "ln1.b")), m->hd, B, d, 1e-5f, dt, true))) return rc;
+        if ((rc = dec_proj(m, st, m->hd, lname("dec", l, "qkv.w"), PF(m, lname("dec", l, "qkv.b")), B, 3 * d, d, 0, m->qkvd, false, S2S_ACT_NONE, nullptr))) return rc;
+        if ((rc = kv_append(st, m->qkvd, 3 * d, d, 2 * d, sk, sv, (long)m->tmax * d, m->pos, B, d, dt))) return rc;
+        AttnRowsParams p{};
+        p.Q = m->qkvd; p.q_bs = 3 * d; p.q_rs = 3 * d;
+        p.K = sk; p.V = sv; p.kv_bs = (long)m->tmax * d; p.kv_rs = d;
+        p.O = m->attd; p.o_bs = d; p.o_rs = d; p.o_frag = true;
+        p.kv_len_const = m->tmax; p.causal = 1; p.causal_off_arr = m->pos;
+        p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
+        if ((rc = attn_rows(st, p, dt))) return rc;
+        if ((rc = dec_proj(m, st, m->attd, lname("dec", l, "o.w"), PF(m, lname("dec", l, "o.b")), B, d, d, 2, nullptr, false, S2S_ACT_NONE, m->xd))) return rc;
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln2.g")), PF(m, lname("dec", l, "ln2.b")), m->hd, B, d, 1e-5f, dt, true))) return rc;
+        if ((rc = dec_proj(m, st, m->hd, lname("dec", l, "cq.w"), PF(m, lname("dec", l, "cq.b")), B, d, d, 0, m->qd, false, S2S_ACT_NONE, nullptr))) return rc;
+        AttnRowsParams pc{};
+        pc.Q = m->qd; pc.q_bs = d; pc.q_rs = d;
+        pc.K = ckv; pc.V = at(ckv, (size_t)d * e); pc.kv_bs = (long)ENC_T * 2 * d; pc.kv_rs = 2 * d;
+        pc.O = m->attd; pc.o_bs = d; pc.o_rs = d; pc.o_frag = true;
+        pc.kv_len_const = ENC_T; pc.B = B; pc.H = H; pc.Hkv = H; pc.Tq = 1; pc.D = D; pc.scale = scale;
+        if ((rc = attn_rows(st, pc, dt))) return rc;
+        if ((rc = dec_proj(m, st, m->attd, lname("dec", l, "co.w"), PF(m, lname("dec", l, "co.b")), B, d, d, 2, nullptr, false, S2S_ACT_NONE, m->xd))) return rc;
+        if ((rc = layernorm(st, m->xd, PF(m, lname("dec", l, "ln3.g")), PF(m, lname("dec", l, "ln3.b")), m->hd, B, d, 1e-5f, dt, true))) return rc;
+        if ((rc = dec_proj(m, st, m->hd, lname("dec", l, "fc1.w"), PF(m, lname("dec", l, "fc1.b")), B, c.ffn, d, 0, m->ffnd, true, S2S_ACT_GELU, nullptr))) return rc;
+        if ((rc = dec_proj(m, st, m->ffnd, lname("dec", l, "fc2.w"), PF(m, lname("dec", l, "fc2.b")), B, d, c.ffn, 2, nullptr, false, S2S_ACT_NONE, m->xd))) return rc;
+    }
+    if ((rc = layernorm(st, m->xd, PF(m, "dec.ln.g"), PF(m, "dec.ln.b"), m->hd, B, d, 1e-5f, dt, true))) return rc;
+    // logits = h @ tok_emb^T (tied embedding)
+    return dec_proj(m, st, m->hd, "dec.tok", nullptr, B, c.vocab, d, 1, m->logits, false, S2S_ACT_NONE, nullptr);
+}
+
 // one decoder step for B sessions: input ids in m->cur_ids, positions in m->pos
 static int decode_step(Whisper* m, hipStream_t st, int B, bool split_ok) {
+    if (!m->fragw.empty() && B <= 128 && m->tmax >= 64) return decode_step_dec(m, st, B);
     const auto& c = m->cfg;
     const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
     const float scale = 1.0f / sqrtf((float)D);
@@ -392,6 +463,7 @@ extern "C" int32_t s2s_whisper_destroy(void* model) {
     if (m->step_dev) (void)hipFree(m->step_dev);
     if (m->mask_sup) (void)hipFree(m->mask_sup);
     for (auto& kv : m->step_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void* p : m->owned) (void)hipFree(p);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return S2S_OK;

@@ -19,7 +19,8 @@ from typing import Any, Iterator, Optional
 import numpy as np
 import torch
 
-from ..boundary import AUDIO_RESPONSE_DONE, BaseHandler, EndOfResponse, TTSInput
+from ..boundary import (AUDIO_RESPONSE_DONE, PIPELINE_END, SESSION_END, AssistantOutputEvent, AssistantTextPart, BaseHandler, EndOfResponse, TTSInput,
+                        is_control_message)
 from ..checkpoints import TTS_DIMS, load_safetensors_dir, parse_model_name
 from ..session_pool import SessionPool
 from ..text import ByteTextFrontend
@@ -89,39 +90,73 @@ class MI355XQwen3TTSHandler(BaseHandler):
         return estimate_max_new_tokens(text, self.streaming_chunk_size, self.max_new_tokens)
 
     def _coalesce_pending_tts_input(self, current: Any) -> tuple[str, Optional[str]]:
-        """Merge already-queued TTSInputs of the same response into one synthesis call (reference :751-810)."""
+        """Merge already-queued TTSInputs of the same response into one synthesis call - the reference's rules
+        (TTS/qwen3_tts_handler.py:751-810): same (turn_id, turn_revision, cancel_generation, response_key); stop at
+        SESSION_END / PIPELINE_END / EndOfResponse, at anything that is not a TTSInput, and at a TTSInput whose language
+        code differs from the one collected so far; text-only AssistantOutputEvents of the same response that sit between
+        the absorbed inputs are taken out and forwarded BEFORE the audio (protocol order text -> audio)."""
         q = self.queue_in
         text, lang = current.text, current.language_code
         if not hasattr(q, "mutex") or not hasattr(q, "queue"):
             return text, lang
         parts = [text.strip()] if text and text.strip() else []
+        text_events: list = []
+
+        def same_response(item: Any) -> bool:
+            return (item.turn_id == current.turn_id and item.turn_revision == current.turn_revision
+                    and item.cancel_generation == current.cancel_generation and item.response_key == current.response_key)
+
         with q.mutex:
             while q.queue:
                 nxt = q.queue[0]
-                same = (isinstance(nxt, TTSInput) and nxt.response_key == current.response_key and nxt.cancel_generation == current.cancel_generation
-                        and nxt.turn_id == current.turn_id and nxt.prefetch_transaction is None)
-                if not same:
+                if is_control_message(nxt, SESSION_END.kind):
+                    break
+                if isinstance(nxt, bytes) and nxt == PIPELINE_END:
+                    break
+                if isinstance(nxt, EndOfResponse):
+                    break
+                if isinstance(nxt, AssistantOutputEvent):
+                    if not same_response(nxt) or any(not isinstance(part, AssistantTextPart) for part in nxt.parts):
+                        break
+                    text_events.append(q.queue.popleft())
+                    continue
+                if not isinstance(nxt, TTSInput):
+                    break
+                if not same_response(nxt):
+                    break
+                if lang is not None and nxt.language_code is not None and nxt.language_code != lang:
                     break
                 q.queue.popleft()
-                if nxt.text and nxt.text.strip():
+                if nxt.text.strip():
                     parts.append(nxt.text.strip())
-                lang = nxt.language_code or lang
-        return " ".join(parts), lang
+                if lang is None:
+                    lang = nxt.language_code
+        for event in text_events:
+            self.queue_out.put(event)
+        return " ".join(parts).strip(), lang
 
     def _build_prompt(self, text: str) -> TTSPrompt:
         eng = self.pool.engine("tts")
         return TTSPrompt(eng.text_frontend.embed(text, eng.max_prompt))
 
     def process(self, tts_input: Any) -> Iterator[Any]:
+        # stale-turn handling exactly as the reference's process() (TTS/qwen3_tts_handler.py:812-836): the tracker's commit()
+        # returns None - its result is never a filter
+        speculative_turns = getattr(self, "speculative_turns", None)
         if isinstance(tts_input, EndOfResponse):
+            if speculative_turns and not speculative_turns.is_latest_after_reopen_grace(tts_input.turn_id, tts_input.turn_revision):
+                if tts_input.response_key is None:
+                    return
+                tts_input.cleanup_only = True
             yield AUDIO_RESPONSE_DONE
             return
-        if self.speculative_turns is not None and tts_input.turn_id is not None and hasattr(self.speculative_turns, "commit"):
-            if not self.speculative_turns.commit(tts_input.turn_id, tts_input.turn_revision):
-                return
-        text, _lang = self._coalesce_pending_tts_input(tts_input)
-        if not text or not text.strip():
+        if speculative_turns and not speculative_turns.is_latest_after_reopen_grace(tts_input.turn_id, tts_input.turn_revision):
+            logger.debug("Dropping stale TTS input for turn=%s rev=%s", tts_input.turn_id, tts_input.turn_revision)
             return
+        if speculative_turns:
+            speculative_turns.commit(tts_input.turn_id, tts_input.turn_revision)
+        text, _lang = self._coalesce_pending_tts_input(tts_input)
+        text = text or "Hello."          # the reference synthesises "Hello." for an empty response text
         gen = self.cancel_scope.generation if self.cancel_scope is not None else None
         start = perf_counter()
         try:

@@ -150,6 +150,95 @@ def test_tts_coalesces_queued_inputs_of_same_response(pool):
     assert text == "One. Two." and h.queue_in.qsize() == 1
 
 
+def test_tts_coalescing_follows_the_reference_break_rules(pool):
+    """TTS/qwen3_tts_handler.py:751-810: a different turn_revision or language code ends the merge, EndOfResponse /
+    SESSION_END are never crossed, text-only AssistantOutputEvents of the same response are forwarded before the audio."""
+    from speech_to_speech_amd.boundary import AssistantOutputEvent, AssistantTextPart
+
+    h = _tts(pool)
+    mk = lambda text, **kw: TTSInput(text=text, response_key="r", cancel_generation=0, turn_id="t", turn_revision=1, **kw)   # noqa: E731
+    first = mk("One.", language_code="en")
+    ev = AssistantOutputEvent(parts=[AssistantTextPart(text="Two.")], text="Two.", response_key="r", cancel_generation=0, turn_id="t", turn_revision=1)
+    h.queue_in.put(ev)
+    h.queue_in.put(mk("Two."))
+    h.queue_in.put(mk("Drei.", language_code="de"))           # language changes: stop here
+    text, lang = h._coalesce_pending_tts_input(first)
+    assert (text, lang) == ("One. Two.", "en") and h.queue_in.qsize() == 1
+    assert h.queue_out.get_nowait() is ev                      # forwarded ahead of the synthesis
+    h2 = _tts(pool)
+    h2.queue_in.put(TTSInput(text="Newer.", response_key="r", cancel_generation=0, turn_id="t", turn_revision=2))
+    assert h2._coalesce_pending_tts_input(mk("One."))[0] == "One." and h2.queue_in.qsize() == 1      # other revision
+    h3 = _tts(pool)
+    h3.queue_in.put(EndOfResponse(turn_id="t", turn_revision=1))
+    h3.queue_in.put(mk("After."))
+    assert h3._coalesce_pending_tts_input(mk("One."))[0] == "One." and h3.queue_in.qsize() == 2      # never crosses EndOfResponse
+    h4 = _tts(pool)
+    h4.queue_in.put(SESSION_END)
+    h4.queue_in.put(mk("After."))
+    assert h4._coalesce_pending_tts_input(mk("One."))[0] == "One." and h4.queue_in.qsize() == 2
+
+
+def _reference_tracker():
+    """The reference's own SpeculativeTurnTracker (pipeline/speculative_turns.py has no third-party imports and loads
+    standalone); skipped where /root/reference is not mounted (the GPU box)."""
+    import importlib.util
+    import os
+
+    path = "/root/reference/src/speech_to_speech/pipeline/speculative_turns.py"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not available")
+    spec = importlib.util.spec_from_file_location("_ref_speculative_turns", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod.SpeculativeTurnTracker()
+
+
+def test_tts_emits_audio_with_the_reference_speculative_turn_tracker(pool):
+    """commit() of the real tracker returns None: it must never be used as a filter (round-1 bug: every TTSInput with a
+    turn id was dropped, so the registered backend never produced audio in the real pipeline)."""
+    tracker = _reference_tracker()
+    h = _tts(pool)
+    h.speculative_turns = tracker
+    rev = 1
+    tracker.observe("turn-1", rev)
+    blocks = list(h.process(TTSInput(text="Hello there.", turn_id="turn-1", turn_revision=rev)))
+    assert len(blocks) == 5
+    assert tracker.is_committed("turn-1", rev)
+
+
+class _StaleTracker:
+    """Every revision is stale (is_latest_after_reopen_grace -> False); commit must not be reached."""
+
+    def is_latest_after_reopen_grace(self, turn_id, revision):
+        return False
+
+    def commit(self, turn_id, revision):
+        raise AssertionError("stale input was committed")
+
+
+def test_tts_stale_turn_handling_matches_the_reference(pool):
+    h = _tts(pool)
+    h.speculative_turns = _StaleTracker()
+    assert list(h.process(TTSInput(text="Hello.", turn_id="t", turn_revision=1))) == []                  # dropped, no audio
+    assert list(h.process(EndOfResponse(turn_id="t", turn_revision=1))) == []                           # stale and no response key: nothing
+    eor = EndOfResponse(turn_id="t", turn_revision=1, response_key="k")
+    assert list(h.process(eor)) == [AUDIO_RESPONSE_DONE] and eor.cleanup_only is True                   # cleanup-only completion
+
+
+def test_run_loop_forwards_pipeline_events_in_order(pool):
+    from speech_to_speech_amd.boundary import AssistantOutputEvent
+
+    h = _tts(pool)
+    t = threading.Thread(target=h.run)
+    t.start()
+    ev = AssistantOutputEvent(text="tool", response_key="k", cancel_generation=1)
+    h.queue_in.put(ev)
+    h.queue_in.put(PIPELINE_END)
+    t.join(timeout=10)
+    assert h.queue_out.get_nowait() is ev and h.queue_out.get_nowait() == PIPELINE_END
+
+
 def test_run_loop_wraps_audio_and_forwards_session_end(pool):
     h = _tts(pool)
     t = threading.Thread(target=h.run)
