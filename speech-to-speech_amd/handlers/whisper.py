@@ -50,22 +50,32 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         self.gen_kwargs = dict(gen_kwargs or {})
         self.start_language = language
         self.last_language = language if language != "auto" else None
-        self.vocab = vocab or WhisperVocab()
         kind, key, _ = parse_model_name(model_name) if pool is None or "whisper" not in getattr(pool, "_engines", {}) else ("pool", None, None)
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
         self.pool.ensure_engine("whisper", lambda: build_whisper_engine(model_name, device, torch_dtype, max_batch))
+        # special-token ids, suppress_tokens and begin_suppress_tokens come from the checkpoint's generation_config.json - what
+        # the reference's model.generate() applies (generation_whisper.py:1774-1812); synthetic checkpoints get a vocabulary
+        # laid out for their size.  Every id is checked against the model's vocabulary before anything is launched.
+        dims = getattr(self.pool.engine("whisper"), "dims", None)
+        if vocab is None:
+            vocab = WhisperVocab.from_checkpoint(key) if kind == "dir" else WhisperVocab.synthetic(dims.vocab if dims is not None else 51866)
+        self.vocab = vocab.validate(dims.vocab) if dims is not None else vocab
+        self.task = self.gen_kwargs.get("task", "transcribe")
+        if language not in (None, "auto") and self.vocab.multilingual and language not in self.vocab.lang_to_id:
+            raise ValueError(f"language {language!r} is not supported by this checkpoint ({sorted(self.vocab.lang_to_id)})")
         self.warmup()
 
     def warmup(self) -> None:
         import numpy as np
 
         logger.info("Warming up %s", self.__class__.__name__)
-        self.pool.transcribe("whisper", np.zeros(16000, np.float32), language=self.last_language or DEFAULT_LANGUAGE, max_new_tokens=2, vocab=self.vocab)
+        lang = self.last_language if self.last_language in self.vocab.lang_to_id else (DEFAULT_LANGUAGE if DEFAULT_LANGUAGE in self.vocab.lang_to_id else "auto")
+        self.pool.transcribe("whisper", np.zeros(16000, np.float32), language=lang, max_new_tokens=2, vocab=self.vocab, task=self.task)
 
     def process(self, vad_audio: Any) -> Iterator[Any]:
         forced = self.gen_kwargs.get("language") or (self.start_language if self.start_language not in (None, "auto") else None)
-        opts = dict(language=forced or "auto", max_new_tokens=int(self.gen_kwargs.get("max_new_tokens", 128)), vocab=self.vocab)
+        opts = dict(language=forced or "auto", max_new_tokens=int(self.gen_kwargs.get("max_new_tokens", 128)), vocab=self.vocab, task=getattr(self, "task", "transcribe"))
         if vad_audio.mode == "progressive":
             res = self.pool.try_transcribe("whisper", vad_audio.audio, max_queue=self.pool.max_batch, **opts)
             if res is None:

@@ -219,14 +219,15 @@ class WhisperEngine:
         options per request: language (code | "auto" | None), max_new_tokens, vocab (text.WhisperVocab)."""
         vocab = options[0]["vocab"]
         max_new = max(int(o.get("max_new_tokens", 128)) for o in options)
-        prompts = [vocab.prompt(o.get("language")) for o in options]
+        vocab.validate(self.dims.vocab)
+        prompts = [vocab.prompt(o.get("language"), o.get("task", "transcribe")) for o in options]
         self.encode(self.features(audios))
         ids, filled = self.decode(prompts, vocab.eot, max_new, suppress=vocab.suppress, begin_suppress=vocab.begin_suppress,
-                                  lang_ids=list(vocab.lang_to_id.values()))
+                                  lang_ids=list(vocab.lang_to_id.values()) or None)
         out = []
         for i, o in enumerate(options):
             n = int(o.get("max_new_tokens", 128))
-            out.append({"ids": ids[i][:n], "language": vocab.id_to_lang(filled[i][1])})
+            out.append({"ids": ids[i][:n], "language": vocab.id_to_lang(filled[i][1]) if vocab.multilingual else "en"})
         return out
 
     def transcribe_ids(self, audios: Sequence[np.ndarray], prompt: Sequence[int], eos: int, max_new_tokens: int = 128, **kw):

@@ -82,3 +82,36 @@ def test_text_frontends_round_trip():
     e = fe.embed("hi", 16)
     assert e.shape[1] == 4 and 2 <= e.shape[0] <= 16
     assert fe.embed("x" * 100, 8).shape[0] == 8
+
+
+def test_whisper_vocab_from_generation_config_and_synthetic_layouts(tmp_path):
+    """suppress_tokens / begin_suppress_tokens / lang_to_id / task ids come from the checkpoint's generation_config.json (what the
+    reference's generate() applies, generation_whisper.py:1774-1812); synthetic vocabularies are laid out inside the model's size."""
+    import json
+
+    from speech_to_speech_amd.text import WhisperVocab
+
+    gen = {"suppress_tokens": [1, 2, 7, 50359], "begin_suppress_tokens": [220, 50257], "decoder_start_token_id": 50258, "eos_token_id": 50257,
+           "no_timestamps_token_id": 50364, "lang_to_id": {"<|en|>": 50259, "<|de|>": 50261}, "task_to_id": {"transcribe": 50360, "translate": 50359},
+           "is_multilingual": True}
+    (tmp_path / "generation_config.json").write_text(json.dumps(gen))
+    v = WhisperVocab.from_checkpoint(str(tmp_path)).validate(51866)
+    assert v.suppress == (1, 2, 7, 50359) and v.begin_suppress == (220, 50257) and v.lang_to_id == {"en": 50259, "de": 50261}
+    assert v.prompt("de") == [50258, 50261, 50360, 50364] and v.prompt("auto")[1] == -1 and v.prompt("en", "translate")[2] == 50359
+    with pytest.raises(ValueError):
+        v.prompt("xx")
+    with pytest.raises(ValueError):
+        v.validate(320)                                      # large-v3 ids do not fit a 320-token model
+    t = WhisperVocab.synthetic(320).validate(320)
+    assert (t.sot, t.eot, t.transcribe, t.notimestamps) == (300, 319, 305, 306) and t.lang_to_id["en"] == 301
+    en = WhisperVocab.synthetic(51864).validate(51864)       # English-only (tiny.en): <sot><notimestamps>, no language token
+    assert en.prompt("en") == [50257, 50362] and not en.multilingual
+    assert WhisperVocab.synthetic(51866).prompt("fr") == [50258, 50265, 50360, 50364]
+    # a generation config that lacks the ids falls back to the tokenizer's special tokens
+    (tmp_path / "generation_config.json").write_text(json.dumps({"suppress_tokens": [5]}))
+    (tmp_path / "tokenizer.json").write_text(json.dumps({"added_tokens": [{"id": 50257, "content": "<|endoftext|>"}, {"id": 50258, "content": "<|startoftranscript|>"},
+                                                                            {"id": 50259, "content": "<|en|>"}, {"id": 50360, "content": "<|transcribe|>"},
+                                                                            {"id": 50364, "content": "<|notimestamps|>"}]}))
+    (tmp_path / "config.json").write_text(json.dumps({"vocab_size": 51866}))
+    f = WhisperVocab.from_checkpoint(str(tmp_path))
+    assert (f.sot, f.eot, f.transcribe, f.notimestamps, f.suppress, f.lang_to_id) == (50258, 50257, 50360, 50364, (5,), {"en": 50259})

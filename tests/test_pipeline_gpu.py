@@ -49,6 +49,9 @@ def test_units_share_one_pool_and_get_their_own_results():
         units.append((cs, stt, ct, tts))
     pool = SessionPool.for_device("cuda:0")
     assert all(u[1].pool is pool and u[3].pool is pool for u in units)        # one engine replica per GPU, shared
+    # without an explicit vocabulary the handler derives one that fits the model (round-1 bug: large-v3 ids on a 320-token model)
+    plain = specs["mi355x-whisper"].create_handler(_context(99), {k: v for k, v in stt_cfg.items() if k != "vocab"})
+    assert plain.vocab.eot == 319 and max(plain.vocab.lang_to_id.values()) < 320
 
     lens = [48000, 30500, 64000, 20000]
     audios = [synth_audio(n, 200 + i) for i, n in enumerate(lens)]
