@@ -475,9 +475,9 @@ static int launch_attn_step(hipStream_t st, const AttnStepParams& p) {
     const size_t lds = sizeof(float) * (size_t)(p.kv_cap + 8 + 8 + 4 * p.D + 3 * p.D);
     S2S_REQUIRE(lds <= 64 * 1024, "attention step: cache capacity %d too long", p.kv_cap);
     switch (p.D) {
-        case 32: attn_step_kernel<T, 32><<<grid, 256, lds, st>>>(p); break;
-        case 64: attn_step_kernel<T, 64><<<grid, 256, lds, st>>>(p); break;
-        case 128: attn_step_kernel<T, 128><<<grid, 256, lds, st>>>(p); break;
+        case 32: launch_k(attn_step_kernel<T, 32>, grid, dim3(256), lds, st, p); break;
+        case 64: launch_k(attn_step_kernel<T, 64>, grid, dim3(256), lds, st, p); break;
+        case 128: launch_k(attn_step_kernel<T, 128>, grid, dim3(256), lds, st, p); break;
         default: return fail(S2S_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32/64/128)", p.D);
     }
     S2S_LAUNCH_CHECK();
@@ -500,7 +500,7 @@ static int launch_attn_decode(hipStream_t st, const AttnRowsParams& p) {
         if (lds > 64 * 1024)                                                                              \
             S2S_HIP_CHECK(hipFuncSetAttribute((const void*)attn_decode_kernel<T, DV>,                     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-        attn_decode_kernel<T, DV><<<grid, 256, lds, st>>>(p);                                             \
+        launch_k(attn_decode_kernel<T, DV>, grid, dim3(256), lds, st, p);                                 \
     } while (0)
     switch (p.D) {
         case 32: S2S_DEC(32); break;
@@ -525,7 +525,7 @@ static int launch_attn_rows(hipStream_t st, const AttnRowsParams& p) {
         if (lds > 64 * 1024)                                                                             \
             S2S_HIP_CHECK(hipFuncSetAttribute((const void*)attn_rows_kernel<T, DV>,                      \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-        attn_rows_kernel<T, DV><<<grid, 256, lds, st>>>(p);                                              \
+        launch_k(attn_rows_kernel<T, DV>, grid, dim3(256), lds, st, p);                                  \
     } while (0)
     switch (p.D) {
         case 32: S2S_ROWS(32); break;
@@ -776,8 +776,8 @@ int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
     dim3 grid(cdiv(p.Tq, 128), p.H, p.B);
     ProfScope prof(st, S2S_PROF_ATTN_MFMA, 4.0 * p.B * p.H * (double)p.Tq * p.Tk * D,
                    2.0 * p.B * p.H * ((double)p.Tq * D * 2 + (double)p.Tk * D * 2));
-    if (D == 64) attn_mfma_kernel<64><<<grid, 256, 0, st>>>(p);
-    else if (D == 128) attn_mfma_kernel<128><<<grid, 256, 0, st>>>(p);
+    if (D == 64) launch_k(attn_mfma_kernel<64>, grid, dim3(256), 0, st, p);
+    else if (D == 128) launch_k(attn_mfma_kernel<128>, grid, dim3(256), 0, st, p);
     else return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);
     S2S_LAUNCH_CHECK();
     return S2S_OK;

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libs2s_mi355x (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,19 +43,33 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::s2s::fail(S2S_ERR_ARG, __VA_ARGS__);                  \
     } while (0)
 
-// Optional per-kernel timing with HIP events on the launching stream (s2s_prof_enable / _collect).
+// Optional per-kernel timing (s2s_prof_enable / _collect).  While a category is enabled, the launch made inside a ProfScope goes
+// through hipExtLaunchKernelGGL with a start / stop event pair: those events carry the KERNEL's own begin / end timestamps (what
+// rocprofv3 --kernel-trace reports as its duration), not stream markers - so no event-overhead correction is involved and the
+// family averages can be recomputed from a profiler CSV.
 class ProfScope {
   public:
     ProfScope(hipStream_t st, int cat, double flops, double bytes);
     ~ProfScope();
 
   private:
-    hipStream_t st_;
+    [[maybe_unused]] hipStream_t st_;
     int cat_;
     bool on_;
     void* start_ = nullptr;
     void* stop_ = nullptr;
 };
+
+// the innermost active ProfScope's event pair on this thread (false: timing off for the current launch)
+bool prof_current_events(hipEvent_t* start, hipEvent_t* stop);
+
+// kernel launch that is timed when it happens inside an active ProfScope
+template <typename... KArgs, typename... Args>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof_current_events(&e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, e0, e1, 0, static_cast<KArgs>(args)...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);
+}
 
 // decode loops replay captured graphs unless kernel timing is on (events cannot be recorded inside a replay)
 bool prof_active();

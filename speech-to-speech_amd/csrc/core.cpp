@@ -50,6 +50,17 @@ static bool g_graphs = getenv("S2S_NO_GRAPHS") == nullptr;
 bool prof_active() { return g_prof_mask != 0; }
 bool graphs_enabled() { return g_graphs; }
 
+static thread_local hipEvent_t t_cur_start = nullptr, t_cur_stop = nullptr;
+static thread_local bool t_cur_on = false, t_cur_used = false;
+
+bool prof_current_events(hipEvent_t* start, hipEvent_t* stop) {
+    if (!t_cur_on || t_cur_used) return false;      // one timed launch per scope
+    t_cur_used = true;
+    *start = t_cur_start;
+    *stop = t_cur_stop;
+    return true;
+}
+
 ProfScope::ProfScope(hipStream_t st, int cat, double flops, double bytes) : st_(st), cat_(cat), on_(false) {
     if (!(g_prof_mask & (1u << cat))) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -58,13 +69,22 @@ ProfScope::ProfScope(hipStream_t st, int cat, double flops, double bytes) : st_(
     stop_ = take_event();
     g_prof[cat].flops += flops;
     g_prof[cat].bytes += bytes;
-    (void)hipEventRecord((hipEvent_t)start_, st);
+    t_cur_start = (hipEvent_t)start_;
+    t_cur_stop = (hipEvent_t)stop_;
+    t_cur_on = true;
+    t_cur_used = false;
 }
 ProfScope::~ProfScope() {
     if (!on_) return;
-    (void)hipEventRecord((hipEvent_t)stop_, st_);
+    const bool used = t_cur_used;
+    t_cur_on = false;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof[cat_].spans.emplace_back((hipEvent_t)start_, (hipEvent_t)stop_);
+    if (used) {
+        g_prof[cat_].spans.emplace_back((hipEvent_t)start_, (hipEvent_t)stop_);
+    } else {   // nothing was launched through launch_k inside the scope: drop the pair
+        g_event_pool.push_back((hipEvent_t)start_);
+        g_event_pool.push_back((hipEvent_t)stop_);
+    }
 }
 
 }  // namespace s2s
@@ -80,9 +100,9 @@ extern "C" int32_t s2s_graphs_enable(int32_t on) {
     return S2S_OK;
 }
 
-// Device time between a start and a stop event with nothing in between (median of 64 pairs on an idle device): the
-// bracketing itself costs a few microseconds per launch, which matters for the 5-20 us decode kernels.  Subtracted from
-// every span so that the per-family averages agree with rocprofv3's kernel durations.
+// Device time between a start and a stop event with nothing in between (median of 64 pairs on an idle device).  Round 1
+// bracketed kernels with stream events and subtracted this; the spans now come from the kernels' own timestamps
+// (hipExtLaunchKernelGGL) and nothing is subtracted - kept as a diagnostic (s2s_prof_event_overhead_us measures on demand).
 static double g_event_overhead_ms = -1.0;
 static int measure_event_overhead() {
     if (g_event_overhead_ms >= 0.0) return S2S_OK;
@@ -102,22 +122,21 @@ static int measure_event_overhead() {
     return S2S_OK;
 }
 
-extern "C" double s2s_prof_event_overhead_us(void) { return g_event_overhead_ms < 0 ? 0.0 : g_event_overhead_ms * 1e3; }
+extern "C" double s2s_prof_event_overhead_us(void) {
+    (void)measure_event_overhead();
+    return g_event_overhead_ms < 0 ? 0.0 : g_event_overhead_ms * 1e3;
+}
 
 extern "C" int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches) {
     S2S_REQUIRE(category >= 0 && category < S2S_PROF_NCAT, "prof_collect: bad category %d", category);
     std::lock_guard<std::mutex> lk(s2s::g_prof_mu);
     s2s::ProfCat& c = s2s::g_prof[category];
-    if (!c.spans.empty()) {
-        const int rc = measure_event_overhead();
-        if (rc) return rc;
-    }
     double ms = 0;
     for (auto& sp : c.spans) {
         S2S_HIP_CHECK(hipEventSynchronize(sp.second));
         float t = 0;
         S2S_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
-        ms += std::max(0.0, (double)t - g_event_overhead_ms);
+        ms += (double)t;       // kernel begin -> end (hipExtLaunchKernelGGL events): nothing to subtract
         s2s::g_event_pool.push_back(sp.first);
         s2s::g_event_pool.push_back(sp.second);
     }

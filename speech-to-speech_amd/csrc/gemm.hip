@@ -692,8 +692,8 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * M * N * K * nz * (g.glu ? 2 : 1),
                        ((double)N * K * sizeof(T) * (g.glu ? 2 : 1) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
 #define S2S_SK1(MTV, NFV, GLUV, NORMV)                                                                                        \
-    gemm_skinny_kernel<T, CT, MTV, NFV, GLUV, NORMV><<<grid, 512, 0, st>>>((const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, \
-                                                                           (CT*)g.C, g.ldc, M, N, K, g.act, rm, ksplit, g.rms_eps)
+    launch_k(gemm_skinny_kernel<T, CT, MTV, NFV, GLUV, NORMV>, grid, dim3(512), 0, st, (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, \
+             (CT*)g.C, g.ldc, M, N, K, g.act, rm, ksplit, g.rms_eps)
 #define S2S_SK(MTV, NFV, GLUV)                                           \
     do {                                                                 \
         if constexpr (sizeof(T) == 2) {                                  \
@@ -741,18 +741,17 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
         if (gen)
-            gemm_tile3_kernel<T, CT, true><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
-                (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            launch_k(gemm_tile3_kernel<T, CT, true>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
         else
-            gemm_tile3_kernel<T, CT, false><<<dim3(tiles_m * tiles_n, nz), 512, lds_bytes, st>>>(
-                (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            launch_k(gemm_tile3_kernel<T, CT, false>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-        gemm_tile_kernel<T, CT><<<dim3(tiles_m * tiles_n, nz), 256, 0, st>>>(
-            (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act,
-            tiles_m, rm);
+        launch_k(gemm_tile_kernel<T, CT>, dim3(tiles_m * tiles_n, nz), dim3(256), 0, st,
+                 (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
     }
     S2S_LAUNCH_CHECK();
     return S2S_OK;

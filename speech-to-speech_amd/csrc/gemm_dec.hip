@@ -320,9 +320,9 @@ int launch_dec3(hipStream_t st, const DecGemm& a) {
     const int slabs = cdiv(a.N, 16 * NF);
     const int T = cdiv(a.K >> 5, DEC_NW);
     if (UC_ALT != UC && dec_loaded_steps(T, UC_ALT) < dec_loaded_steps(T, UC))
-        gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT><<<slabs, DEC_NW * 64, 0, st>>>(a);
+        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT>, dim3(slabs), dim3(DEC_NW * 64), 0, st, a);
     else
-        gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF, NT><<<slabs, DEC_NW * 64, 0, st>>>(a);
+        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF, NT>, dim3(slabs), dim3(DEC_NW * 64), 0, st, a);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

@@ -303,14 +303,16 @@ static int finalize(Tts* m) {
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
         m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB);
         S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * std::max(E, P) * e));   // padding rows of fragment tiles must stay finite
-        int rc;
-        auto frag = [&](const std::string& wname, const char* gname, long rows, int K, void** out) -> int {
-            void* buf = nullptr;
-            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)((rows + 15) / 16 * 16) * K * e));
-            m->owned.push_back(buf);
-            *out = buf;
-            return to_frag(nullptr, TP(m, wname), K, gname ? TPF(m, gname) : nullptr, buf, (int)rows, K);
+        // The fragment-major copies ("<name>.f": s2s_op_to_frag of the projection, RMSNorm weight folded into qkv / gate-up / the
+        // predictor heads) are made once by the host side and shared by every engine replica on the GPU; the norm-free decode
+        // path is on only when all of them were registered.
+        auto fragw = [&](const std::string& name, long rows, long K, void** out) -> bool {
+            const TTensor* t = tf(m, name);
+            if (!t || t->numel != (rows + 15) / 16 * 16 * K) return false;
+            *out = const_cast<void*>(t->ptr);
+            return true;
         };
+        bool all = true;
         for (Stack* s : {&m->talker, &m->pred}) {
             const auto& sc = s->c;
             const long nq = (long)(sc.heads + 2 * sc.kv_heads) * sc.head_dim;
@@ -320,16 +322,18 @@ static int finalize(Tts* m) {
             s->down_f.assign(sc.layers, nullptr);
             for (int l = 0; l < sc.layers; ++l) {
                 const std::string p = s->prefix + std::to_string(l) + ".";
-                if ((rc = frag(p + "qkv.w", (p + "ln1").c_str(), nq, sc.hidden, &s->qkv_n[l]))) return rc;
-                if ((rc = frag(p + "gu.w", (p + "ln2").c_str(), 2L * sc.ffn, sc.hidden, &s->gu_n[l]))) return rc;
-                if ((rc = frag(p + "o.w", nullptr, sc.hidden, sc.heads * sc.head_dim, &s->o_f[l]))) return rc;
-                if ((rc = frag(p + "down.w", nullptr, sc.hidden, sc.ffn, &s->down_f[l]))) return rc;
+                all = all && fragw(p + "qkv.f", nq, sc.hidden, &s->qkv_n[l]) && fragw(p + "gu.f", 2L * sc.ffn, sc.hidden, &s->gu_n[l]) &&
+                      fragw(p + "o.f", sc.hidden, (long)sc.heads * sc.head_dim, &s->o_f[l]) && fragw(p + "down.f", sc.hidden, sc.ffn, &s->down_f[l]);
             }
         }
         m->head_n.assign(c.n_groups - 1, nullptr);
-        for (int g = 0; g < c.n_groups - 1; ++g)
-            if ((rc = frag("pred.head." + std::to_string(g) + ".w", "pred.norm", c.codebook, c.p_hidden, &m->head_n[g]))) return rc;
-        if (P != E && (rc = frag("pred.in_proj.w", nullptr, P, E, &m->in_proj_f))) return rc;
+        for (int g = 0; g < c.n_groups - 1; ++g) all = all && fragw("pred.head." + std::to_string(g) + ".f", c.codebook, c.p_hidden, &m->head_n[g]);
+        if (P != E) all = all && fragw("pred.in_proj.f", P, E, &m->in_proj_f);
+        if (!all) {   // no (or incomplete) fragment-major weights: the engine runs the rmsnorm + row-major projections path
+            m->talker.qkv_n.clear();
+            m->pred.qkv_n.clear();
+            m->head_n.clear();
+        }
         S2S_HIP_CHECK(hipDeviceSynchronize());
     }
     m->finalized = true;

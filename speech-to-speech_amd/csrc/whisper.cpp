@@ -180,20 +180,19 @@ static int finalize(Whisper* m) {
         m->mask_sup = mb; m->mask_begin = mb + c.vocab; m->mask_fill = mb + 2 * (size_t)c.vocab;
     }
     if (c.dtype == S2S_BF16 && getenv("S2S_NO_DEC_FUSION") == nullptr && d % 32 == 0 && c.ffn % 32 == 0 && d >= 256 && c.ffn >= 256 && c.dec_layers > 0) {
-        auto frag = [&](const std::string& name, long rows, int K) -> int {
-            void* buf = nullptr;
-            S2S_HIP_CHECK(hipMalloc(&buf, (size_t)((rows + 15) / 16 * 16) * K * e));
-            m->owned.push_back(buf);
-            m->fragw[name] = buf;
-            return to_frag(nullptr, P(m, name), K, nullptr, buf, (int)rows, K);
+        // fragment-major copies ("<name>.f", s2s_op_to_frag) are made once by the host side and shared by every engine replica
+        auto fragw = [&](const std::string& name, long rows, long K) -> bool {
+            const Tensor* t = find(m, name + ".f");
+            if (!t || t->numel != (rows + 15) / 16 * 16 * K) return false;
+            m->fragw[name] = const_cast<void*>(t->ptr);
+            return true;
         };
-        for (int l = 0; l < c.dec_layers; ++l) {
-            if ((rc = frag(lname("dec", l, "qkv.w"), 3 * d, (int)d)) || (rc = frag(lname("dec", l, "o.w"), d, (int)d)) || (rc = frag(lname("dec", l, "cq.w"), d, (int)d)) ||
-                (rc = frag(lname("dec", l, "co.w"), d, (int)d)) || (rc = frag(lname("dec", l, "fc1.w"), c.ffn, (int)d)) || (rc = frag(lname("dec", l, "fc2.w"), d, c.ffn)))
-                return rc;
-        }
-        if ((rc = frag("dec.tok", c.vocab, (int)d))) return rc;
-        S2S_HIP_CHECK(hipDeviceSynchronize());
+        bool all = true;
+        for (int l = 0; l < c.dec_layers; ++l)
+            all = all && fragw(lname("dec", l, "qkv.w"), 3 * d, d) && fragw(lname("dec", l, "o.w"), d, d) && fragw(lname("dec", l, "cq.w"), d, d) &&
+                  fragw(lname("dec", l, "co.w"), d, d) && fragw(lname("dec", l, "fc1.w"), c.ffn, d) && fragw(lname("dec", l, "fc2.w"), d, c.ffn);
+        all = all && fragw("dec.tok", c.vocab, d);
+        if (!all) m->fragw.clear();
     }
     m->finalized = true;
     return S2S_OK;

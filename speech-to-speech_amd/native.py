@@ -198,6 +198,19 @@ def stream_handle() -> int:
     return int(torch.cuda.current_stream().cuda_stream)
 
 
+def to_frag(w, gamma=None):
+    """Row-major bf16 [rows][K] device tensor -> the fragment-major copy the decode projections read (csrc/gemm_dec.hip): rows
+    padded to a multiple of 16 with zeros, optional norm weight ``gamma`` [K] (float32) folded into the columns."""
+    import torch
+
+    assert w.dim() == 2 and w.dtype == torch.bfloat16 and w.is_cuda and w.stride(1) == 1
+    rows, K = w.shape
+    out = torch.empty(((rows + 15) // 16 * 16) * K, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        check(load().s2s_op_to_frag(stream_handle(), ptr(w), w.stride(0), ptr(gamma), ptr(out), rows, K), "s2s_op_to_frag")
+    return out
+
+
 def dtype_code(dt) -> int:
     import torch
 

@@ -198,6 +198,31 @@ def random_tts_engine_tensors(dims: Qwen3TTSDims, dtype: torch.dtype, device: to
     return out
 
 
+def add_fragment_major_weights(tensors: dict, dims: Qwen3TTSDims) -> None:
+    """Decode-path copies of the talker / code-predictor projections in the fragment-major layout of csrc/gemm_dec.hip
+    ("<name>.f"), with the RMSNorm weight that precedes qkv / gate-up / the predictor heads folded into their columns.
+    Made once per GPU: engine replicas share them through ``TTSEngine._weights``.  No-op when they are already there or
+    when the widths do not fit the kernel (multiples of 32, >= 256)."""
+    if "talker.0.qkv.f" in tensors:
+        return
+    E, P = dims.t_hidden, dims.p_hidden
+    widths = (E, P, dims.t_ffn, dims.p_ffn, dims.t_heads * dims.t_head_dim, dims.p_heads * dims.p_head_dim)
+    if any(w % 32 or w < 256 for w in widths):
+        return
+    for pre, layers in (("talker.", dims.t_layers), ("pred.", dims.p_layers)):
+        for l in range(layers):
+            q = f"{pre}{l}."
+            tensors[q + "qkv.f"] = native.to_frag(tensors[q + "qkv.w"], tensors[q + "ln1"])
+            tensors[q + "gu.f"] = native.to_frag(tensors[q + "gu.w"], tensors[q + "ln2"])
+            tensors[q + "o.f"] = native.to_frag(tensors[q + "o.w"])
+            tensors[q + "down.f"] = native.to_frag(tensors[q + "down.w"])
+    for g in range(dims.n_groups - 1):
+        tensors[f"pred.head.{g}.f"] = native.to_frag(tensors[f"pred.head.{g}.w"], tensors["pred.norm"])
+    if P != E:
+        tensors["pred.in_proj.f"] = native.to_frag(tensors["pred.in_proj.w"])
+    torch.cuda.synchronize()
+
+
 def resample_fir_2_3(dtype=np.float32) -> np.ndarray:
     """The prototype low-pass scipy.signal.resample_poly(x, 2, 3) designs (firwin(61, 1/3, kaiser 5.0) * up)."""
     from scipy.signal import firwin
@@ -277,8 +302,10 @@ class TTSEngine:
         with torch.cuda.device(self.device):
             tensors = engine_tensors if engine_tensors is not None else convert_tts_state_dict(
                 state_dict, dims, dtype, self.max_pos, self.max_codec_frames, pad_embed)
-            for name, t in tensors.items():
-                dt = t.to(self.device)
+            tensors = {name: t.to(self.device) for name, t in tensors.items()}
+            if dtype == torch.bfloat16:
+                add_fragment_major_weights(tensors, dims)
+            for name, dt in tensors.items():
                 self._weights[name] = dt
                 native.check(self._lib.s2s_tts_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
             native.check(self._lib.s2s_tts_finalize(h), "s2s_tts_finalize")

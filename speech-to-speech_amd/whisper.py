@@ -136,8 +136,15 @@ class WhisperEngine:
         self._weights = {}
         with torch.cuda.device(self.device):
             tensors = engine_tensors if engine_tensors is not None else convert_whisper_state_dict(state_dict, dims, dtype)
-            for name, t in tensors.items():
-                dt = t.to(self.device)
+            tensors = {name: t.to(self.device) for name, t in tensors.items()}
+            if dtype == torch.bfloat16 and dims.d_model % 32 == 0 and dims.ffn % 32 == 0 and dims.d_model >= 256 and "dec.tok.f" not in tensors:
+                # decode-path copies in the fragment-major layout of csrc/gemm_dec.hip, shared by replicas through _weights
+                for l in range(dims.dec_layers):
+                    for nm in ("qkv.w", "o.w", "cq.w", "co.w", "fc1.w", "fc2.w"):
+                        tensors[f"dec.{l}.{nm}.f"] = native.to_frag(tensors[f"dec.{l}.{nm}"].view(-1, dims.ffn if nm == "fc2.w" else dims.d_model))
+                tensors["dec.tok.f"] = native.to_frag(tensors["dec.tok"].view(dims.vocab, dims.d_model))
+                torch.cuda.synchronize()
+            for name, dt in tensors.items():
                 self._weights[name] = dt   # keep alive: the engine holds raw pointers
                 native.check(self._lib.s2s_whisper_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
             native.check(self._lib.s2s_whisper_finalize(h), "s2s_whisper_finalize")
