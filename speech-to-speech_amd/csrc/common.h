@@ -5,6 +5,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 
 #include "../../include/s2s_mi355x.h"
@@ -70,6 +71,10 @@ inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds
     if (prof_current_events(&e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, e0, e1, 0, static_cast<KArgs>(args)...);
     else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);
 }
+
+// Stream captures are serialised process-wide: two threads capturing at the same time (e.g. the TTS lanes of a session pool warming up
+// together) leave the HIP runtime in hipErrorIllegalState for later launches, thread-local capture mode notwithstanding.
+std::mutex& capture_mutex();
 
 // decode loops replay captured graphs unless kernel timing is on (events cannot be recorded inside a replay)
 bool prof_active();

@@ -46,6 +46,11 @@ static hipEvent_t take_event() {
     return e;
 }
 
+std::mutex& capture_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+
 static bool g_graphs = getenv("S2S_NO_GRAPHS") == nullptr;
 bool prof_active() { return g_prof_mask != 0; }
 bool graphs_enabled() { return g_graphs; }

@@ -566,6 +566,7 @@ static int frame_graph(Tts* m, int B, hipGraphExec_t* out) {
         *out = it->second;
         return S2S_OK;
     }
+    std::lock_guard<std::mutex> capture_lock(capture_mutex());
     if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     S2S_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
     const int rc = frame_body(m, m->cap_stream, B);

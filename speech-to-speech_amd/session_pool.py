@@ -59,8 +59,15 @@ class SessionPool:
         with cls._pools_lock:
             if device not in cls._pools:
                 cls._pools[device] = cls(device, **kw)
-            elif "tts_lanes" in kw:          # the pool may have been created by the STT handler: grow to the TTS handler's lane count
-                cls._pools[device]._ensure_lanes(int(kw["tts_lanes"]))
+            else:
+                pool = cls._pools[device]
+                if "tts_lanes" in kw:        # the pool may have been created by the STT handler: grow to the TTS handler's lane count
+                    pool._ensure_lanes(int(kw["tts_lanes"]))
+                for k, v in kw.items():      # one pool per GPU: the first handler's settings stand; say so instead of silently ignoring
+                    cur = {"max_batch": pool.max_batch, "batch_window_ms": pool.batch_window_s * 1e3, "tts_chunk_size": pool.tts_chunk_size,
+                           "tts_ctx_frames": pool.tts_ctx_frames}.get(k)
+                    if cur is not None and abs(float(cur) - float(v)) > 1e-9:
+                        logger.warning("SessionPool(%s) already exists with %s=%s; ignoring %s=%s from a later handler", device, k, cur, k, v)
             return cls._pools[device]
 
     @classmethod
@@ -84,6 +91,7 @@ class SessionPool:
         self._tts_q: "queue.Queue[Any]" = queue.Queue()
         self._wake = threading.Event()
         self._engine_lock = threading.Lock()
+        self._building: dict[str, Future] = {}
         self.stats = {"stt_batches": 0, "stt_requests": 0, "tts_batches": 0, "tts_requests": 0, "max_stt_batch": 0, "tts_lanes_used": 0}
         self._stats_lock = threading.Lock()
         self._thread = threading.Thread(target=self._run, name=f"s2s-pool-{device}", daemon=True)
@@ -110,10 +118,16 @@ class SessionPool:
         with self._engine_lock:
             if name in self._engines:
                 return
-            fut: Future = Future()
-            self._stt_q.put(("build", name, factory, fut))
-            self._wake.set()
-        fut.result()
+            fut = self._building.get(name)            # a second caller waits for the build already in flight instead of starting another
+            if fut is None:
+                fut = self._building[name] = Future()
+                self._stt_q.put(("build", name, factory, fut))
+                self._wake.set()
+        try:
+            fut.result()
+        finally:
+            with self._engine_lock:
+                self._building.pop(name, None)
 
     def engine(self, name: str) -> Any:
         return self._engines[name]
@@ -128,6 +142,8 @@ class SessionPool:
 
     # ---- client API (handler threads) -----------------------------------------------------------
     def transcribe(self, model: str, audio: np.ndarray, **options) -> dict:
+        if self._stopping:
+            raise RuntimeError("SessionPool is shut down")
         req = _STTRequest(model, np.array(audio, dtype=np.float32, copy=True), options)
         self._stt_q.put(req)
         self._wake.set()
@@ -142,6 +158,8 @@ class SessionPool:
 
     def synthesize(self, prompt: Any, max_new_tokens: int) -> tuple[Iterator[np.ndarray], threading.Event]:
         """-> (iterator over int16 16 kHz chunks of one utterance, cancel event)."""
+        if self._stopping:
+            raise RuntimeError("SessionPool is shut down")
         req = _TTSRequest(prompt, int(max_new_tokens))
         self._tts_q.put(req)
         self._wake.set()
@@ -157,8 +175,27 @@ class SessionPool:
 
         return it(), req.cancelled
 
-    def shutdown(self) -> None:
+    def _fail_pending(self) -> None:
+        """Requests still queued at shutdown are failed, so no handler thread blocks forever on a future / chunk queue."""
+        err = RuntimeError("SessionPool is shut down")
+        for q in (self._stt_q, self._tts_q):
+            while True:
+                try:
+                    it = q.get_nowait()
+                except queue.Empty:
+                    break
+                if isinstance(it, _STTRequest) and not it.future.done():
+                    it.future.set_exception(err)
+                elif isinstance(it, _TTSRequest):
+                    it.chunks.put(err)
+                elif isinstance(it, tuple) and it[0] == "build" and not it[3].done():
+                    it[3].set_exception(err)
+
+    def shutdown(self, close_engines: bool = True) -> None:
+        """close_engines=False leaves the engines registered with the pool open (they belong to the caller); lane replicas the pool
+        built itself are always closed."""
         self._stopping = True
+        self._fail_pending()
         self._stt_q.put(_STOP)
         for _ in self._lanes:
             self._tts_q.put(_STOP)
@@ -166,7 +203,8 @@ class SessionPool:
         self._thread.join(timeout=10)
         for t in self._lanes:
             t.join(timeout=10)
-        for e in list(self._engines.values()) + self._lane_replicas:
+        self._fail_pending()
+        for e in (list(self._engines.values()) if close_engines else []) + self._lane_replicas:
             try:
                 e.close()
             except Exception:  # noqa: BLE001
@@ -193,7 +231,10 @@ class SessionPool:
                 continue
             if self.batch_window_s > 0 and not (isinstance(first, tuple) or first is _STOP):
                 time.sleep(self.batch_window_s)      # let concurrent sessions' finals join the batch
-            items = [first] + self._drain(self._stt_q, self.max_batch - 1)
+            cap = self.max_batch
+            if isinstance(first, _STTRequest):
+                cap = min(cap, int(getattr(self._engines.get(first.model), "max_batch", cap)))     # never hand an engine more rows than it was built for
+            items = [first] + self._drain(self._stt_q, cap - 1)
             reqs: list[_STTRequest] = []
             for it in items:
                 if it is _STOP:
@@ -284,7 +325,7 @@ class SessionPool:
                     return
             if self.batch_window_s > 0:
                 time.sleep(self.batch_window_s)
-            drained = self._drain(self._tts_q, self.max_batch - 1)
+            drained = self._drain(self._tts_q, min(self.max_batch, int(getattr(eng, "max_batch", self.max_batch))) - 1)
             for it in drained:
                 if it is _STOP:
                     self._tts_q.put(_STOP)           # leave it for shutdown handling after this batch
