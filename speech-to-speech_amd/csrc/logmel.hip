@@ -322,6 +322,7 @@ using namespace s2s;
 
 extern "C" int32_t s2s_frontend_create(int32_t kind, int32_t n_mels, const float* mel_filters_host,
                                        int32_t max_batch, void** out_frontend) {
+    std::lock_guard<std::mutex> no_capture(s2s::capture_mutex());   // synchronous uploads below: never during a stream capture
     S2S_REQUIRE(kind == S2S_FRONTEND_WHISPER || kind == S2S_FRONTEND_PARAKEET, "bad frontend kind %d", kind);
     S2S_REQUIRE(n_mels > 0 && n_mels <= 128, "n_mels %d out of range (1..128)", n_mels);
     S2S_REQUIRE(mel_filters_host && out_frontend && max_batch > 0, "null argument");

@@ -479,6 +479,9 @@ extern "C" int32_t s2s_whisper_set_tensor(void* model, const char* name, const v
 }
 
 extern "C" int32_t s2s_whisper_finalize(void* model) {
+    // workspace allocation uses synchronous (legacy-stream) memsets / copies, which HIP refuses - and which poison the other thread's
+    // capture - while any stream of the process is capturing: take the capture lock
+    std::lock_guard<std::mutex> no_capture(s2s::capture_mutex());
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m, "whisper_finalize: null model");
     if (m->finalized) return S2S_OK;
