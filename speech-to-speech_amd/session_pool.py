@@ -221,7 +221,11 @@ class SessionPool:
         return items
 
     def _run(self) -> None:
-        """STT worker (also builds the engines, so that model loading stays on one thread)."""
+        """STT worker (also builds the engines, so that model loading stays on one thread).  Like the TTS lanes it issues all its GPU
+        work - including the host-to-device copies of the utterances - on its own HIP stream: anything on the legacy default stream
+        would collide with (and poison) a lane's stream capture."""
+        ctx = self._lane_stream_ctx()
+        ctx.__enter__()
         while True:
             try:
                 first = self._stt_q.get(timeout=0.05)
