@@ -49,3 +49,10 @@ class MI355XQwen3TTSHandlerArguments:
     qwen3_tts_batch_window_ms: float = field(default=4.0)
     qwen3_tts_lanes: int = field(default=3, metadata={"help": "TTS turn-batches in flight per GPU (engine replicas sharing the weights, one HIP stream each)."})
     qwen3_tts_codec_context_frames: int = field(default=25)
+
+
+@dataclass
+class EchoLLMHandlerArguments:
+    """``--llm echo``: replies with the user's own transcript (benchmarks / BASELINE config C1)."""
+
+    echo_llm_prefix: str = field(default="", metadata={"help": "Text put in front of the echoed transcript."})

@@ -70,6 +70,39 @@ class TTSInput(PipelineMessage):
     prefetch_transaction: Any = Field(default=None, exclude=True, repr=False)
 
 
+class GenerateResponseRequest(PipelineMessage):
+    """Triggers LLM generation (reference pipeline/messages.py:334-355; the fields the echo stub reads)."""
+
+    tag: Literal["generate_response"] = "generate_response"
+    response_key: str = Field(default="", exclude=True, repr=False)
+    runtime_config: Any = None
+    response: Any = None
+    audio: Any = None
+    language_code: Optional[str] = None
+    turn_id: str | None = None
+    turn_revision: int | None = None
+    speech_stopped_at_s: float | None = None
+    prefetch_transaction: Any = Field(default=None, exclude=True, repr=False)
+
+
+class LLMResponseChunk(PipelineMessage):
+    """One ordered group of assistant output parts (reference pipeline/messages.py:137-157)."""
+
+    tag: Literal["llm_response_chunk"] = "llm_response_chunk"
+    parts: list = Field(default_factory=list)
+    text: str = ""
+    language_code: Optional[str] = None
+    tools: list = Field(default_factory=list)
+    runtime_config: Any = None
+    response: Any = None
+    turn_id: str | None = None
+    turn_revision: int | None = None
+    speech_stopped_at_s: float | None = None
+    cancel_generation: int | None = None
+    response_key: str | None = Field(default=None, exclude=True, repr=False)
+    prefetch_transaction: Any = Field(default=None, exclude=True, repr=False)
+
+
 class EndOfResponse(PipelineMessage):
     tag: Literal["end_of_response"] = "end_of_response"
     turn_id: str | None = None

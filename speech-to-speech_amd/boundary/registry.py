@@ -75,7 +75,8 @@ except Exception:  # noqa: BLE001
             return normalize_dataclass_config(config, self.config_prefix)
 
 
-from ..arguments import MI355XParakeetSTTHandlerArguments, MI355XQwen3TTSHandlerArguments, MI355XWhisperSTTHandlerArguments  # noqa: E402
+from ..arguments import (EchoLLMHandlerArguments, MI355XParakeetSTTHandlerArguments, MI355XQwen3TTSHandlerArguments,  # noqa: E402
+                         MI355XWhisperSTTHandlerArguments)
 
 
 def _load(module: str, cls: str):
@@ -115,9 +116,26 @@ MI355X_STT_BACKENDS = (
 MI355X_TTS_BACKENDS = (BackendSpec("mi355x-qwen3", "tts", MI355XQwen3TTSHandlerArguments, _create_tts, config_prefix="qwen3_tts"),)
 
 
-def register_mi355x_backends(stt_registry: dict, tts_registry: dict) -> None:
-    """The two lines a maintainer adds after STT_BACKENDS / TTS_BACKENDS are built."""
+def _create_echo_llm(context: Any, config: Mapping[str, Any]):
+    kwargs = dict(config)
+    kwargs["cancel_scope"] = context.cancel_scope
+    kwargs["speculative_turns"] = context.speculative_turns
+    handler = _load("speech_to_speech_amd.handlers.echo_llm", "EchoLLMHandler")(context.stop_event, queue_in=context.queue_in, queue_out=context.queue_out,
+                                                                                setup_kwargs=kwargs)
+    handler.pipeline_index = context.pipeline_index
+    return handler
+
+
+# the stub LLM of BASELINE config C1 / the benchmarks (precedent tests/test_backend_registry.py:153-170)
+ECHO_LLM_BACKENDS = (BackendSpec("echo", "llm", EchoLLMHandlerArguments, _create_echo_llm, config_prefix="echo_llm"),)
+
+
+def register_mi355x_backends(stt_registry: dict, tts_registry: dict, llm_registry: dict | None = None) -> None:
+    """The lines a maintainer adds after STT_BACKENDS / TTS_BACKENDS / LLM_BACKENDS are built."""
     for spec in MI355X_STT_BACKENDS:
         stt_registry[spec.name] = spec
     for spec in MI355X_TTS_BACKENDS:
         tts_registry[spec.name] = spec
+    if llm_registry is not None:
+        for spec in ECHO_LLM_BACKENDS:
+            llm_registry[spec.name] = spec

@@ -437,3 +437,53 @@ def test_warm_tts_lanes_builds_and_warms_every_lane_before_the_first_request():
         assert len(warmed) == 3                     # serving does not warm again
     finally:
         p.shutdown()
+
+
+# ---- stub LLM and OpenAI-compatible server mode ---------------------------------------------------
+def test_echo_llm_backend_spec_honours_the_llm_contract():
+    from types import SimpleNamespace
+
+    from speech_to_speech_amd.boundary import GenerateResponseRequest, LLMResponseChunk
+
+    llm = {}
+    registry.register_mi355x_backends({}, {}, llm)
+    spec = llm["echo"]
+    assert spec.kind == "llm"
+    cs = CancelScope()
+    cs.cancel()                                  # generation 1: the stub must capture the CURRENT generation
+    ctx = registry.HandlerContext(stop_event=Event(), queue_in=Queue(), queue_out=Queue(), text_output_queue=Queue(), should_listen=Event(), cancel_scope=cs,
+                                  speculative_turns=None, pipeline_index=0, sample_rate=16000, enable_live_transcription=False,
+                                  live_transcription_update_interval=0.5)
+    h = spec.create_handler(ctx, spec.normalize(spec.config_type(echo_llm_prefix="")))
+    chat = SimpleNamespace(buffer=[SimpleNamespace(role="user", content=[SimpleNamespace(text="first")]), SimpleNamespace(role="assistant", content="x"),
+                                   {"role": "user", "content": [{"type": "input_text", "text": "hello there"}]}])
+    req = GenerateResponseRequest(response_key="rk", runtime_config=SimpleNamespace(chat=chat), turn_id="t", turn_revision=2, language_code="en",
+                                  speech_stopped_at_s=1.5)
+    out = list(h.process(req))
+    assert isinstance(out[0], LLMResponseChunk) and isinstance(out[1], EndOfResponse) and len(out) == 2
+    assert (out[0].text, out[0].turn_id, out[0].turn_revision, out[0].cancel_generation, out[0].response_key, out[0].speech_stopped_at_s) == \
+        ("hello there", "t", 2, 1, "rk", 1.5)
+    assert (out[1].turn_id, out[1].turn_revision, out[1].cancel_generation, out[1].response_key) == ("t", 2, 1, "rk")
+
+
+def test_openai_compatible_server_serves_the_reference_client_request(pool):
+    """The request the reference's --stt openai client posts (STT/openai_compatible_handler.py:57-80: multipart `file` = mono PCM16
+    WAV, `model`, `language`, `response_format`) is answered from the session pool; the TTS route streams int16 PCM."""
+    from starlette.testclient import TestClient
+
+    from speech_to_speech_amd.server import create_app, float_pcm16_wav
+    from speech_to_speech_amd.tts import TTSPrompt
+
+    app = create_app(pool, "whisper", tokenizer=IdTextCodec(), tts_prompt=lambda text: TTSPrompt(np.zeros((4, 8), np.float32)), tts_max_new_tokens=16)
+    client = TestClient(app)
+    wav = float_pcm16_wav((np.zeros(1697) * 32767).astype(np.int16))
+    r = client.post("/v1/audio/transcriptions", data={"model": "nvidia/parakeet-tdt-0.6b-v3", "language": "de", "response_format": "json"},
+                    files={"file": ("audio.wav", wav, "audio/wav")})
+    assert r.status_code == 200 and r.json() == {"text": f"t{1697 % 97} t5", "language": "de"}
+    r = client.post("/v1/audio/transcriptions", data={"response_format": "text"}, files={"file": ("audio.wav", wav, "audio/wav")})
+    assert r.status_code == 200 and r.text == f"t{1697 % 97} t5"
+    assert client.post("/v1/audio/transcriptions", data={"model": "x"}).status_code == 400
+    r = client.post("/v1/audio/speech", json={"input": "Hello.", "response_format": "pcm"})
+    pcm = np.frombuffer(r.content, dtype="<i2")
+    assert r.status_code == 200 and len(pcm) == 3 * 700 and set(pcm.tolist()) == {3000, 3001, 3002}
+    assert client.get("/health").json()["status"] == "ok"
