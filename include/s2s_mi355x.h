@@ -366,6 +366,16 @@ int32_t s2s_resample_24k16k_int16(void* stream, const float* pcm24_dev, int64_t 
                                   const float* fir_dev, int32_t taps, int32_t delay, int16_t* out16_dev, float* outf_dev,
                                   int64_t out_stride, int32_t n_out_max, int32_t B);
 
+/* API-edge resampling: batched scipy.signal.resample_poly(x, up, down) per row followed by
+ * clip(y * 32768).astype(int16) - the reference's resample() of api/openai_realtime/utils.py:5-12, which handlers/audio.py runs per
+ * chunk per session on the asyncio thread (:122-149 client rate -> 16 kHz in, :293-330 16 kHz -> client rate out).
+ *   in_dev: int16 [B][in_stride] (in_is_int16 != 0; samples are int16 / 32768 exactly as the reference converts them) or float32;
+ *   n_in_dev: optional int32 [B] valid samples per row; fir_dev: the host-designed prototype (scipy's firwin(2*10*max(up,down)+1,
+ *   1/max(up,down), kaiser 5.0) * up), odd length; n_out per row = ceil(n_in * up / down), rows are zero-filled up to n_out_max. */
+int32_t s2s_resample_poly_int16(void* stream, const void* in_dev, int32_t in_is_int16, int64_t in_stride, const int32_t* n_in_dev, int32_t up,
+                                int32_t down, const float* fir_dev, int32_t taps, int16_t* out16_dev, float* outf_dev, int64_t out_stride,
+                                int32_t n_out_max, int32_t B);
+
 #ifdef __cplusplus
 }
 #endif

@@ -458,7 +458,60 @@ int resample_2_3_int16(hipStream_t st, const float* x, long x_bs, const int* n_i
     return S2S_OK;
 }
 
+// ---- general polyphase resampler for the API edge (client rate <-> 16 kHz pipeline rate) -----------------------------------------
+// scipy.signal.resample_poly(x, up, down) per row, then clip(y * 32768).astype(int16): the reference's api/openai_realtime/utils.py:5-12.
+// y[m] = sum_i x[i] * h[down*m + off - up*i]; h (taps, host-designed like scipy: firwin(2*10*max(up,down)+1, 1/max(up,down), kaiser 5) * up),
+// off = (taps - 1) / 2.  IN = short: samples are int16 / 32768 (exact).  Same tap order / separately rounded multiply-add as upfirdn (float32).
+template <typename IN>
+__global__ void resample_poly_kernel(const IN* __restrict__ x, long x_bs, const int* __restrict__ n_in, int up, int down, const float* __restrict__ h,
+                                     int taps, int off, short* __restrict__ y16, float* __restrict__ yf, long y_bs, int n_out_max) {
+    const int b = blockIdx.y;
+    const int n = n_in ? n_in[b] : (int)x_bs;
+    const int n_out = (int)(((long)n * up + down - 1) / down);
+    const IN* xb = x + (long)b * x_bs;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n_out_max; m += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        if (m < n_out) {
+            const long c = (long)down * m + off;
+            long lo = c - taps + 1;
+            int i_lo = lo <= 0 ? 0 : (int)((lo + up - 1) / up);
+            const int i_hi = (int)min((long)(c / up), (long)n - 1);
+            for (int i = i_lo; i <= i_hi; ++i) {
+                float xv;
+                if constexpr (sizeof(IN) == 2) xv = (float)xb[i] * (1.0f / 32768.0f);
+                else xv = xb[i];
+                acc = __fadd_rn(acc, __fmul_rn(xv, h[c - (long)up * i]));
+            }
+        }
+        if (yf) yf[(long)b * y_bs + m] = acc;
+        if (y16) {
+            const float s = fminf(fmaxf(acc * 32768.0f, -32768.0f), 32767.0f);
+            y16[(long)b * y_bs + m] = (short)s;   // truncation toward zero == numpy astype(int16)
+        }
+    }
+}
+
 }  // namespace s2s
+
+/* Batched scipy.signal.resample_poly(x, up, down) + clip(y*32768).astype(int16) for the API edge (reference
+ * api/openai_realtime/utils.py:5-12, used by handlers/audio.py:122-149 on input and :293-330 on output).  in_is_int16 != 0: in_dev is
+ * int16 [B][in_stride] (treated as int16 / 32768, exactly like the reference), else float32.  n_out per row = ceil(n_in * up / down). */
+extern "C" int32_t s2s_resample_poly_int16(void* stream, const void* in_dev, int32_t in_is_int16, int64_t in_stride, const int32_t* n_in_dev, int32_t up,
+                                           int32_t down, const float* fir_dev, int32_t taps, int16_t* out16_dev, float* outf_dev, int64_t out_stride,
+                                           int32_t n_out_max, int32_t B) {
+    S2S_REQUIRE(in_dev && fir_dev && (out16_dev || outf_dev) && taps > 0 && (taps & 1) && up > 0 && down > 0, "resample_poly: bad arguments");
+    if (B == 0 || n_out_max <= 0) return S2S_OK;
+    dim3 grid(std::min(s2s::cdiv(n_out_max, 256), 1024), B);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_is_int16)
+        s2s::resample_poly_kernel<short><<<grid, 256, 0, st>>>((const short*)in_dev, (long)in_stride, n_in_dev, up, down, fir_dev, taps, (taps - 1) / 2,
+                                                              (short*)out16_dev, outf_dev, (long)out_stride, n_out_max);
+    else
+        s2s::resample_poly_kernel<float><<<grid, 256, 0, st>>>((const float*)in_dev, (long)in_stride, n_in_dev, up, down, fir_dev, taps, (taps - 1) / 2,
+                                                              (short*)out16_dev, outf_dev, (long)out_stride, n_out_max);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
 
 extern "C" int32_t s2s_resample_24k16k_int16(void* stream, const float* pcm24_dev, int64_t in_stride, const int32_t* n_in_dev,
                                              const float* fir_dev, int32_t taps, int32_t delay, int16_t* out16_dev, float* outf_dev,

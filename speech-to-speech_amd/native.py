@@ -114,6 +114,7 @@ _SIGNATURES = {
     "s2s_codec_stream_reset": [_vp],
     "s2s_codec_stream_decode": [_vp, _vp, _vp, _i32, _i32, _vp, _i32],
     "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
+    "s2s_resample_poly_int16": [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
