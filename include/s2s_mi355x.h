@@ -337,6 +337,17 @@ int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_de
  * min_total_frames frames; *all_done_host (optional, forces a stream sync) = 1 when every session has ended. */
 int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
                          int32_t* n_frames_dev, int32_t* all_done_host);
+/* Sampling of the frame loop (the reference's backend samples; greedy is the parity policy and the default).  which: 0 = talker
+ * (codebook 0; the repetition penalty covers the utterance's earlier codebook-0 picks), 1 = code predictor (residual groups).
+ * Processor order = transformers generate(): repetition penalty -> temperature -> top-k -> top-p -> seeded multinomial
+ * (counter-based uniform of (seed, session, frame, group): reproducible, independent of batch composition).  temperature <= 0
+ * restores greedy.  Re-captures the frame graphs on the next generate call. */
+int32_t s2s_tts_set_sampling(void* model, int32_t which, float temperature, int32_t top_k, float top_p, float repetition_penalty,
+                             uint64_t seed);
+/* The frame loop's sampler on plain rows (tests): out_dev int32 [B] = one token per row of logits_dev f32 [B][V], V <= 4096; row b
+ * draws the counter-based uniform of (seed, b); hist_dev optional int32 [B][n_hist] (repetition penalty). */
+int32_t s2s_op_sample_tokens(void* stream, const float* logits_dev, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
+                             float repetition_penalty, uint64_t seed, const int32_t* hist_dev, int32_t n_hist, int32_t* out_dev);
 /* Teacher-forced continuation (continuing given codec frames in context; the parity tests' teacher-forced logits): like
  * s2s_tts_generate, but every code of the n_frames new frames whose entry in forced_codes_dev int32 [B][n_frames][n_groups]
  * is >= 0 is emitted (and fed back to the code predictor / talker) instead of the greedy pick, and the raw logits of every

@@ -121,6 +121,16 @@ struct PickDebug {
     int f0, n_log, Vlog;
 };
 
+// Sampling of the TTS frame loop (tts.hip pick kernels).  temperature <= 0 selects the greedy argmax (the parity policy).
+// Order of the processors = transformers' generate(): repetition penalty -> temperature -> top-k -> top-p -> multinomial.
+struct SampleParams {
+    float temperature;      // > 0: sample
+    int top_k;              // 0: off
+    float top_p;            // >= 1: off
+    float rep_penalty;      // 1: off; applied to the codes already emitted for this group in the current utterance
+    unsigned long long seed;
+};
+
 // conformer.hip
 struct TdtState {
     int* frame;      // [B] encoder frame pointer

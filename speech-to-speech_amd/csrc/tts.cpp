@@ -28,9 +28,10 @@ int add_int(hipStream_t st, int* p, int v, int n);
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
-                const PickDebug& dbg);
+                const PickDebug& dbg, const SampleParams& sp);
 int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg);
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg,
+              const SampleParams& sp);
 int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
 int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
@@ -102,6 +103,7 @@ struct Tts {
     // norm-free decode path (gemm_dec.hip): bf16 copy of the residual rows + two partial-sum-of-squares buffers
     void* xb = nullptr;                // [DEC_ROWS][max hidden] model dtype
     float *ssA = nullptr, *ssB = nullptr;   // [SS_PARTS][DEC_ROWS]
+    SampleParams sp_talker{0.f, 0, 1.f, 1.f, 0ull}, sp_pred{0.f, 0, 1.f, 1.f, 0ull};   // temperature 0: greedy (s2s_tts_set_sampling)
     PickDebug dbg{};                   // teacher forcing / logit capture (s2s_tts_generate_forced); null on the serving path
     int* forced_buf = nullptr;         // [max_batch][max_frames][G], allocated on first forced call
     int ss_parts_A = 0;                // parts currently valid in ssA (written by the last residual projection / rows_prep)
@@ -486,7 +488,7 @@ static int talker_head(Tts* m, hipStream_t st, int B) {
     // x's hidden rows are consumed (hn); the pick writes the next talker input over them
     return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_dev,
                        m->min_dev, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
-                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg);
+                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg, m->sp_talker);
 }
 
 // run the code predictor for the current frame; the residual groups' embeddings accumulate into the next talker input (m->x)
@@ -536,7 +538,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         // dec: logits hold all M rows (row b * T_len + T_len - 1 is session b's); the next pass's input row is written fragment-major
         const bool next_dec = g + 1 < G - 1 && dec_fusion_ok(m, m->pred, B) && P != E;
         if ((rc = pred_pick(st, dec ? m->logits + (size_t)(T_len - 1) * CB : m->logits, CB, dec ? (long)T_len * CB : (long)CB, m->frame_dev, m->finished, m->codes_out,
-                            c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)), m->x, m->pin, m->pin_t, E, next_dec, B, dt, m->dbg))) return rc;
+                            c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)), m->x, m->pin, m->pin_t, E, next_dec, B, dt, m->dbg, m->sp_pred))) return rc;
     }
     return S2S_OK;
 }
@@ -704,6 +706,22 @@ static int32_t tts_generate_impl(Tts* m, hipStream_t st, int32_t n_frames, int32
         for (int b = 0; b < B; ++b) all &= m->host_flag[b] != 0;
         *all_done_host = all;
     }
+    return S2S_OK;
+}
+
+// Sampling of the frame loop.  which: 0 = talker (code 0; repetition penalty over the utterance's earlier code-0 picks), 1 = code
+// predictor (residual groups).  temperature <= 0 -> greedy argmax (default, the parity policy).  The captured frame graphs hold the
+// parameters by value, so they are dropped and re-captured on the next generate call.
+extern "C" int32_t s2s_tts_set_sampling(void* model, int32_t which, float temperature, int32_t top_k, float top_p, float repetition_penalty,
+                                        uint64_t seed) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && (which == 0 || which == 1), "tts_set_sampling: bad arguments");
+    S2S_REQUIRE(top_k >= 0 && top_p > 0.f && repetition_penalty > 0.f, "tts_set_sampling: top_k >= 0, top_p > 0, repetition_penalty > 0");
+    SampleParams sp{temperature, top_k, top_p, repetition_penalty, (unsigned long long)seed};
+    (which == 0 ? m->sp_talker : m->sp_pred) = sp;
+    std::lock_guard<std::mutex> capture_lock(capture_mutex());
+    for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
+    m->frame_graphs.clear();
     return S2S_OK;
 }
 

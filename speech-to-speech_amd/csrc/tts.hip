@@ -181,6 +181,165 @@ __device__ __forceinline__ void pick_debug(const PickDebug& d, const float* __re
     }
 }
 
+// ---- seeded sampling (one 256-thread block per session row) ---------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {   // splitmix64 finaliser: counter-based, stateless
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Sample one token from logits row `row` (V <= 4096) with transformers' processor order: repetition penalty (over hist[0 .. n_hist),
+// stride hist_stride; negative entries skipped) -> temperature -> top-k (ties at the k-th value are kept, like HF) -> top-p (smallest
+// set of most likely tokens whose mass exceeds top_p, at least one) -> multinomial with the counter-based uniform u(seed, key).
+// mask / mask2: optional suppress masks (-inf).  Dynamic LDS: float[V] + float[8].  Every thread returns the same token.
+__device__ int block_sample_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask, const unsigned char* __restrict__ mask2,
+                                const int* __restrict__ hist, int n_hist, int hist_stride, const SampleParams sp, unsigned long long key) {
+    extern __shared__ __attribute__((aligned(16))) float smp[];
+    float* sl = smp;            // [V] processed logits, then probabilities
+    float* red = smp + V;       // [8]
+    const int tid = threadIdx.x;
+    for (int v = tid; v < V; v += 256) {
+        float x = row[v];
+        if ((mask && mask[v]) || (mask2 && mask2[v])) x = -INFINITY;
+        sl[v] = x;
+    }
+    __syncthreads();
+    if (sp.rep_penalty != 1.0f && hist) {   // each distinct previously emitted token is penalised once (first occurrence does it)
+        for (int f = tid; f < n_hist; f += 256) {
+            const int t = hist[(long)f * hist_stride];
+            if (t < 0 || t >= V) continue;
+            bool first = true;
+            for (int q = 0; q < f; ++q)
+                if (hist[(long)q * hist_stride] == t) { first = false; break; }
+            if (first) {
+                const float x = sl[t];
+                sl[t] = x > 0.f ? x / sp.rep_penalty : x * sp.rep_penalty;
+            }
+        }
+        __syncthreads();
+    }
+    const float inv_t = 1.0f / sp.temperature;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) {
+        const float x = sl[v] * inv_t;
+        sl[v] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    // top-k: largest threshold (in the order-preserving integer image of float) that still keeps >= k values
+    if (sp.top_k > 0 && sp.top_k < V) {
+        unsigned lo = 0u, hi = 0xffffffffu;          // invariant: count(key >= lo) >= k
+        for (int it = 0; it < 32; ++it) {
+            const unsigned mid = lo + (unsigned)(((unsigned long long)hi - lo + 1) >> 1);
+            float c = 0.f;
+            for (int v = tid; v < V; v += 256) c += f32_ordered(sl[v]) >= mid ? 1.f : 0.f;
+            c = block_sum_256(c, red);
+            if (c >= (float)sp.top_k) lo = mid; else hi = mid - 1;
+            if (lo == hi) break;
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += 256)
+            if (f32_ordered(sl[v]) < lo) sl[v] = -INFINITY;
+        __syncthreads();
+    }
+    // probabilities
+    float z = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        const float p = sl[v] == -INFINITY ? 0.f : __expf(sl[v] - mx);
+        sl[v] = p;
+        z += p;
+    }
+    z = block_sum_256(z, red);
+    // top-p: keep p_i iff the mass of tokens at least as likely as i ... i.e. drop the low tail whose cumulative mass <= 1 - top_p
+    float thr = 0.f;      // probabilities >= thr are kept
+    if (sp.top_p < 1.0f) {
+        const float tail = (1.0f - sp.top_p) * z;
+        unsigned lo = 0u, hi = __float_as_uint(1.0f);        // probabilities are in [0, 1]: positive floats order like their bits
+        // largest threshold whose strictly-lower tail mass is <= tail (the most likely token always stays)
+        for (int it = 0; it < 31; ++it) {
+            const unsigned mid = lo + ((hi - lo + 1) >> 1);
+            const float t = __uint_as_float(mid);
+            float m = 0.f;
+            for (int v = tid; v < V; v += 256) m += sl[v] < t ? sl[v] : 0.f;
+            m = block_sum_256(m, red);
+            if (m <= tail) lo = mid; else hi = mid - 1;
+            if (lo == hi) break;
+        }
+        thr = __uint_as_float(lo);
+        float pm = 0.f;
+        for (int v = tid; v < V; v += 256) pm = fmaxf(pm, sl[v]);
+        pm = wave_max(pm);
+        __syncthreads();
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = pm;
+        __syncthreads();
+        thr = fminf(thr, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        __syncthreads();
+        float z2 = 0.f;
+        for (int v = tid; v < V; v += 256) {
+            if (sl[v] < thr) sl[v] = 0.f;
+            z2 += sl[v];
+        }
+        z = block_sum_256(z2, red);
+    }
+    // multinomial in index order: thread t owns the contiguous range [t*per, (t+1)*per)
+    const unsigned long long r = mix64(sp.seed ^ mix64(key));
+    const float u = (float)((r >> 40) + 0.5) * (1.0f / 16777216.0f) * z;     // in (0, z)
+    const int per = (V + 255) / 256;
+    float loc = 0.f;
+    for (int j = 0; j < per; ++j) {
+        const int v = tid * per + j;
+        if (v < V) loc += sl[v];
+    }
+    // exclusive scan of the 256 partial sums (wave scan + wave offsets)
+    float inc = loc;
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += n;
+    }
+    __syncthreads();
+    if ((tid & 63) == 63) red[tid >> 6] = inc;
+    __syncthreads();
+    float base = 0.f;
+    for (int w = 0; w < (tid >> 6); ++w) base += red[w];
+    const float excl = base + inc - loc;
+    __shared__ int chosen;
+    if (tid == 0) chosen = -1;
+    __syncthreads();
+    if (loc > 0.f && u >= excl && u < excl + loc) {
+        float c = excl;
+        int pick = -1;
+        for (int j = 0; j < per; ++j) {
+            const int v = tid * per + j;
+            if (v < V && sl[v] > 0.f) {
+                pick = v;
+                c += sl[v];
+                if (u < c) break;
+            }
+        }
+        chosen = pick;
+    }
+    __syncthreads();
+    if (chosen < 0) {        // u fell on a rounding seam: take the most likely kept token
+        __syncthreads();
+        int best = block_argmax_256(sl, V, nullptr, nullptr);
+        return best;
+    }
+    return chosen;
+}
+
 // Talker pick (one block per session): code 0 = argmax over the codec vocabulary (specials suppressed; eos too while
 // frame < min_frames), eos / frame bookkeeping, then the inputs that depend on it:
 //   xnext[b] = talker_emb[code0] + pad_embed          (next talker input, residual-group embeddings are added later)
@@ -193,10 +352,15 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
                                                           int* __restrict__ codes_out, int max_frames, int G,
                                                           const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
                                                           float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E,
-                                                          int pin_frag, PickDebug dbg) {
+                                                          int pin_frag, PickDebug dbg, SampleParams sp) {
     const int b = blockIdx.x;
     const int frame = *frame_dev;
-    int code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
+    int code;
+    if (sp.temperature > 0.f)      // seeded sampling; the repetition penalty looks at this session's earlier code-0 picks
+        code = block_sample_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr, codes_out + (long)b * max_frames * G, frame, G, sp,
+                                ((unsigned long long)b << 40) ^ ((unsigned long long)frame << 8));
+    else
+        code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
     pick_debug(dbg, logits + (long)b * V, V, b, frame, 0, max_frames, G, code);
     if (threadIdx.x == 0) {
         int f = finished[b];
@@ -224,9 +388,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, long logits_rs, const int* __restrict__ frame_dev,
                                                         const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
                                                         int G, int g, const T* __restrict__ emb, float* __restrict__ xnext,
-                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E, int pin_frag, PickDebug dbg) {
+                                                        float* __restrict__ pin, T* __restrict__ pin_t, int E, int pin_frag, PickDebug dbg,
+                                                        SampleParams sp) {
     const int b = blockIdx.x;
-    int code = block_argmax_256(logits + (long)b * logits_rs, V, nullptr, nullptr);
+    int code;
+    if (sp.temperature > 0.f)
+        code = block_sample_256(logits + (long)b * logits_rs, V, nullptr, nullptr, nullptr, 0, 0, sp,
+                                ((unsigned long long)b << 40) ^ ((unsigned long long)(*frame_dev) << 8) ^ (unsigned long long)g);
+    else
+        code = block_argmax_256(logits + (long)b * logits_rs, V, nullptr, nullptr);
     pick_debug(dbg, logits + (long)b * logits_rs, V, b, *frame_dev, g, max_frames, G, code);
     if (threadIdx.x == 0) codes_out[((long)b * max_frames + *frame_dev) * G + g] = finished[b] ? -1 : code;
     const T* row = emb + (long)code * E;
@@ -247,18 +417,23 @@ __global__ void tts_frame_end_kernel(int* pos_t, int* frame_dev, int B) {
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
-                const PickDebug& dbg) {
-    S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
-                                                         codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E,
-                                                         pin_frag ? 1 : 0, dbg)));
+                const PickDebug& dbg, const SampleParams& sp) {
+    S2S_REQUIRE(sp.temperature <= 0.f || V <= 4096, "talker_pick: sampling supports vocabularies up to 4096 entries");
+    const size_t lds = sp.temperature > 0.f ? sizeof(float) * (V + 8) : 0;
+    S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
+                                                           codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E,
+                                                           pin_frag ? 1 : 0, dbg, sp)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
 int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
-              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg) {
-    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, 0, st>>>(logits, V, logits_rs, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
-                                                       pin, (TT*)pin_t, E, pin_frag ? 1 : 0, dbg)));
+              int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg,
+              const SampleParams& sp) {
+    S2S_REQUIRE(sp.temperature <= 0.f || V <= 4096, "pred_pick: sampling supports vocabularies up to 4096 entries");
+    const size_t lds = sp.temperature > 0.f ? sizeof(float) * (V + 8) : 0;
+    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, logits_rs, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
+                                                         pin, (TT*)pin_t, E, pin_frag ? 1 : 0, dbg, sp)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -492,6 +667,26 @@ __global__ void resample_poly_kernel(const IN* __restrict__ x, long x_bs, const 
 }
 
 }  // namespace s2s
+
+namespace s2s {
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ logits, int V, const int* __restrict__ hist, int n_hist, SampleParams sp,
+                                                          int* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int t = block_sample_256(logits + (long)b * V, V, nullptr, nullptr, hist ? hist + (long)b * n_hist : nullptr, n_hist, 1, sp, (unsigned long long)b);
+    if (threadIdx.x == 0) out[b] = t;
+}
+}  // namespace s2s
+
+/* Public op (tests): one sampled token per row of logits f32 [B][V] (V <= 4096) with the frame loop's sampler; row b uses the
+ * counter-based uniform of (seed, b).  hist_dev: optional int32 [B][n_hist] tokens the repetition penalty applies to. */
+extern "C" int32_t s2s_op_sample_tokens(void* stream, const float* logits_dev, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
+                                        float repetition_penalty, uint64_t seed, const int32_t* hist_dev, int32_t n_hist, int32_t* out_dev) {
+    S2S_REQUIRE(logits_dev && out_dev && B > 0 && V > 0 && V <= 4096 && temperature > 0.f && top_p > 0.f && repetition_penalty > 0.f, "op_sample_tokens: bad arguments");
+    s2s::SampleParams sp{temperature, top_k, top_p, repetition_penalty, (unsigned long long)seed};
+    s2s::sample_rows_kernel<<<B, 256, sizeof(float) * (V + 8), (hipStream_t)stream>>>(logits_dev, V, hist_dev, n_hist, sp, out_dev);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
 
 /* Batched scipy.signal.resample_poly(x, up, down) + clip(y*32768).astype(int16) for the API edge (reference
  * api/openai_realtime/utils.py:5-12, used by handlers/audio.py:122-149 on input and :293-330 on output).  in_is_int16 != 0: in_dev is

@@ -58,9 +58,24 @@ def build_tts_engine(model_name: str, device: str, dtype: str, max_batch: int, m
     from ..tts import TTSEngine
 
     kind, key, seed = parse_model_name(model_name)
-    if kind != "synthetic":
-        raise NotImplementedError("loading a real Qwen3-TTS checkpoint needs its (unavailable offline) config / prompt layout; "
-                                  "see DESIGN.md 'Qwen3-TTS assumptions'")
+    if kind == "dir":
+        # a checkpoint directory: config.json -> dims, safetensors -> the converter's names (name_map.json may extend the rules),
+        # prompt_layout.json -> prompt assembly; see qwen3_tts_checkpoint.py for what is verified and what is not
+        from ..qwen3_tts_checkpoint import TableTextFrontend, load_qwen3_tts_checkpoint
+        from ..text import load_tokenizer
+
+        dims, sd, layout, text = load_qwen3_tts_checkpoint(key)
+        pad = text["text.pad_embed"] if text and "text.pad_embed" in text else torch.zeros(dims.t_hidden)
+        eng = TTSEngine(dims, sd, dtype=getattr(torch, dtype), max_batch=max_batch, max_prompt=128, max_frames=max_new_tokens,
+                        max_codec_frames=ctx_frames + chunk_size, pad_embed=pad, device=device)
+        if not text or "text.embedding.weight" not in text:
+            raise KeyError(f"{key}: the checkpoint has no text embedding table ('text.embedding.weight' after name mapping)")
+        proj = None
+        if "text.proj.0.weight" in text:
+            proj = [(text["text.proj.0.weight"].numpy(), text["text.proj.0.bias"].numpy()), (text["text.proj.1.weight"].numpy(), text["text.proj.1.bias"].numpy())]
+        tok = load_tokenizer(key)
+        eng.text_frontend = TableTextFrontend(text["text.embedding.weight"].numpy(), layout, tok if hasattr(tok, "encode") and not isinstance(tok, __import__("speech_to_speech_amd.text", fromlist=["IdTextCodec"]).IdTextCodec) else None, proj)
+        return eng
     dims = TTS_DIMS[key]()
     sd = qwen3_tts_state_dict(dims, seed=seed or 5)
     pad = _normal(seed or 5, "tts_pad_embed", (dims.t_hidden,), 0.5)
@@ -139,6 +154,26 @@ class MI355XQwen3TTSHandler(BaseHandler):
         eng = self.pool.engine("tts")
         return TTSPrompt(eng.text_frontend.embed(text, eng.max_prompt))
 
+    def _build_prompts(self, text: str) -> list[tuple[str, TTSPrompt]]:
+        """One prompt per piece of text that fits the engine's prefill budget.  An over-long input is split at sentence ends, then at
+        spaces (never truncated: the cut-off tail would silently not be spoken); the pieces are synthesised one after the other."""
+        try:
+            return [(text, self._build_prompt(text))]
+        except ValueError:
+            pass
+        cut = -1
+        mid = len(text) // 2
+        for pat in (r"[.!?\u3002\uff01\uff1f]\s", r"[,;:]\s", r"\s"):
+            pos = [m.end() for m in re.finditer(pat, text)]
+            if pos:
+                cut = min(pos, key=lambda p: abs(p - mid))
+                if 0 < cut < len(text):
+                    break
+        if not 0 < cut < len(text):
+            cut = mid
+        left, right = text[:cut].strip(), text[cut:].strip()
+        return (self._build_prompts(left) if left else []) + (self._build_prompts(right) if right else [])
+
     def process(self, tts_input: Any) -> Iterator[Any]:
         # stale-turn handling exactly as the reference's process() (TTS/qwen3_tts_handler.py:812-836): the tracker's commit()
         # returns None - its result is never a filter
@@ -160,22 +195,23 @@ class MI355XQwen3TTSHandler(BaseHandler):
         gen = self.cancel_scope.generation if self.cancel_scope is not None else None
         start = perf_counter()
         try:
-            chunks, cancel = self.pool.synthesize(self._build_prompt(text), self._estimate_max_new_tokens(text))
             blocker = AudioBlocker(self.blocksize)
             first, total = True, 0
-            for chunk in chunks:
-                if gen is not None and self.cancel_scope.is_stale(gen):
-                    cancel.set()
-                    logger.info("TTS generation cancelled (interruption)")
-                    return
-                if first:
-                    logger.info("MI355X Qwen3-TTS TTFA: %.3fs", perf_counter() - start)
-                    if tts_input.speech_stopped_at_s is not None:
-                        logger.info("Last speech detected to first speech out: %.3fs", perf_counter() - tts_input.speech_stopped_at_s)
-                    first = False
-                for block in blocker.push(np.asarray(chunk, dtype=np.int16)):
-                    total += len(block)
-                    yield block
+            for piece, prompt in self._build_prompts(text):
+                chunks, cancel = self.pool.synthesize(prompt, self._estimate_max_new_tokens(piece))
+                for chunk in chunks:
+                    if gen is not None and self.cancel_scope.is_stale(gen):
+                        cancel.set()
+                        logger.info("TTS generation cancelled (interruption)")
+                        return
+                    if first:
+                        logger.info("MI355X Qwen3-TTS TTFA: %.3fs", perf_counter() - start)
+                        if tts_input.speech_stopped_at_s is not None:
+                            logger.info("Last speech detected to first speech out: %.3fs", perf_counter() - tts_input.speech_stopped_at_s)
+                        first = False
+                    for block in blocker.push(np.asarray(chunk, dtype=np.int16)):
+                        total += len(block)
+                        yield block
             for block in blocker.flush():
                 total += len(block)
                 yield block

@@ -169,5 +169,9 @@ class ByteTextFrontend:
         self.table = table.astype(np.float32)
 
     def embed(self, text: str, max_tokens: int) -> np.ndarray:
-        ids = [256] + list(text.encode("utf-8"))[: max(0, max_tokens - 2)] + [257]
+        raw = list(text.encode("utf-8"))
+        if len(raw) > max(0, max_tokens - 2):
+            # never truncate silently (the tail of the sentence would simply not be spoken): the handler splits long inputs
+            raise ValueError(f"TTS input of {len(raw)} bytes exceeds the prompt budget of {max_tokens - 2}; split the text into shorter sentences")
+        ids = [256] + raw + [257]
         return self.table[np.asarray(ids)]

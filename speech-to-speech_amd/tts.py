@@ -386,6 +386,12 @@ class TTSEngine:
                                                            native.ptr(codes), native.ptr(nfr)), "s2s_tts_generate_forced")
         return codes, logits
 
+    def set_sampling(self, which: str = "talker", temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0, repetition_penalty: float = 1.0,
+                     seed: int = 0) -> None:
+        """Seeded sampling for the talker (codebook 0) or the code predictor (residual groups); temperature <= 0 = greedy (default)."""
+        native.check(self._lib.s2s_tts_set_sampling(self._h, {"talker": 0, "predictor": 1}[which], float(temperature), int(top_k), float(top_p),
+                                                    float(repetition_penalty), int(seed)), "s2s_tts_set_sampling")
+
     def codec_samples(self, F: int) -> int:
         return int(self._lib.s2s_codec_samples(self._h, F))
 

@@ -81,7 +81,8 @@ def test_text_frontends_round_trip():
     fe = ByteTextFrontend(table)
     e = fe.embed("hi", 16)
     assert e.shape[1] == 4 and 2 <= e.shape[0] <= 16
-    assert fe.embed("x" * 100, 8).shape[0] == 8
+    with pytest.raises(ValueError):            # never truncated silently: the handler splits long inputs
+        fe.embed("x" * 100, 8)
 
 
 def test_whisper_vocab_from_generation_config_and_synthetic_layouts(tmp_path):
@@ -115,3 +116,69 @@ def test_whisper_vocab_from_generation_config_and_synthetic_layouts(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps({"vocab_size": 51866}))
     f = WhisperVocab.from_checkpoint(str(tmp_path))
     assert (f.sot, f.eot, f.transcribe, f.notimestamps, f.suppress, f.lang_to_id) == (50258, 50257, 50360, 50364, (5,), {"en": 50259})
+
+
+def test_qwen3_tts_checkpoint_directory_round_trip_and_name_rules(tmp_path):
+    """A checkpoint directory (config.json + safetensors [+ name_map.json / prompt_layout.json]) loads into the converter's names;
+    tensors the engine needs but the directory lacks are reported, never replaced by random weights."""
+    import json
+
+    import torch
+
+    from speech_to_speech_amd.qwen3_tts_checkpoint import (TableTextFrontend, TTSPromptLayout, load_qwen3_tts_checkpoint, read_dims, remap_names,
+                                                          save_synthetic_checkpoint)
+    from speech_to_speech_amd.synth_weights import Qwen3TTSDims, qwen3_tts_state_dict
+
+    dims = Qwen3TTSDims.test_tiny()
+    sd = qwen3_tts_state_dict(dims, seed=5)
+    table = np.random.default_rng(0).standard_normal((258, dims.t_hidden)).astype(np.float32)
+    d = tmp_path / "ckpt"
+    # stored under "foreign" names: the predictor nested under the talker and an in-projection called small_to_mtp_projection, plus a custom rule
+    foreign = {}
+    for k, v in sd.items():
+        k2 = "talker." + k if k.startswith("code_predictor.") else k
+        k2 = k2.replace("code2wav.code_embedding.weight", "vq.codebooks")
+        foreign[k2] = v
+    save_synthetic_checkpoint(str(d), dims, foreign, text_table=table, pad_embed=torch.ones(dims.t_hidden))
+    (d / "name_map.json").write_text(json.dumps({"^vq[.]codebooks$": "code2wav.code_embedding.weight"}))
+    (d / "prompt_layout.json").write_text(json.dumps({"text_bos": 256, "text_eos": 257, "speaker_ids": {"aiden": 3}, "max_text_tokens": 40}))
+    got_dims, got_sd, layout, text = load_qwen3_tts_checkpoint(str(d))
+    assert got_dims == dims and set(got_sd) == set(sd) and all(torch.equal(got_sd[k], sd[k]) for k in sd)
+    assert layout.speaker_ids == {"aiden": 3} and layout.max_text_tokens == 40 and np.array_equal(text["text.embedding.weight"].numpy(), table)
+    fe = TableTextFrontend(table, layout)
+    assert fe.embed("hi", 64).shape == (4, dims.t_hidden) and np.array_equal(fe.embed("hi", 64)[1], table[ord("h")])
+    with pytest.raises(ValueError):
+        fe.embed("x" * 41, 64)
+    # a missing tensor is an error that names it
+    del foreign["talker.codec_head.weight"]
+    save_synthetic_checkpoint(str(tmp_path / "bad"), dims, foreign, text_table=table)
+    with pytest.raises(KeyError, match="codec_head"):
+        load_qwen3_tts_checkpoint(str(tmp_path / "bad"))
+    # nested HF-style config blocks
+    hf = {"talker_config": {"hidden_size": 2048, "num_hidden_layers": 28, "num_attention_heads": 16, "num_key_value_heads": 8, "head_dim": 128,
+                            "intermediate_size": 6144, "vocab_size": 3072, "codec_eos_token_id": 2150, "num_code_groups": 16,
+                            "code_predictor_config": {"hidden_size": 1024, "num_hidden_layers": 5, "num_attention_heads": 16, "num_key_value_heads": 8,
+                                                      "head_dim": 128, "intermediate_size": 3072, "vocab_size": 2048}}}
+    big = read_dims(hf)
+    assert (big.t_hidden, big.t_layers, big.t_kv_heads, big.p_hidden, big.codebook, big.n_groups, big.codec_eos) == (2048, 28, 8, 1024, 2048, 16, 2150)
+    assert remap_names({"talker.code_predictor.small_to_mtp_projection.weight": 1}) == {"code_predictor.in_proj.weight": 1}
+
+
+def test_tts_handler_splits_over_long_text_instead_of_truncating():
+    from speech_to_speech_amd.handlers.qwen3_tts import MI355XQwen3TTSHandler
+
+    class Eng:
+        max_prompt = 32
+        text_frontend = ByteTextFrontend(np.zeros((258, 4), np.float32))
+
+    class Pool:
+        def engine(self, name):
+            return Eng()
+
+    h = object.__new__(MI355XQwen3TTSHandler)
+    h.pool = Pool()
+    text = "This sentence is fine. This one is also short enough! And a third, slightly longer one, follows here."
+    pieces = h._build_prompts(text)
+    assert len(pieces) >= 4 and all(len(p.encode()) <= 30 for p, _ in pieces)
+    assert " ".join(p for p, _ in pieces).split() == text.split()          # nothing dropped, order kept
+    assert [p for p, _ in h._build_prompts("short")] == ["short"]
