@@ -11,7 +11,7 @@ from threading import Event
 from time import perf_counter
 from typing import Any, Iterator
 
-from .messages import (PIPELINE_END, SESSION_END, AudioOutput, EndOfResponse, PartialTranscription, PipelineControlMessage, PipelineEvent,
+from .messages import (PIPELINE_END, SESSION_END, AudioOutput, EndOfResponse, PartialTranscription, PipelineControlMessage, PipelineEvent, VADAudio,
                        Transcription, TTSInput, is_control_message)
 
 logger = logging.getLogger(__name__)
@@ -141,11 +141,53 @@ class BaseSTTHandler(BaseHandler):
             return tr.is_latest_after_pending_reopen(key[0], key[1])
         return tr.is_latest(key[0], key[1])
 
+    def _has_queued_final_for_revision_locked(self, item: Any) -> bool:
+        key = self._key(item)
+        if key is None:
+            return False
+        return any(isinstance(q, VADAudio) and q.mode == "final" and self._key(q) == key for q in self.queue_in.queue)
+
+    def _has_queued_final_for_revision(self, item: Any) -> bool:
+        if not hasattr(self.queue_in, "mutex") or not hasattr(self.queue_in, "queue"):
+            return False
+        with self.queue_in.mutex:
+            return self._has_queued_final_for_revision_locked(item)
+
+    def _drop_stale_queued_inputs(self) -> int:
+        """Purge queued VADAudio that can no longer matter (reference base_stt_handler.py:105-131): inputs of an already
+        finalised revision, progressives with their own final queued behind them, inputs of a superseded revision."""
+        if self.speculative_turns is None or not hasattr(self.queue_in, "mutex") or not hasattr(self.queue_in, "queue"):
+            return 0
+        dropped = 0
+        with self.queue_in.mutex:
+            kept = []
+            while self.queue_in.queue:
+                q = self.queue_in.queue.popleft()
+                if isinstance(q, VADAudio) and (self._key(q) in self._completed() or (q.mode == "progressive" and self._has_queued_final_for_revision_locked(q))
+                                                or not self._is_latest(q, stability=False, pending_reopen=False)):
+                    dropped += 1
+                else:
+                    kept.append(q)
+            self.queue_in.queue.extend(kept)
+            if dropped:
+                self.queue_in.not_full.notify_all()
+        return dropped
+
     def should_process_input(self, item: Any) -> bool:
         key = self._key(item)
         if key is not None and key in self._completed():
+            self._drop_stale_queued_inputs()
             return False
-        return self._is_latest(item, stability=getattr(item, "mode", None) == "final", pending_reopen=True)
+        if getattr(item, "mode", None) == "progressive" and self._has_queued_final_for_revision(item):
+            return False          # its own final is already waiting: transcribing the partial would only delay it
+        if not self._is_latest(item, stability=getattr(item, "mode", None) == "final", pending_reopen=True):
+            self._drop_stale_queued_inputs()
+            return False
+        return True
+
+    def on_session_end(self) -> None:
+        if hasattr(self, "_completed_final"):
+            self._completed_final.clear()
 
     def should_emit_output(self, output: Any) -> bool:
         key = self._key(output)

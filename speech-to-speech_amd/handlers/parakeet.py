@@ -103,9 +103,24 @@ def build_parakeet_engine(model_name: str, device: str, compute_type: str, max_b
     if kind == "synthetic":
         dims = PARAKEET_DIMS[key]()
         return ParakeetEngine(dims, parakeet_state_dict(dims, seed=seed or 12, gain=1.5), dtype=dtype, max_batch=max_batch, max_seconds=max_seconds, device=device)
+    import json
+    import os
+
     from ..synth_weights import ParakeetDims
 
-    return ParakeetEngine(ParakeetDims.tdt_0_6b(), load_safetensors_dir(key), dtype=dtype, max_batch=max_batch, max_seconds=max_seconds, device=device)
+    dims = ParakeetDims.tdt_0_6b()
+    cfg_path = os.path.join(key, "config.json")
+    if os.path.exists(cfg_path):       # dims from the checkpoint (transformers ParakeetConfig keys), not assumed
+        with open(cfg_path) as f:
+            cfg = json.load(f)
+        enc = cfg.get("encoder_config", cfg)
+        dims = ParakeetDims(n_mels=enc.get("num_mel_bins", dims.n_mels), d_model=enc.get("hidden_size", dims.d_model),
+                            n_heads=enc.get("num_attention_heads", dims.n_heads), layers=enc.get("num_hidden_layers", dims.layers),
+                            ffn=enc.get("intermediate_size", dims.ffn), sub_channels=enc.get("subsampling_conv_channels", dims.sub_channels),
+                            conv_kernel=enc.get("conv_kernel_size", dims.conv_kernel), vocab=cfg.get("vocab_size", dims.vocab),
+                            dec_hidden=cfg.get("decoder_hidden_size", dims.dec_hidden), dec_layers=cfg.get("num_decoder_layers", dims.dec_layers),
+                            n_durations=len(cfg.get("durations", range(dims.n_durations))), scale_input=enc.get("scale_input", dims.scale_input))
+    return ParakeetEngine(dims, load_safetensors_dir(key), dtype=dtype, max_batch=max_batch, max_seconds=max_seconds, device=device)
 
 
 class MI355XParakeetSTTHandler(BaseSTTHandler):

@@ -17,6 +17,8 @@ WEIGHT LAYOUT handed to ``s2s_parakeet_set_tensor`` (``W`` = model dtype; everyt
 
 from __future__ import annotations
 
+import logging
+
 import ctypes as C
 import math
 from typing import Mapping, Sequence
@@ -27,6 +29,8 @@ import torch
 from . import native
 from .frontend import LogMelFrontend, pack_pcm
 from .synth_weights import ParakeetDims
+
+logger = logging.getLogger(__name__)
 
 
 def _half_up(n: int) -> int:
@@ -177,15 +181,30 @@ class ParakeetEngine:
         """SessionPool entry point: {"ids": non-blank token ids, "starts_s" / "ends_s": start / end time of each token in
         seconds (encoder frame x 80 ms; end = start + the TDT duration, at least one frame)}."""
         max_len = (self.max_feat_frames - 1) * 160
-        feats, nf, _ = self.features([a[:max_len] if len(a) >= 1280 else np.pad(a, (0, 1280 - len(a))) for a in audios])
-        self.encode(feats, nf)
-        toks, durs, frames = self.tdt_greedy()
+        # A turn longer than the engine's window (max_seconds) is transcribed window by window and stitched (token times shifted by the
+        # window start) - the reference transcribes turns of any length (its VAD max_speech_ms defaults to infinity); nothing is dropped.
+        pieces, owner, offset = [], [], []
+        for i, a in enumerate(audios):
+            if len(a) > max_len:
+                logger.info("Parakeet: %.1f s turn exceeds the %.1f s window: transcribing it in %d windows", len(a) / 16000.0, max_len / 16000.0,
+                            -(-len(a) // max_len))
+            for s0 in range(0, max(len(a), 1), max_len):
+                seg = a[s0 : s0 + max_len]
+                pieces.append(seg if len(seg) >= 1280 else np.pad(seg, (0, 1280 - len(seg))))
+                owner.append(i)
+                offset.append(s0 / 16000.0)
         blank = self.dims.blank
-        out = []
-        for tk, du, fr in zip(toks, durs, frames):
-            keep = [j for j, t in enumerate(tk) if t != blank]
-            out.append({"ids": [tk[j] for j in keep], "starts_s": [fr[j] * 0.08 for j in keep],
-                        "ends_s": [(fr[j] + max(du[j], 1)) * 0.08 for j in keep]})
+        out = [{"ids": [], "starts_s": [], "ends_s": []} for _ in audios]
+        for b0 in range(0, len(pieces), self.max_batch):
+            feats, nf, _ = self.features(pieces[b0 : b0 + self.max_batch])
+            self.encode(feats, nf)
+            toks, durs, frames = self.tdt_greedy()
+            for j, (tk, du, fr) in enumerate(zip(toks, durs, frames)):
+                o, t0 = out[owner[b0 + j]], offset[b0 + j]
+                keep = [k for k, t in enumerate(tk) if t != blank]
+                o["ids"] += [tk[k] for k in keep]
+                o["starts_s"] += [t0 + fr[k] * 0.08 for k in keep]
+                o["ends_s"] += [t0 + (fr[k] + max(du[k], 1)) * 0.08 for k in keep]
         return out
 
     def transcribe_ids(self, audios: Sequence[np.ndarray]):

@@ -487,3 +487,35 @@ def test_openai_compatible_server_serves_the_reference_client_request(pool):
     pcm = np.frombuffer(r.content, dtype="<i2")
     assert r.status_code == 200 and len(pcm) == 3 * 700 and set(pcm.tolist()) == {3000, 3001, 3002}
     assert client.get("/health").json()["status"] == "ok"
+
+
+def test_stt_shim_drops_progressive_behind_its_final_and_purges_stale_queue(pool):
+    """BaseSTTHandler behaviours the reference has (STT/base_stt_handler.py:24-62,105-131,215-217): a progressive whose own final is
+    already queued is skipped, stale queued inputs are purged when a stale item is met, session end clears the finalised revisions."""
+
+    class Tracker:
+        latest = {"t": 2}
+
+        def is_latest(self, t, r):
+            return self.latest.get(t, r) == r
+
+        def is_latest_after_pending_reopen(self, t, r):
+            return self.is_latest(t, r)
+
+        def is_latest_after_stability_window(self, t, r, settle):
+            return self.is_latest(t, r)
+
+    h = _whisper(pool)
+    h.speculative_turns = Tracker()
+    mk = lambda mode, rev: VADAudio(audio=np.zeros(800, np.float32), mode=mode, turn_id="t", turn_revision=rev)   # noqa: E731
+    h.queue_in.put(mk("final", 2))
+    assert h.should_process_input(mk("progressive", 2)) is False           # its final is waiting behind it
+    assert h.queue_in.qsize() == 1
+    h.queue_in.put(mk("progressive", 1))                                   # superseded revision, queued
+    assert h.should_process_input(mk("final", 1)) is False                 # stale input ...
+    assert h.queue_in.qsize() == 1 and h.queue_in.queue[0].turn_revision == 2   # ... purges the stale queued one, keeps the live final
+    out = Transcription(text="x", turn_id="t", turn_revision=2)
+    h.before_emit_output(out)
+    assert h.should_process_input(mk("progressive", 2)) is False           # revision already finalised
+    h.on_session_end()
+    assert h.should_process_input(mk("final", 2)) is True
