@@ -23,7 +23,9 @@ def resample_fir(up: int, down: int, dtype=np.float32) -> np.ndarray:
 
     max_rate = max(up, down)
     half_len = 10 * max_rate
-    return (firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up).astype(dtype)
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)).astype(dtype)      # scipy casts to the signal's dtype FIRST ...
+    h *= dtype(up)                                                                        # ... and applies the gain in that precision
+    return h
 
 
 def reference_resample(audio_int16: bytes, from_rate: int, to_rate: int) -> bytes:
