@@ -77,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c1", "c5", "tiny"])
     ap.add_argument("--sessions", type=int, default=None, help="concurrent sessions per GPU (default: 64 c3, 1 c2 / c1, 32 c5)")
     ap.add_argument("--decode-tokens", type=int, default=32, help="Whisper greedy tokens per utterance (eos masked)")
+    ap.add_argument("--reply-frames", type=int, default=None, help="codec frames of the reply (default: 128 = 10.24 s; 64 for c1); reduced runs for counter collection")
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream")
     ap.add_argument("--tts-lanes", type=int, default=3, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
@@ -501,6 +502,8 @@ def main():
         wdims, tdims = WhisperDims.test_tiny(), Qwen3TTSDims.test_tiny()
     reply_s = TURN_REPLY_SECONDS if wl != "c1" else 5.0
     n_frames = int(reply_s * 12.5 / CHUNK_FRAMES + 0.999) * CHUNK_FRAMES      # 128 codec frames = 10.24 s reply, 16 streamed chunks
+    if args.reply_frames:
+        n_frames = max(CHUNK_FRAMES, args.reply_frames // CHUNK_FRAMES * CHUNK_FRAMES)
     sessions = shard_sessions(B, rank)
     audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
     pcm, ns = pack_pcm(audios, dev)                                     # inputs resident in HBM before the timed region
@@ -692,13 +695,19 @@ def main():
         dom = max(fams, key=lambda k: fams[k]["kernel_ms_per_step"])
         roof = dict(fams[dom])
         roof["traffic"] = None
+        # HBM traffic of the dominant family from the PMC counters: FETCH_SIZE (x2 on gfx950 for 16 B/lane streaming reads) + WRITE_SIZE,
+        # separate rocprofv3 --pmc passes over a REDUCED step of this same bench (tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json);
+        # the measured / algorithmic ratio of that run is applied to this run's algorithmic bytes per launch
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc_path):
             pm = json.load(open(pmc_path)).get(dom)
             if pm:
-                roof["traffic"] = round(pm["hbm_bytes_per_launch"])
-                roof["traffic_note"] = pm.get("note", "")
-        roof["families"] = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "kernel_ms_per_step", "avg_kernel_us")}
+                per_launch = fams[dom]["algorithmic_gb_per_step"] * 1e9 / max(fams[dom]["launches_per_step"], 1)
+                roof["traffic"] = round(pm["hbm_over_algorithmic"] * per_launch)
+                roof["traffic_note"] = (f"bytes per launch = {pm['hbm_over_algorithmic']:.3f} x this run's algorithmic bytes per launch; ratio measured with rocprofv3 --pmc "
+                                        f"FETCH_SIZE / WRITE_SIZE (separate passes) over a reduced step of this bench ({pm.get('command', '')})")
+        roof["families"] = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "kernel_ms_per_step", "avg_kernel_us",
+                                                     "algorithmic_gb_per_step", "algorithmic_tflop_per_step")}
                             for k, v in fams.items()}
         roof["sampled_over"] = (f"{n_prof} extra step(s) of the same workload right after the timed region, plain stream launches on one stream; durations = "
                                 "the kernels' own begin/end timestamps (hipExtLaunchKernelGGL events, the quantity rocprofv3 --kernel-trace reports) - nothing subtracted")

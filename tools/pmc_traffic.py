@@ -1,0 +1,44 @@
+"""HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a reduced bench step, against the
+algorithmic bytes the bench line of the same command reports.
+usage (GPU box): python tools/pmc_traffic.py <fetch_dir> <write_dir> <bench_line.json> <out.json> "<command>"
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for 16 B/lane streaming reads -> doubled
+(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated and taken as is."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+FAMILIES = {"gemm_dec": ("gemm_dec_kernel", "gemm_skinny_kernel"), "gemm_tile": ("gemm_tile3_kernel", "gemm_tile_kernel"), "attn_mfma": ("attn_mfma_kernel",),
+            "attn_rows": ("attn_step_kernel", "attn_decode_kernel", "attn_rows_kernel")}
+
+
+def collect(d, counter):
+    tot, n = defaultdict(float), defaultdict(int)
+    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(path, newline="")):
+            if row["Counter_Name"] != counter:
+                continue
+            for fam, pats in FAMILIES.items():
+                if any(p in row["Kernel_Name"] for p in pats):
+                    tot[fam] += float(row["Counter_Value"])
+                    n[fam] += 1
+    return tot, n
+
+
+fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
+write, nw = collect(sys.argv[2], "WRITE_SIZE")
+line = json.load(open(sys.argv[3]))
+steps = line["steps"] + line["warmup"] + 1          # timed + warm-up + the roofline sample step
+out = {}
+for fam in FAMILIES:
+    if not nf.get(fam):
+        continue
+    f = line["roofline"]["families"].get(fam)
+    hbm = 2.0 * fetch[fam] * 1024 + write.get(fam, 0.0) * 1024
+    alg = f["algorithmic_gb_per_step"] * 1e9 * steps if f else None
+    out[fam] = {"dispatches": nf[fam], "FETCH_SIZE_KiB_sum": fetch[fam], "WRITE_SIZE_KiB_sum": write.get(fam, 0.0), "hbm_bytes": hbm,
+                "hbm_bytes_per_launch": hbm / nf[fam], "algorithmic_bytes": alg, "hbm_over_algorithmic": (hbm / alg) if alg else None,
+                "command": sys.argv[5] if len(sys.argv) > 5 else ""}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out, indent=1))
