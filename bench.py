@@ -84,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=16.0, help="measurement window of one open-loop probe")
+    ap.add_argument("--pool-lanes", type=int, default=6, help="TTS lanes of the SessionPool in the open-loop probe (more lanes = shorter wait for a free lane)")
     ap.add_argument("--ttfa-bound-ms", type=float, default=1000.0, help="p95 time-to-first-audio bound of the sustained-sessions search")
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the kernel-timestamp roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
@@ -736,7 +737,7 @@ def main():
     # ---- the SURVEY 8d metric through the boundary (handlers + SessionPool), world == 1 only
     if not args.no_boundary and world == 1 and tts is not None and wl in ("c3", "c1", "c2", "tiny"):
         try:
-            lanes = max(3, args.tts_lanes)
+            lanes = max(1, args.pool_lanes)
 
             def probe(n, window=args.boundary_seconds):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios)
