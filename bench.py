@@ -366,7 +366,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
             time.sleep(t_arr - now)
         va = VADAudio(audio=audios[session % len(audios)], mode="final", turn_id=f"s{session}", turn_revision=0, created_at_s=t_arr)
         out = list(stt.process(va))
-        text = out[0].text if out else ""
+        text = (out[0].text if out else "")[:100]      # echo "LLM": the (capped) transcript is the reply, as in the timed region
         t_first, n_blocks, late = None, 0, 0.0
         for block in tts.process(TTSInput(text=text or "t1", turn_id=va.turn_id, turn_revision=0, speech_stopped_at_s=t_arr)):
             tn = time.perf_counter()

@@ -336,7 +336,6 @@ static int finalize(Tts* m) {
             m->pred.qkv_n.clear();
             m->head_n.clear();
         }
-        S2S_HIP_CHECK(hipDeviceSynchronize());
     }
     m->finalized = true;
     return S2S_OK;
@@ -686,9 +685,14 @@ static int32_t tts_generate_impl(Tts* m, hipStream_t st, int32_t n_frames, int32
     const int f0 = m->frames_done;
     fill_int_kernel<<<1, 64, 0, st>>>(m->min_dev, min_total_frames, 1);
     S2S_LAUNCH_CHECK();
-    if (allow_graph && graphs_enabled() && !prof_active()) {
-        hipGraphExec_t exec = nullptr;
-        if ((rc = frame_graph(m, B, &exec))) return rc;
+    hipGraphExec_t exec = nullptr;
+    if (allow_graph && graphs_enabled() && !prof_active() && frame_graph(m, B, &exec) != S2S_OK) {
+        // the capture was refused or invalidated (HIP aborts a capture when another thread touches the legacy stream): not fatal -
+        // clear the sticky error and run this call as plain stream launches; the next call captures again
+        (void)hipGetLastError();
+        exec = nullptr;
+    }
+    if (exec) {
         for (int f = 0; f < n_frames; ++f) S2S_HIP_CHECK(hipGraphLaunch(exec, st));
     } else {
         for (int f = 0; f < n_frames; ++f)

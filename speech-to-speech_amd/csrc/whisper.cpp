@@ -538,12 +538,13 @@ extern "C" int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t 
     const bool split_ok = c.dtype == S2S_BF16;
     const bool use_graph = graphs_enabled() && !prof_active();
     hipGraphExec_t exec = nullptr;
-    if (use_graph) {
-        const int rc = step_graph(m, B, split_ok, &exec);
-        if (rc) return rc;
+    bool graph_ok = use_graph;
+    if (use_graph && step_graph(m, B, split_ok, &exec) != S2S_OK) {   // refused / invalidated capture: run this call as stream launches
+        (void)hipGetLastError();
+        graph_ok = false;
     }
     for (int s = 0; s < total_steps; ++s) {
-        if (use_graph) {
+        if (graph_ok) {
             S2S_HIP_CHECK(hipGraphLaunch(exec, st));
         } else {
             const int rc = step_body(m, st, B, split_ok);

@@ -247,6 +247,7 @@ class SessionPool:
                     _, name, factory, fut = it
                     try:
                         self._engines[name] = factory()
+                        self._sync_current_stream()      # uploads / conversions of the build are complete before any lane uses the weights
                         fut.set_result(True)
                     except BaseException as e:  # noqa: BLE001
                         fut.set_exception(e)
@@ -279,11 +280,22 @@ class SessionPool:
             dev = torch.device(self.device)
             if dev.type == "cuda" and torch.cuda.is_available():
                 torch.cuda.set_device(dev)
-                torch.cuda.synchronize(dev)      # weights were uploaded on the STT worker's stream
+                # (no device-wide synchronise here: it would collide with another lane's stream capture; the worker that builds an
+                # engine synchronises ITS stream before the build is reported done)
                 return torch.cuda.stream(torch.cuda.Stream(device=dev))
         except Exception:  # noqa: BLE001
             pass
         return contextlib.nullcontext()
+
+    def _sync_current_stream(self) -> None:
+        try:
+            import torch
+
+            dev = torch.device(self.device)
+            if dev.type == "cuda" and torch.cuda.is_available():
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception:  # noqa: BLE001
+            pass
 
     def _lane_start(self, lane: int, warm: bool):
         """-> (engine, entered stream context) of a lane, or (None, None) when the TTS engine cannot be replicated."""

@@ -220,7 +220,7 @@ def add_fragment_major_weights(tensors: dict, dims: Qwen3TTSDims) -> None:
         tensors[f"pred.head.{g}.f"] = native.to_frag(tensors[f"pred.head.{g}.w"], tensors["pred.norm"])
     if P != E:
         tensors["pred.in_proj.f"] = native.to_frag(tensors["pred.in_proj.w"])
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()      # (a stream, not the device: never collide with another thread's capture)
 
 
 def resample_fir_2_3(dtype=np.float32) -> np.ndarray:

@@ -143,7 +143,7 @@ class WhisperEngine:
                     for nm in ("qkv.w", "o.w", "cq.w", "co.w", "fc1.w", "fc2.w"):
                         tensors[f"dec.{l}.{nm}.f"] = native.to_frag(tensors[f"dec.{l}.{nm}"].view(-1, dims.ffn if nm == "fc2.w" else dims.d_model))
                 tensors["dec.tok.f"] = native.to_frag(tensors["dec.tok"].view(dims.vocab, dims.d_model))
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()      # (a stream, not the device: never collide with another thread's capture)
             for name, dt in tensors.items():
                 self._weights[name] = dt   # keep alive: the engine holds raw pointers
                 native.check(self._lib.s2s_whisper_set_tensor(h, name.encode(), native.ptr(dt), dt.numel()), name)
