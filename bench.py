@@ -84,7 +84,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=16.0, help="measurement window of one open-loop probe")
-    ap.add_argument("--pool-lanes", type=int, default=6, help="TTS lanes of the SessionPool in the open-loop probe (more lanes = shorter wait for a free lane)")
+    ap.add_argument("--pool-lanes", type=int, default=3, help="TTS lanes of the SessionPool in the open-loop probe (measured: 6 lanes contend and are slower than 3)")
     ap.add_argument("--ttfa-bound-ms", type=float, default=1000.0, help="p95 time-to-first-audio bound of the sustained-sessions search")
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the kernel-timestamp roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
