@@ -43,6 +43,7 @@ extern "C" {
 #define S2S_ACT_GELU 1 /* exact erf GELU (Whisper, modeling_whisper.py:618-619) */
 #define S2S_ACT_SILU 2 /* SiLU (FastConformer FFN; Qwen3 SwiGLU gate) */
 #define S2S_ACT_RELU 3
+#define S2S_ACT_SNAKE 4 /* SnakeBeta with per-channel tables (codec decoder; internal GEMM epilogues only) */
 
 const char* s2s_last_error(void);
 int32_t s2s_abi_version(void);

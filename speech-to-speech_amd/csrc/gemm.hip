@@ -70,7 +70,26 @@ struct RowMap {
     float alpha;                    // C = act(acc + bias) * alpha + residual
     int tap_len;                    // > 0: K index k of A lives at row + (k / tap_len) * tap_stride + k % tap_len
     long tap_stride;                //      (dilated 1-D convolution taps over a time-major buffer)
+    // epilogue extensions (GemmArgs): SnakeBeta on the primary output, model-dtype residual, second snake'd output
+    const float* sn_a; const float* sn_ib; int sn_mod;
+    const void* res_c;
+    void* C2; const float* sn2_a; const float* sn2_ib;
 };
+
+// SnakeBeta y = x + sin^2(a x) / b.  The bf16 pipeline uses the hardware sine (abs error ~1e-6 on the |a x| < 256 range
+// the codec produces, far below bf16 resolution); f32 keeps sinf so the f32 path matches the oracle to rounding.
+template <typename CT>
+__device__ __forceinline__ float snake_f(float v, float a, float ib) {
+    float s;
+    if constexpr (sizeof(CT) == 2) s = __sinf(v * a);
+    else s = sinf(v * a);
+    return v + s * s * ib;
+}
+template <typename CT>
+__device__ __forceinline__ float round_to(float v) {
+    if constexpr (sizeof(CT) == 2) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+    else return v;
+}
 
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];   // source of out-of-range chunks
 
@@ -196,33 +215,75 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
     // rows are grouped, i.e. conv / batched layouts) is computed once per row instead of once per element.
     float bv[4];
     int ncol[4];
+    int nch[4];     // snake channel of the column
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         ncol[j] = n0 + wn + j * 16 + l15;
         bv[j] = (bias && ncol[j] < N) ? bias[ncol[j]] : 0.f;
+        nch[j] = rm.sn_mod > 0 ? ncol[j] % rm.sn_mod : ncol[j];
+        if (ncol[j] >= N) nch[j] = 0;
+    }
+    // the lane's columns are fixed over the row loop: table values live in registers
+    float sa[4], sb[4], ta[4], tb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sa[j] = act == S2S_ACT_SNAKE ? rm.sn_a[nch[j]] : 0.f;
+        sb[j] = act == S2S_ACT_SNAKE ? rm.sn_ib[nch[j]] : 0.f;
+        ta[j] = rm.C2 ? rm.sn2_a[nch[j]] : 0.f;
+        tb[j] = rm.C2 ? rm.sn2_ib[nch[j]] : 0.f;
     }
     const bool grouped = rm.G < M;
+    // Residual values first, ALL of them, before any store: the residual may alias C (in-place adds), so the compiler
+    // cannot move a load above an earlier store - interleaved they form 16 serial load -> store round trips per lane.
+    const bool has_res = residual != nullptr || rm.res_c != nullptr;
+    float rres[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + i * 16 + lg * 4 + r;
+            long coff = 0, roff = 0;
+            if (has_res && m < M) {
+                if (grouped) {
+                    const int mb = m / rm.G, mr = m - mb * rm.G;
+                    coff = (long)mb * rm.c_bs + (long)mr * ldc;
+                    roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+                } else {
+                    coff = (long)m * ldc;
+                    roff = (long)m * rm.ldr;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float rv = 0.f;
+                if (has_res && m < M && ncol[j] < N) {
+                    if (residual) rv += residual[roff + ncol[j]];
+                    if (rm.res_c) rv += Elem<CT>::ld((const CT*)rm.res_c + coff + ncol[j]);
+                }
+                rres[i][r][j] = rv;
+            }
+        }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wm + i * 16 + lg * 4 + r;
             if (m >= M) continue;
-            long coff, roff;
+            long coff;
             if (grouped) {
                 const int mb = m / rm.G, mr = m - mb * rm.G;
                 coff = (long)mb * rm.c_bs + (long)mr * ldc;
-                roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
             } else {
                 coff = (long)m * ldc;
-                roff = (long)m * rm.ldr;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ncol[j] >= N) continue;
                 float v = apply_act(acc[i][j][r] + bv[j], act) * rm.alpha;
-                if (residual) v += residual[roff + ncol[j]];
+                if (act == S2S_ACT_SNAKE) v = snake_f<CT>(v, sa[j], sb[j]);
+                v += rres[i][r][j];
                 Elem<CT>::st(C + coff + ncol[j], v);
+                if (rm.C2) Elem<CT>::st((CT*)rm.C2 + coff + ncol[j], snake_f<CT>(round_to<CT>(v), ta[j], tb[j]));
             }
         }
 }
@@ -400,6 +461,69 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     // Epilogue through LDS: the C fragments (column-strided per lane) are staged as a 64 x 64 f32 tile per wave
     // (row pitch 68 floats: conflict-free fragment writes) and read back row-wise, so every lane stores 16 contiguous
     // bytes of one output row (8 rows x 128 B per wave instruction for bf16) instead of 2-byte scattered stores.
+    constexpr int VEC = 16 / (int)sizeof(CT);   // output elements per 16-byte store: 8 (bf16) / 4 (f32)
+    constexpr int LPR = 64 / VEC;               // lanes per output row
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int NIT = 64 / RPI;
+    const bool grouped = rm.G < M;
+    const int cc = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc;
+    const bool full = n + VEC <= N;
+    // Residual values first, all of them, before the staging barrier: the residual may alias C (in-place adds), so a load
+    // can never be moved above an earlier store - inside the store loop they were NIT serial load -> store round trips per
+    // lane with nothing else resident on the CU to hide them.  Issued here their latency overlaps the LDS staging.
+    float rres[NIT][VEC];
+    const bool has_res = residual != nullptr || rm.res_c != nullptr;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) rres[it][e] = 0.f;
+        const int m = m0 + wm + it * RPI + lane / LPR;
+        if (!has_res || m >= M || n >= N) continue;
+        long coff, roff;
+        if (grouped) {
+            const int mb = m / rm.G, mr = m - mb * rm.G;
+            coff = (long)mb * rm.c_bs + (long)mr * ldc;
+            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+        } else {
+            coff = (long)m * ldc;
+            roff = (long)m * rm.ldr;
+        }
+        if (residual) {
+            const float* rp = residual + roff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
+                    rres[it][q * 4 + 0] = r4.x; rres[it][q * 4 + 1] = r4.y; rres[it][q * 4 + 2] = r4.z; rres[it][q * 4 + 3] = r4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] = rp[e];
+            }
+        }
+        if (rm.res_c) {
+            const CT* rp = (const CT*)rm.res_c + coff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+                if constexpr (sizeof(CT) == 4) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                    rres[it][0] += r4.x; rres[it][1] += r4.y; rres[it][2] += r4.z; rres[it][3] += r4.w;
+                } else {
+                    const u32x4_t pk = *reinterpret_cast<const u32x4_t*>(rp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        rres[it][2 * q] += bf16_bits_to_f32((unsigned short)(pk[q] & 0xffffu));
+                        rres[it][2 * q + 1] += bf16_bits_to_f32((unsigned short)(pk[q] >> 16));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] += Elem<CT>::ld(rp + e);
+            }
+        }
+    }
     __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
     constexpr int PITCH = 68;
     float* stg = reinterpret_cast<float*>(lds3) + wave * (64 * PITCH);
@@ -421,25 +545,32 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    constexpr int VEC = 16 / (int)sizeof(CT);   // output elements per 16-byte store: 8 (bf16) / 4 (f32)
-    constexpr int LPR = 64 / VEC;               // lanes per output row
-    constexpr int RPI = 64 / LPR;               // rows per wave instruction
-    const bool grouped = rm.G < M;
-    const int cc = (lane % LPR) * VEC;
-    const int n = n0 + wn + cc;
-#pragma unroll 4
-    for (int it = 0; it < 64 / RPI; ++it) {
+    const int chmod = rm.sn_mod > 0 ? rm.sn_mod : (1 << 30);      // snake channel of column n (wraps at sn_mod)
+    const int ch0 = n < N ? n % chmod : 0;
+    float s1a[VEC], s1b[VEC], s2a[VEC], s2b[VEC];      // the lane's columns are fixed over the row loop
+    {
+        int ch = ch0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bool in = n + e < N;
+            s1a[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_a[ch] : 0.f;
+            s1b[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_ib[ch] : 0.f;
+            s2a[e] = (in && rm.C2) ? rm.sn2_a[ch] : 0.f;
+            s2b[e] = (in && rm.C2) ? rm.sn2_ib[ch] : 0.f;
+            if (++ch == chmod) ch = 0;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         const int row = it * RPI + lane / LPR;
         const int m = m0 + wm + row;
         if (m >= M || n >= N) continue;
-        long coff, roff;
+        long coff;
         if (grouped) {
             const int mb = m / rm.G, mr = m - mb * rm.G;
             coff = (long)mb * rm.c_bs + (long)mr * ldc;
-            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
         } else {
             coff = (long)m * ldc;
-            roff = (long)m * rm.ldr;
         }
         float v[VEC];
 #pragma unroll
@@ -448,35 +579,35 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
             v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
         }
         CT* cp = C + coff + n;
-        const bool full = n + VEC <= N;
-        if (residual) {
-            const float* rp = residual + roff + n;
-            if (full && ((uintptr_t)rp & 15) == 0) {
+        if (act == S2S_ACT_SNAKE) {
 #pragma unroll
-                for (int q = 0; q < VEC / 4; ++q) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
-                    v[q * 4 + 0] += r4.x; v[q * 4 + 1] += r4.y; v[q * 4 + 2] += r4.z; v[q * 4 + 3] += r4.w;
+            for (int e = 0; e < VEC; ++e) v[e] = snake_f<CT>(v[e], s1a[e], s1b[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += rres[it][e];
+        auto store_vec = [&](CT* dp, const float* w) {
+            if (full && ((uintptr_t)dp & 15) == 0) {
+                if constexpr (sizeof(CT) == 4) {
+                    *reinterpret_cast<float4*>(dp) = make_float4(w[0], w[1], w[2], w[3]);
+                } else {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        pk[q] = (unsigned)f32_to_bf16_bits(w[2 * q]) | ((unsigned)f32_to_bf16_bits(w[2 * q + 1]) << 16);
+                    *reinterpret_cast<u32x4_t*>(dp) = pk;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    if (n + e < N) v[e] += rp[e];
+                    if (n + e < N) Elem<CT>::st(dp + e, w[e]);
             }
-        }
-        if (full && ((uintptr_t)cp & 15) == 0) {
-            if constexpr (sizeof(CT) == 4) {
-                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                u32x4_t pk;
+        };
+        store_vec(cp, v);
+        if (rm.C2) {
+            float w[VEC];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    pk[q] = (unsigned)f32_to_bf16_bits(v[2 * q]) | ((unsigned)f32_to_bf16_bits(v[2 * q + 1]) << 16);
-                *reinterpret_cast<u32x4_t*>(cp) = pk;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                if (n + e < N) Elem<CT>::st(cp + e, v[e]);
+            for (int e = 0; e < VEC; ++e) w[e] = snake_f<CT>(round_to<CT>(v[e]), s2a[e], s2b[e]);
+            store_vec((CT*)rm.C2 + coff + n, w);
         }
     }
 }
@@ -678,8 +809,12 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     rm.alpha = g.alpha_set ? g.alpha : 1.0f;
     rm.tap_len = g.tap_len;
     rm.tap_stride = g.tap_stride;
+    rm.sn_a = g.snake_a; rm.sn_ib = g.snake_ib; rm.sn_mod = g.snake_mod;
+    rm.res_c = g.res_c;
+    rm.C2 = g.C2; rm.sn2_a = g.snake2_a; rm.sn2_ib = g.snake2_ib;
+    const bool ext = g.act == S2S_ACT_SNAKE || g.res_c || g.C2;      // tile-kernel epilogues only
     const int M = g.M, N = g.N, K = g.K;
-    if (M <= 128 && !(g.glu && M > 64)) {
+    if (M <= 128 && !(g.glu && M > 64) && !ext) {
         const int MT = cdiv(M, 16);
         int NF = 1;
         if (MT <= 4) {
@@ -769,6 +904,12 @@ int gemm_ex(hipStream_t st, const GemmArgs& g) {
     S2S_REQUIRE(g.tap_len % epc == 0 && g.tap_stride % epc == 0, "gemm: tap_len / tap_stride must be multiples of %d", epc);
     S2S_REQUIRE(g.ldw % epc == 0 && g.a_z1 % epc == 0 && g.a_z2 % epc == 0 && g.w_z1 % epc == 0 && g.w_z2 % epc == 0,
                 "gemm: ldw / batch strides must be multiples of %d elements", epc);
+    if (g.act == S2S_ACT_SNAKE || g.res_c || g.C2) {
+        S2S_REQUIRE(g.ab_dtype == g.c_dtype && !g.glu && !g.a_f32_rms && !g.alpha_set, "gemm: the snake / model-dtype residual / second-output epilogues need C in the operand dtype");
+        S2S_REQUIRE(g.act != S2S_ACT_SNAKE || (g.snake_a && g.snake_ib), "gemm: S2S_ACT_SNAKE without tables");
+        S2S_REQUIRE(!g.C2 || (g.snake2_a && g.snake2_ib), "gemm: second output without snake tables");
+        S2S_REQUIRE(g.C2 != g.A && g.C != g.A, "gemm: outputs must not alias A");
+    }
     if (g.a_f32_rms)
         S2S_REQUIRE(g.ab_dtype == S2S_BF16 && g.M <= 64 && g.G <= 0 && g.tap_len == 0 && g.nz1 <= 1 && g.nz2 <= 1 && g.rms_eps > 0.f &&
                         g.residual == nullptr,

@@ -22,6 +22,13 @@ struct GemmArgs {
     // to bf16 on the fly, accumulates every row's sum of squares from the same loads and scales the output tile by
     // rsqrt(mean(x^2) + rms_eps).  The norm weight must already be folded into W's columns (W[n][k] * gamma[k]).
     bool a_f32_rms; float rms_eps;
+    // Epilogue extensions of the tile kernels (codec decoder; C in the model dtype, alpha 1):
+    //   act == S2S_ACT_SNAKE: v += sin^2(v * snake_a[c]) * snake_ib[c], c = n % snake_mod (snake_mod 0: c = n)
+    //   res_c: residual in C's dtype, ld and batch stride (may BE C: in-place x += projection)
+    //   C2: second output in C's dtype / ld / batch stride = snake2(the value as stored in C) - the next layer's activation
+    const float* snake_a; const float* snake_ib; int snake_mod;
+    const void* res_c;
+    void* C2; const float* snake2_a; const float* snake2_ib;
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,

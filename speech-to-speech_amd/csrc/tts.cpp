@@ -814,6 +814,13 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         return er == hipSuccess ? S2S_OK : fail(S2S_ERR_HIP, "codec history save: %s", hipGetErrorString(er));
     };
 #define HLOAD(var, buf, Tn, Cn) const int var = hist_load(buf, Tn, Cn); if (var < 0) return done(var)
+    static const bool dbg_sync = getenv("S2S_CODEC_DEBUG_SYNC") != nullptr;      // localise a faulting stage: sync + trace after every stage
+    auto stage_ok = [&](const char* what, int i, int j) {
+        if (!dbg_sync) return;
+        const hipError_t er = hipStreamSynchronize(st);
+        fprintf(stderr, "[codec] %s %d.%d: %s\n", what, i, j, hipGetErrorString(er));
+        fflush(stderr);
+    };
     // code embeddings -> sliding-window transformer (KV cache continues across streamed chunks)
     if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
     const int f0 = streaming ? m->codec_frames_done : 0;
@@ -822,6 +829,7 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         S2S_LAUNCH_CHECK();
     }
     if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
+    stage_ok("transformer", 0, 0);
     if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
     S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,
                                    hipMemcpyDeviceToDevice, st));
@@ -846,63 +854,97 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         GemmArgs g2{};
         g2.A = tmp; g2.lda = 4 * H; g2.a_bs = (long)T * 4 * H;
         g2.W = TP(m, q + "pw2.w"); g2.bias = TPF(m, q + "pw2.b");
-        g2.C = m->cx; g2.ldc = H; g2.c_bs = (long)T * H;
-        g2.M = B * T; g2.N = H; g2.K = 4 * H; g2.G = T; g2.ab_dtype = dt; g2.c_dtype = S2S_F32; g2.act = S2S_ACT_NONE;
-        if ((rc = gemm_ex(st, g2))) return done(rc);
         HLOAD(s_out, cur, T, H);
-        if ((rc = add_f32_padded(st, cur, alt, m->cx, B, T, H, LPAD, dt))) return done(rc);     // cur = alt + cx
+        g2.C = at(cur, (size_t)LPAD * H * e); g2.ldc = H; g2.c_bs = (long)(LPAD + T) * H;     // cur = alt + pw2(...)  (residual read in the epilogue)
+        g2.res_c = at(alt, (size_t)LPAD * H * e);
+        g2.M = B * T; g2.N = H; g2.K = 4 * H; g2.G = T; g2.ab_dtype = dt; g2.c_dtype = dt; g2.act = S2S_ACT_NONE;
+        if ((rc = gemm_ex(st, g2))) return done(rc);
         if ((rc = hist_save(cur, T, H, s_out))) return done(rc);
+        stage_ok("upsample stage", i, 0);
     }
-    // decoder.0: causal conv k7 H -> Dd
+    // Decoder.  Three rotating buffers per block: X (the block's x), S (a snake'd activation, with conv history rows), F (free).
+    // Every SnakeBeta runs in the epilogue of the GEMM that produces its input (second output C2), every residual add in
+    // the epilogue of the unit's 1x1 conv (in place on x): the blocks are GEMM launches + history copies only.
+    // decoder.0: causal conv k7 H -> Dd; second output = snake of block 0
     int C = c.c_decoder_dim;
-    if ((rc = conv_gemm(m, st, cur, T, H, 7, 1, "codec.dec.in.w", "codec.dec.in.b", alt, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
-    std::swap(cur, alt);
+    void *X = alt, *S = tmp, *Fb = cur;
+    auto snake_tables = [&](int i, const float** a, const float** ib) {      // the snake that consumes block i's input (or the output snake)
+        const std::string q = i < c.n_dec_blocks ? "codec.dec." + std::to_string(i) + ".snake." : std::string("codec.dec.out.");
+        *a = TPF(m, q + "a"); *ib = TPF(m, q + "ib");
+    };
+    {
+        GemmArgs g{};
+        g.A = at(cur, (size_t)(LPAD - 6) * H * e); g.lda = H; g.a_bs = (long)(LPAD + T) * H;
+        g.W = TP(m, "codec.dec.in.w"); g.bias = TPF(m, "codec.dec.in.b");
+        g.C = at(X, (size_t)LPAD * C * e); g.ldc = C; g.c_bs = (long)(LPAD + T) * C;
+        g.M = B * T; g.N = C; g.K = 7 * H; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+        g.tap_len = H; g.tap_stride = H;
+        g.C2 = at(S, (size_t)LPAD * C * e); snake_tables(0, &g.snake2_a, &g.snake2_ib);
+        HLOAD(s_sn, S, T, C);
+        if ((rc = gemm_ex(st, g))) return done(rc);
+        if ((rc = hist_save(S, T, C, s_sn))) return done(rc);
+        stage_ok("decoder in-conv", 0, 0);
+    }
     for (int i = 0; i < c.n_dec_blocks; ++i) {
         const std::string q = "codec.dec." + std::to_string(i) + ".";
         const int r = c.up_rate[i], Co = C >> 1;
-        HLOAD(s_sn, alt, T, C);
-        if ((rc = snake(st, cur, alt, TPF(m, q + "snake.a"), TPF(m, q + "snake.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-        if ((rc = hist_save(alt, T, C, s_sn))) return done(rc);
         // transposed conv k=2r, s=r (trimmed r on both sides): out[(t-1)*r + j] = x[t-1].W[j+r] + x[t].W[j]
         // first chunk: t = 1..T-1; later chunks: t = 0..T-1 with x[-1] = last row of the previous chunk (history row)
         const int Tm = first ? T - 1 : T;
+        void* xbuf = Fb;     // the block's residual stream
+        void* y1 = X;        // snake(x) with history (the old x is dead: its snake is in S)
+        void* y2 = S;        // unit scratch, free once the transposed conv has read S
         {
             GemmArgs g{};
-            g.A = at(alt, (size_t)(first ? LPAD : LPAD - 1) * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+            g.A = at(S, (size_t)(first ? LPAD : LPAD - 1) * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
             g.W = TP(m, q + "tconv.w"); g.bias = TPF(m, q + "tconv.b");
-            g.C = at(tmp, (size_t)LPAD * Co * e); g.ldc = (long)r * Co; g.c_bs = (long)(LPAD + Tm * r) * Co;
+            g.C = at(xbuf, (size_t)LPAD * Co * e); g.ldc = (long)r * Co; g.c_bs = (long)(LPAD + Tm * r) * Co;
             g.M = B * Tm; g.N = r * Co; g.K = 2 * C; g.G = Tm; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+            g.C2 = at(y1, (size_t)LPAD * Co * e); g.snake2_a = TPF(m, q + "ru0.s1.a"); g.snake2_ib = TPF(m, q + "ru0.s1.ib"); g.snake_mod = Co;
+            HLOAD(s_y1, y1, Tm * r, Co);
             if ((rc = gemm_ex(st, g))) return done(rc);
+            if ((rc = hist_save(y1, Tm * r, Co, s_y1))) return done(rc);
+            stage_ok("transposed conv", i, 0);
         }
         T = Tm * r;
         C = Co;
-        void* xbuf = tmp;
-        void* y1 = cur;
-        void* y2 = alt;
         for (int j = 0; j < 3; ++j) {
             const std::string u = q + "ru" + std::to_string(j) + ".";
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            HLOAD(s_y1, y1, T, C);
-            if ((rc = snake(st, xbuf, y1, TPF(m, u + "s1.a"), TPF(m, u + "s1.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-            if ((rc = hist_save(y1, T, C, s_y1))) return done(rc);
-            if ((rc = conv_gemm(m, st, y1, T, C, 7, dil, u + "c1.w", u + "c1.b", y2, LPAD, C, nullptr, S2S_ACT_NONE, dt))) return done(rc);
-            if ((rc = snake(st, y2, y1, TPF(m, u + "s2.a"), TPF(m, u + "s2.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
+            {   // y2 = snake_s2(conv k7 dilated(y1))   (unpadded rows: the 1x1 conv needs no history)
+                GemmArgs g{};
+                g.A = at(y1, (size_t)(LPAD - 6 * dil) * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+                g.W = TP(m, u + "c1.w"); g.bias = TPF(m, u + "c1.b");
+                g.C = y2; g.ldc = C; g.c_bs = (long)T * C;
+                g.M = B * T; g.N = C; g.K = 7 * C; g.G = T; g.ab_dtype = dt; g.c_dtype = dt;
+                g.tap_len = C; g.tap_stride = (long)dil * C;
+                g.act = S2S_ACT_SNAKE; g.snake_a = TPF(m, u + "s2.a"); g.snake_ib = TPF(m, u + "s2.ib");
+                if ((rc = gemm_ex(st, g))) return done(rc);
+                stage_ok("unit conv k7", i, j);
+            }
+            // x += conv 1x1(y2) in place; second output y1 = the NEXT snake of x (next unit's s1, next block's snake, or the output snake)
             GemmArgs g{};
-            g.A = at(y1, (size_t)LPAD * C * e); g.lda = C; g.a_bs = (long)(LPAD + T) * C;
+            g.A = y2; g.lda = C; g.a_bs = (long)T * C;
             g.W = TP(m, u + "c2.w"); g.bias = TPF(m, u + "c2.b");
-            g.C = y2; g.ldc = C; g.c_bs = (long)T * C;     // unpadded model-dtype scratch
+            g.C = at(xbuf, (size_t)LPAD * C * e); g.ldc = C; g.c_bs = (long)(LPAD + T) * C; g.res_c = g.C;
             g.M = B * T; g.N = C; g.K = C; g.G = T; g.ab_dtype = dt; g.c_dtype = dt; g.act = S2S_ACT_NONE;
+            g.C2 = at(y1, (size_t)LPAD * C * e);
+            if (j < 2) {
+                const std::string un = q + "ru" + std::to_string(j + 1) + ".";
+                g.snake2_a = TPF(m, un + "s1.a"); g.snake2_ib = TPF(m, un + "s1.ib");
+            } else {
+                snake_tables(i + 1, &g.snake2_a, &g.snake2_ib);
+            }
+            HLOAD(s_nx, y1, T, C);
             if ((rc = gemm_ex(st, g))) return done(rc);
-            if ((rc = add_into_padded(st, xbuf, y2, B, T, C, LPAD, dt))) return done(rc);
+            if ((rc = hist_save(y1, T, C, s_nx))) return done(rc);
+            stage_ok("unit conv 1x1 + residual", i, j);
         }
-        void* a0 = cur; void* a1 = alt;
-        cur = xbuf; alt = a0; tmp = a1;
+        X = xbuf; S = y1; Fb = y2;
     }
-    // output: snake -> conv k7 C -> 1, clamp
-    HLOAD(s_fin, alt, T, C);
-    if ((rc = snake(st, cur, alt, TPF(m, "codec.dec.out.a"), TPF(m, "codec.dec.out.ib"), B, T, C, LPAD, LPAD, dt))) return done(rc);
-    if ((rc = hist_save(alt, T, C, s_fin))) return done(rc);
-    if ((rc = conv_gemm(m, st, alt, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", tmp, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+    // output: conv k7 C -> 1 over the output snake, clamp
+    if ((rc = conv_gemm(m, st, S, T, C, 7, 1, "codec.dec.out.w", "codec.dec.out.b", Fb, LPAD, 1, nullptr, S2S_ACT_NONE, dt))) return done(rc);
+    tmp = Fb;
 #undef HLOAD
     const long skip = (long)ctx * c.total_upsample;
     S2S_REQUIRE(n_samples == T - skip, "codec_decode: n_samples %d != %ld", n_samples, T - skip);
