@@ -66,6 +66,21 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: k-slice bounds live in SGPRs
+    if (gridDim.y > 1) {
+        // M > 128: blockIdx.y walks slabs of 128 rows (M % 128 == 0); every slab re-streams the weights (L2 / MALL hits after
+        // the first) and is an independent M = 128 problem on shifted row pointers.
+        const long r0 = (long)blockIdx.y * 128;
+        a.A += r0 * (AF ? (long)a.K : a.lda);
+        if constexpr (MODE == 0) a.C = reinterpret_cast<__hip_bfloat16*>(a.C) + r0 * a.ldc;
+        else if constexpr (MODE == 1) a.C = reinterpret_cast<float*>(a.C) + r0 * a.ldc;
+        else {
+            a.X += r0 * a.ldx;
+            if (a.XB) a.XB += r0 * a.ldxb;
+            if (a.ss_out) a.ss_out += r0;
+        }
+        if (a.ss_in) a.ss_in += r0 * (a.ss_rs > 0 ? a.ss_rs : 1);
+        a.M = 128;
+    }
     const int n0 = blockIdx.x * 16 * NF;
     const int steps = a.K >> 5;                                  // k-steps of 32
     const int spw = (steps + DEC_NW - 1) / DEC_NW;
@@ -318,11 +333,12 @@ int launch_dec3(hipStream_t st, const DecGemm& a) {
     constexpr int UC = FR <= 2 ? 8 : FR == 3 ? 6 : FR <= 6 ? 4 : FR <= 9 ? 2 : 1;
     constexpr int UC_ALT = FR == 2 ? 6 : (FR == 5 ? 3 : UC);      // second stage depth for slices UC does not divide (K = 3072)
     const int slabs = cdiv(a.N, 16 * NF);
+    const int rslabs = a.M > 128 ? a.M / 128 : 1;
     const int T = cdiv(a.K >> 5, DEC_NW);
     if (UC_ALT != UC && dec_loaded_steps(T, UC_ALT) < dec_loaded_steps(T, UC))
-        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT>, dim3(slabs), dim3(DEC_NW * 64), 0, st, a);
+        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT>, dim3(slabs, rslabs), dim3(DEC_NW * 64), 0, st, a);
     else
-        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF, NT>, dim3(slabs), dim3(DEC_NW * 64), 0, st, a);
+        launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC, AF, NT>, dim3(slabs, rslabs), dim3(DEC_NW * 64), 0, st, a);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -367,7 +383,7 @@ int dec_nf(const DecGemm& a) {
 }
 
 int gemm_dec(hipStream_t st, const DecGemm& a) {
-    S2S_REQUIRE(a.M >= 1 && a.M <= 128 && a.N > 0 && a.K > 0, "gemm_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    S2S_REQUIRE(a.M >= 1 && (a.M <= 128 || a.M % 128 == 0) && a.N > 0 && a.K > 0, "gemm_dec: bad shape M=%d N=%d K=%d (M <= 128 or a multiple of 128)", a.M, a.N, a.K);
     S2S_REQUIRE(a.K >= 256 && a.K % 32 == 0 && (a.a_frag || a.lda % 8 == 0), "gemm_dec: K=%d must be >= 256 and a multiple of 32, lda a multiple of 8", a.K);
     S2S_REQUIRE((!a.c_frag || (a.mode == 0 && a.ldc % 32 == 0)) && (!a.xb_frag || a.ldxb % 32 == 0), "gemm_dec: fragment-major outputs need a row width that is a multiple of 32");
     S2S_REQUIRE(a.A && a.W && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_dec: operands must be 16-byte aligned");

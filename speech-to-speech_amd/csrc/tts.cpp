@@ -44,7 +44,7 @@ int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, 
 int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype);
 int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
 
-constexpr int DEC_ROWS = 128;   // rows (sessions x new tokens) the norm-free decode path handles per pass
+constexpr int DEC_ROWS = 512;   // most rows (sessions x new tokens) of a norm-free decode pass: <= 128, or a multiple of 128 (gemm_dec row slabs)
 constexpr int SS_PARTS = 256;   // most column slabs of a residual projection (hidden / 16)
 constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
 
@@ -106,6 +106,7 @@ struct Tts {
     SampleParams sp_talker{0.f, 0, 1.f, 1.f, 0ull}, sp_pred{0.f, 0, 1.f, 1.f, 0ull};   // temperature 0: greedy (s2s_tts_set_sampling)
     PickDebug dbg{};                   // teacher forcing / logit capture (s2s_tts_generate_forced); null on the serving path
     int* forced_buf = nullptr;         // [max_batch][max_frames][G], allocated on first forced call
+    int xb_width = 0;                  // columns of xb
     int ss_parts_A = 0;                // parts currently valid in ssA (written by the last residual projection / rows_prep)
     std::vector<void*> owned;          // device buffers created at finalize (folded weights)
 };
@@ -300,11 +301,12 @@ static int finalize(Tts* m) {
         // (ffn / hidden multiples of 32 also make every 16-row tile of the fragment-major weight copies complete)
         // norm-free decode path: RMSNorm weights folded into the columns of the consuming projections (own copies; the
         // prefill path keeps the checkpoint's matrices)
-        S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * std::max(E, P) * e));
+        m->xb_width = (int)std::max(std::max(E, P), (long)c.c_hidden);
+        S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * m->xb_width * e));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * SS_PARTS * DEC_ROWS));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
         m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB);
-        S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * std::max(E, P) * e));   // padding rows of fragment tiles must stay finite
+        S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * m->xb_width * e));   // padding rows of fragment tiles must stay finite
         // The fragment-major copies ("<name>.f": s2s_op_to_frag of the projection, RMSNorm weight folded into qkv / gate-up / the
         // predictor heads) are made once by the host side and shared by every engine replica on the GPU; the norm-free decode
         // path is on only when all of them were registered.
@@ -336,6 +338,20 @@ static int finalize(Tts* m) {
             m->pred.qkv_n.clear();
             m->head_n.clear();
         }
+        {   // the codec's pre-transformer takes the same path when its copies are there (B x chunk frames rows: row slabs of 128)
+            Stack* s = &m->codec;
+            const auto& sc = s->c;
+            const long nq = (long)(sc.heads + 2 * sc.kv_heads) * sc.head_dim;
+            bool ok = all && getenv("S2S_NO_CODEC_DEC") == nullptr && sc.hidden % 32 == 0 && sc.hidden >= 256 && sc.ffn % 32 == 0 && sc.ffn >= 256 && (sc.heads * sc.head_dim) % 32 == 0 &&
+                      sc.heads * sc.head_dim >= 256 && sc.hidden / 16 <= SS_PARTS;
+            s->qkv_n.assign(sc.layers, nullptr); s->gu_n.assign(sc.layers, nullptr); s->o_f.assign(sc.layers, nullptr); s->down_f.assign(sc.layers, nullptr);
+            for (int l = 0; ok && l < sc.layers; ++l) {
+                const std::string p = s->prefix + std::to_string(l) + ".";
+                ok = fragw(p + "qkv.f", nq, sc.hidden, &s->qkv_n[l]) && fragw(p + "gu.f", 2L * sc.ffn, sc.hidden, &s->gu_n[l]) &&
+                     fragw(p + "o.f", sc.hidden, (long)sc.heads * sc.head_dim, &s->o_f[l]) && fragw(p + "down.f", sc.hidden, sc.ffn, &s->down_f[l]);
+            }
+            if (!ok) s->qkv_n.clear();
+        }
     }
     m->finalized = true;
     return S2S_OK;
@@ -350,7 +366,7 @@ static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
 static inline const void* at(const void* p, size_t bytes) { return (const char*)p + bytes; }
 
 static bool dec_fusion_ok(const Tts* m, const Stack& s, int M) {
-    return m->cfg.dtype == S2S_BF16 && M <= DEC_ROWS && !s.qkv_n.empty() && m->xb;
+    return m->cfg.dtype == S2S_BF16 && (M <= 128 || (M % 128 == 0 && M <= DEC_ROWS)) && !s.qkv_n.empty() && m->xb && s.c.hidden <= m->xb_width;
 }
 
 // attention of one stack pass (q/k head norms, RoPE, cache append, softmax(QK^T)V) from m->qkv into m->att
@@ -397,7 +413,7 @@ static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, 
     const auto& c = s.c;
     const int H = c.heads, Hk = c.kv_heads, D = c.head_dim, hid = c.hidden;
     const int nq = (H + 2 * Hk) * D, M = B * T_len;
-    const bool cached = &s == &m->pred;      // the code predictor's matrices are re-read 15 times per frame: keep them in L2 / MALL
+    const bool cached = &s != &m->talker;    // predictor: re-read 15 times per frame; codec: once per 128-row slab - keep them in L2 / MALL
     int rc;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
@@ -828,7 +844,13 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->pos_c, f0, B);
         S2S_LAUNCH_CHECK();
     }
-    if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
+    if (dec_fusion_ok(m, m->codec, B * F)) {
+        if ((rc = rows_prep(st, m->cx, H, m->xb, H, m->ssA, B * F, H, true))) return done(rc);
+        m->ss_parts_A = 1;
+        if ((rc = stack_forward_dec(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F))) return done(rc);
+    } else {
+        if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
+    }
     stage_ok("transformer", 0, 0);
     if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
     S2S_HIP_CHECK(hipMemcpy2DAsync(at(m->ca, (size_t)LPAD * H * e), (size_t)(LPAD + F) * H * e, m->h, (size_t)F * H * e, (size_t)F * H * e, B,

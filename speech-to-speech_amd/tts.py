@@ -209,7 +209,10 @@ def add_fragment_major_weights(tensors: dict, dims: Qwen3TTSDims) -> None:
     widths = (E, P, dims.t_ffn, dims.p_ffn, dims.t_heads * dims.t_head_dim, dims.p_heads * dims.p_head_dim)
     if any(w % 32 or w < 256 for w in widths):
         return
-    for pre, layers in (("talker.", dims.t_layers), ("pred.", dims.p_layers)):
+    stacks = [("talker.", dims.t_layers), ("pred.", dims.p_layers)]
+    if all(w % 32 == 0 and w >= 256 for w in (dims.c_hidden, dims.c_ffn)):
+        stacks.append(("codec.", dims.c_layers))      # the codec's pre-transformer (B x chunk-frames rows, 128-row slabs)
+    for pre, layers in stacks:
         for l in range(layers):
             q = f"{pre}{l}."
             tensors[q + "qkv.f"] = native.to_frag(tensors[q + "qkv.w"], tensors[q + "ln1"])

@@ -203,7 +203,8 @@ def test_gemm_dec_swiglu_matches_float64(M, N, K):
     assert (_f64(out) - want).abs().max().item() <= 6e-3 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("M,hid,ffn,heads_dim", [(64, 2048, 6144, 2048), (48, 1024, 3072, 2048), (128, 2048, 6144, 2048)])
+@pytest.mark.parametrize("M,hid,ffn,heads_dim", [(64, 2048, 6144, 2048), (48, 1024, 3072, 2048), (128, 2048, 6144, 2048), (256, 1024, 3072, 2048),
+                                                (512, 1024, 3072, 1024)])      # M > 128: row slabs of 128 (grid.y), the codec pre-transformer shape
 def test_norm_free_layer_chain_matches_rmsnorm_linear_reference(M, hid, ffn, heads_dim):
     """rows_prep -> qkv(RMS) -> [identity attention] -> out-proj(resid) -> gate/up(RMS, SwiGLU) -> down(resid) vs the float64
     rmsnorm -> linear -> ... chain on the same bf16 weights (the folded matrices are W * gamma rounded to bf16)."""
@@ -238,18 +239,19 @@ def test_norm_free_layer_chain_matches_rmsnorm_linear_reference(M, hid, ffn, hea
 
     X = x0.clone().to(DEV)
     XB = torch.zeros(M, hid, dtype=torch.bfloat16, device=DEV)
-    ssA = torch.zeros(256, 128, device=DEV)
-    ssB = torch.zeros(256, 128, device=DEV)
+    S = max(128, M)      # row stride of the partial-sum arrays
+    ssA = torch.zeros(256, S, device=DEV)
+    ssB = torch.zeros(256, S, device=DEV)
     native.check(lib.s2s_op_rows_prep(native.stream_handle(), native.ptr(X), hid, native.ptr(XB), hid, native.ptr(ssA), M, hid, 0), "rows_prep")
     qkv = torch.zeros(M, heads_dim, dtype=torch.bfloat16, device=DEV)
     # the norm weight is folded by the library's converter (one rounding of W * gamma, like the reference above)
     Wq_f, Wgu_f = to_frag(Wq.to(DEV), g1.to(DEV)), to_frag(Wgu.to(DEV), g2.to(DEV))
-    gemm_dec(XB, Wq_f, M, heads_dim, hid, ss_in=ssA, n_parts=1, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv, w_is_frag=True)
-    gemm_dec(qkv, Wo.to(DEV), M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB)
-    parts_o = lib.s2s_op_gemm_dec_parts(M, hid, 0)
+    gemm_dec(XB, Wq_f, M, heads_dim, hid, ss_in=ssA, n_parts=1, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv, w_is_frag=True)
+    gemm_dec(qkv, Wo.to(DEV), M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB, ss_stride=S)
+    parts_o = lib.s2s_op_gemm_dec_parts(min(M, 128), hid, 0)
     a = torch.zeros(M, ffn, dtype=torch.bfloat16, device=DEV)
-    gemm_dec(XB, Wgu_f, M, ffn, hid, ss_in=ssB, n_parts=parts_o, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True, w_is_frag=True)
-    gemm_dec(a, Wd.to(DEV), M, hid, ffn, mode=2, X=X, XB=XB, ss_out=ssA)
+    gemm_dec(XB, Wgu_f, M, ffn, hid, ss_in=ssB, n_parts=parts_o, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True, w_is_frag=True)
+    gemm_dec(a, Wd.to(DEV), M, hid, ffn, mode=2, X=X, XB=XB, ss_out=ssA, ss_stride=S)
     err = (_f64(X) - x_ref).abs().max().item()
     err_t = (_f64(X) - xt).abs().max().item()
     scale = x_ref.abs().max().item()
