@@ -211,81 +211,159 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
         }
     }
 
-    // epilogue: C fragment (i,j): row = lg*4 + r, col = l15.  Rows outermost so the row mapping (a division only when the
-    // rows are grouped, i.e. conv / batched layouts) is computed once per row instead of once per element.
-    float bv[4];
-    int ncol[4];
-    int nch[4];     // snake channel of the column
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ncol[j] = n0 + wn + j * 16 + l15;
-        bv[j] = (bias && ncol[j] < N) ? bias[ncol[j]] : 0.f;
-        nch[j] = rm.sn_mod > 0 ? ncol[j] % rm.sn_mod : ncol[j];
-        if (ncol[j] >= N) nch[j] = 0;
-    }
-    // the lane's columns are fixed over the row loop: table values live in registers
-    float sa[4], sb[4], ta[4], tb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sa[j] = act == S2S_ACT_SNAKE ? rm.sn_a[nch[j]] : 0.f;
-        sb[j] = act == S2S_ACT_SNAKE ? rm.sn_ib[nch[j]] : 0.f;
-        ta[j] = rm.C2 ? rm.sn2_a[nch[j]] : 0.f;
-        tb[j] = rm.C2 ? rm.sn2_ib[nch[j]] : 0.f;
-    }
+    // Epilogue through LDS, like gemm_tile3_kernel: the C fragments (2- or 4-byte elements strided over rows per lane, which
+    // the texture-address unit serialises into 64 cycles per wave instruction) are staged as f32 rows per wave and read
+    // back row-wise, so every lane moves 16 contiguous bytes of one output row.  The 64 KiB ring only holds 32 of the wave's
+    // 64 rows at pitch 68, so the tile goes out in two halves.  Residual values are fetched first, all of them: the
+    // residual may alias C (in-place adds), and a load can never be hoisted above an earlier store.
+    constexpr int VEC = 16 / (int)sizeof(CT);   // output elements per 16-byte store: 8 (bf16) / 4 (f32)
+    constexpr int LPR = 64 / VEC;               // lanes per output row
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int NIT = 64 / RPI;
+    constexpr int PITCH = 68;
     const bool grouped = rm.G < M;
-    // Residual values first, ALL of them, before any store: the residual may alias C (in-place adds), so the compiler
-    // cannot move a load above an earlier store - interleaved they form 16 serial load -> store round trips per lane.
+    const int cc = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc;
+    const bool full = n + VEC <= N;
+    auto row_off = [&](int m, long& coff, long& roff) {
+        if (grouped) {
+            const int mb = m / rm.G, mr = m - mb * rm.G;
+            coff = (long)mb * rm.c_bs + (long)mr * ldc;
+            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+        } else {
+            coff = (long)m * ldc;
+            roff = (long)m * rm.ldr;
+        }
+    };
+    float rres[NIT][VEC];
     const bool has_res = residual != nullptr || rm.res_c != nullptr;
-    float rres[4][4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int it = 0; it < NIT; ++it) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm + i * 16 + lg * 4 + r;
-            long coff = 0, roff = 0;
-            if (has_res && m < M) {
-                if (grouped) {
-                    const int mb = m / rm.G, mr = m - mb * rm.G;
-                    coff = (long)mb * rm.c_bs + (long)mr * ldc;
-                    roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
-                } else {
-                    coff = (long)m * ldc;
-                    roff = (long)m * rm.ldr;
+        for (int e = 0; e < VEC; ++e) rres[it][e] = 0.f;
+        const int m = m0 + wm + it * RPI + lane / LPR;
+        if (!has_res || m >= M || n >= N) continue;
+        long coff, roff;
+        row_off(m, coff, roff);
+        if (residual) {
+            const float* rp = residual + roff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
+                    rres[it][q * 4 + 0] = r4.x; rres[it][q * 4 + 1] = r4.y; rres[it][q * 4 + 2] = r4.z; rres[it][q * 4 + 3] = r4.w;
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float rv = 0.f;
-                if (has_res && m < M && ncol[j] < N) {
-                    if (residual) rv += residual[roff + ncol[j]];
-                    if (rm.res_c) rv += Elem<CT>::ld((const CT*)rm.res_c + coff + ncol[j]);
-                }
-                rres[i][r][j] = rv;
-            }
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm + i * 16 + lg * 4 + r;
-            if (m >= M) continue;
-            long coff;
-            if (grouped) {
-                const int mb = m / rm.G, mr = m - mb * rm.G;
-                coff = (long)mb * rm.c_bs + (long)mr * ldc;
             } else {
-                coff = (long)m * ldc;
-            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ncol[j] >= N) continue;
-                float v = apply_act(acc[i][j][r] + bv[j], act) * rm.alpha;
-                if (act == S2S_ACT_SNAKE) v = snake_f<CT>(v, sa[j], sb[j]);
-                v += rres[i][r][j];
-                Elem<CT>::st(C + coff + ncol[j], v);
-                if (rm.C2) Elem<CT>::st((CT*)rm.C2 + coff + ncol[j], snake_f<CT>(round_to<CT>(v), ta[j], tb[j]));
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] = rp[e];
             }
         }
+        if (rm.res_c) {
+            const CT* rp = (const CT*)rm.res_c + coff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+                if constexpr (sizeof(CT) == 4) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                    rres[it][0] += r4.x; rres[it][1] += r4.y; rres[it][2] += r4.z; rres[it][3] += r4.w;
+                } else {
+                    const u32x4_t pk = *reinterpret_cast<const u32x4_t*>(rp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        rres[it][2 * q] += bf16_bits_to_f32((unsigned short)(pk[q] & 0xffffu));
+                        rres[it][2 * q + 1] += bf16_bits_to_f32((unsigned short)(pk[q] >> 16));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] += Elem<CT>::ld(rp + e);
+            }
+        }
+    }
+    // per-column constants of the lane's VEC columns: snake tables (channel wraps at sn_mod)
+    const int chmod = rm.sn_mod > 0 ? rm.sn_mod : (1 << 30);
+    float s1a[VEC], s1b[VEC], s2a[VEC], s2b[VEC];
+    {
+        int ch = n < N ? n % chmod : 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bool in = n + e < N;
+            s1a[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_a[ch] : 0.f;
+            s1b[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_ib[ch] : 0.f;
+            s2a[e] = (in && rm.C2) ? rm.sn2_a[ch] : 0.f;
+            s2b[e] = (in && rm.C2) ? rm.sn2_ib[ch] : 0.f;
+            if (++ch == chmod) ch = 0;
+        }
+    }
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nc = n0 + wn + j * 16 + l15;
+        bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
+    }
+    __syncthreads();            // every wave is done reading the ring
+    float* stg = reinterpret_cast<float*>(&lds[0][0]) + wave * (32 * PITCH);
+    auto store_vec = [&](CT* dp, const float* w) {
+        if (full && ((uintptr_t)dp & 15) == 0) {
+            if constexpr (sizeof(CT) == 4) {
+                *reinterpret_cast<float4*>(dp) = make_float4(w[0], w[1], w[2], w[3]);
+            } else {
+                u32x4_t pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pk[q] = (unsigned)f32_to_bf16_bits(w[2 * q]) | ((unsigned)f32_to_bf16_bits(w[2 * q + 1]) << 16);
+                *reinterpret_cast<u32x4_t*>(dp) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (n + e < N) Elem<CT>::st(dp + e, w[e]);
+        }
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stg[(ii * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act(acc[h * 2 + ii][j][r] + bv[j], act) * rm.alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i2 = 0; i2 < NIT / 2; ++i2) {
+            const int it = h * (NIT / 2) + i2;
+            const int hrow = i2 * RPI + lane / LPR;      // row inside the staged half
+            const int m = m0 + wm + h * 32 + hrow;
+            if (m >= M || n >= N) continue;
+            long coff, roff;
+            row_off(m, coff, roff);
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + hrow * PITCH + cc + q * 4);
+                v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
+            }
+            if (act == S2S_ACT_SNAKE) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = snake_f<CT>(v[e], s1a[e], s1b[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += rres[it][e];
+            store_vec(C + coff + n, v);
+            if (rm.C2) {
+                float w[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) w[e] = snake_f<CT>(round_to<CT>(v[e]), s2a[e], s2b[e]);
+                store_vec((CT*)rm.C2 + coff + n, w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();      // the next half overwrites the staging rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // ---- large-M tile GEMM: 256x128 tile, 8 waves, 3-stage LDS ring ----------------------------
