@@ -322,6 +322,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     }
 }
 
+static bool dec_low_regs() {
+    static const bool on = getenv("S2S_DEC_LOWREG") != nullptr;
+    return on;
+}
+
 // loaded k-steps per wave for a slice of T steps with stages of UC: everything past T is re-read and masked
 static inline int dec_loaded_steps(int T, int UC) { return T <= UC ? UC : (T + 2 * UC - 1) / (2 * UC) * (2 * UC); }
 
@@ -335,6 +340,16 @@ int launch_dec3(hipStream_t st, const DecGemm& a) {
     const int slabs = cdiv(a.N, 16 * NF);
     const int rslabs = a.M > 128 ? a.M / 128 : 1;
     const int T = cdiv(a.K >> 5, DEC_NW);
+    // Shallow-stage variant (half the fragments in flight per wave, <= 128 VGPRs): two workgroups fit on a CU, so decode
+    // kernels of DIFFERENT streams (TTS lanes, the STT worker) co-reside instead of splitting the CUs between them.
+    constexpr int UC_LOW = GLU ? 1 : (UC >= 2 ? UC / 2 : 1);
+    if constexpr (MT >= 4 && UC_LOW != UC) {
+        if (dec_low_regs()) {
+            launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC_LOW, AF, NT>, dim3(slabs, rslabs), dim3(DEC_NW * 64), 0, st, a);
+            S2S_LAUNCH_CHECK();
+            return S2S_OK;
+        }
+    }
     if (UC_ALT != UC && dec_loaded_steps(T, UC_ALT) < dec_loaded_steps(T, UC))
         launch_k(gemm_dec_kernel<MT, NF, GLU, MODE, UC_ALT, AF, NT>, dim3(slabs, rslabs), dim3(DEC_NW * 64), 0, st, a);
     else

@@ -44,7 +44,7 @@ int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, 
 int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype);
 int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
 
-constexpr int DEC_ROWS = 512;   // most rows (sessions x new tokens) of a norm-free decode pass: <= 128, or a multiple of 128 (gemm_dec row slabs)
+constexpr int DEC_ROWS = 1024;   // most rows (sessions x new tokens) of a norm-free decode pass: <= 128, or a multiple of 128 (gemm_dec row slabs)
 constexpr int SS_PARTS = 256;   // most column slabs of a residual projection (hidden / 16)
 constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
 
