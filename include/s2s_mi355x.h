@@ -135,13 +135,15 @@ int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, 
                        const float* residual, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                        int32_t ab_dtype, int32_t c_dtype, int32_t act, int32_t flags, float rms_eps);
 
-/* One decode-step projection of the norm-free decoder layer (csrc/gemm_dec.hip; bf16, M <= 128 sessions, K >= 256, K % 32 == 0):
+/* One decode-step projection of the norm-free decoder layer (csrc/gemm_dec.hip; bf16, K >= 256, K % 32 == 0):
  *   acc = A[M,K] @ W[N,K]^T;  out = rstd[m] * acc + bias  with rstd[m] = rsqrt(sum_p ss_in[p*ss_stride + m] * inv_dim + eps)
  *   when ss_in != NULL (RMSNorm of the raw rows A, its weight pre-folded into W's columns), else out = acc + bias.
  *   W is FRAGMENT-MAJOR (s2s_op_to_frag): one contiguous 1 KiB block per (16-row tile, 32-wide k-step) in MFMA operand
  *   order, so that every wave load is one coalesced request; glu != 0: [gate tiles | up tiles], N rows each (N % 16 == 0).
  *   layout bit 0: A is fragment-major too (else row-major [M][lda]); bit 1: mode-0 C is written fragment-major (row width
- *   ldc); bit 2: mode-2 XB is written fragment-major (row width ldxb).
+ *   ldc); bit 2: mode-2 XB is written fragment-major (row width ldxb); bit 3: the weights are re-read by many launches in a
+ *   row (code predictor, codec row slabs): plain cached loads instead of the default non-temporal streaming loads.
+ *   M <= 128, or a multiple of 128 (row slabs of 128 walk grid.y; ss_stride >= M).
  *   mode 0: C bf16 = act(out)   (glu != 0: C = silu(out_gate) * out_up)
  *   mode 1: C f32  = act(out)
  *   mode 2: X f32 [M][ldx] += out in place; XB (optional) = bf16 copy of the new rows; ss_out (optional)

@@ -49,6 +49,13 @@ class MI355XQwen3TTSHandlerArguments:
     qwen3_tts_batch_window_ms: float = field(default=4.0)
     qwen3_tts_lanes: int = field(default=3, metadata={"help": "TTS turn-batches in flight per GPU (engine replicas sharing the weights, one HIP stream each)."})
     qwen3_tts_codec_context_frames: int = field(default=25)
+    # on-device sampler (no counterpart in the reference's arguments: its backend samples internally); folded into gen_kwargs
+    qwen3_tts_gen_do_sample: bool = field(default=False, metadata={"help": "Sample codec tokens on the device instead of greedy decoding."})
+    qwen3_tts_gen_temperature: float = field(default=0.9)
+    qwen3_tts_gen_top_k: int = field(default=50)
+    qwen3_tts_gen_top_p: float = field(default=1.0)
+    qwen3_tts_gen_repetition_penalty: float = field(default=1.05)
+    qwen3_tts_gen_seed: int = field(default=0)
 
 
 @dataclass

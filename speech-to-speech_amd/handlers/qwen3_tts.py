@@ -99,6 +99,9 @@ class MI355XQwen3TTSHandler(BaseHandler):
                                                   tts_chunk_size=self.streaming_chunk_size, tts_ctx_frames=codec_context_frames, tts_lanes=lanes)
         self.pool.ensure_engine("tts", lambda: build_tts_engine(model_name, device, dtype, max_batch, self.max_new_tokens, codec_context_frames,
                                                                self.streaming_chunk_size))
+        eng = self.pool.engine("tts")
+        if hasattr(eng, "configure_sampling"):
+            eng.configure_sampling(gen_kwargs)      # before the lanes clone the engine
         self.pool.warm_tts_lanes()       # load + warm up synchronously, like the reference's setup()
 
     def _estimate_max_new_tokens(self, text: Optional[str]) -> int:

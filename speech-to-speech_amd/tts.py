@@ -337,6 +337,8 @@ class TTSEngine:
         caches / workspace / decode graphs - one per TTS lane of the session pool."""
         rep = TTSEngine(self.dims, None, self.dtype, self.max_batch, self.max_prompt, self.max_frames, self.max_codec_frames, None, self.device,
                         engine_tensors=self._weights)
+        for which, kw in getattr(self, "_sampling", {}).items():      # lanes sample like the engine they were cloned from
+            rep.set_sampling(which, **kw)
         return rep
 
     @property
@@ -394,6 +396,19 @@ class TTSEngine:
         """Seeded sampling for the talker (codebook 0) or the code predictor (residual groups); temperature <= 0 = greedy (default)."""
         native.check(self._lib.s2s_tts_set_sampling(self._h, {"talker": 0, "predictor": 1}[which], float(temperature), int(top_k), float(top_p),
                                                     float(repetition_penalty), int(seed)), "s2s_tts_set_sampling")
+        if not hasattr(self, "_sampling"):
+            self._sampling = {}
+        self._sampling[which] = dict(temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty, seed=seed)
+
+    def configure_sampling(self, gen_kwargs: dict | None) -> None:
+        """Apply a handler's ``gen_kwargs`` (do_sample / temperature / top_k / top_p / repetition_penalty / seed) to the talker and
+        the code predictor; ``do_sample`` false or absent keeps greedy decoding."""
+        g = gen_kwargs or {}
+        if not g.get("do_sample"):
+            return
+        for i, which in enumerate(("talker", "predictor")):
+            self.set_sampling(which, temperature=float(g.get("temperature", 0.9)), top_k=int(g.get("top_k", 50)), top_p=float(g.get("top_p", 1.0)),
+                              repetition_penalty=float(g.get("repetition_penalty", 1.05)) if which == "talker" else 1.0, seed=int(g.get("seed", 0)) + i)
 
     def codec_samples(self, F: int) -> int:
         return int(self._lib.s2s_codec_samples(self._h, F))

@@ -280,6 +280,10 @@ def test_registry_entries_and_lazy_factories():
     assert cfg["model_name"] and cfg["gen_kwargs"]["max_new_tokens"] == 64 and "stt_model_name" not in cfg
     with pytest.raises(TypeError):
         names["mi355x-qwen3"].normalize(object())
+    # the on-device sampler's options reach the handler as gen_kwargs (TTSEngine.configure_sampling)
+    tcfg = names["mi355x-qwen3"].normalize(names["mi355x-qwen3"].config_type(qwen3_tts_gen_do_sample=True, qwen3_tts_gen_top_k=20))
+    assert tcfg["gen_kwargs"]["do_sample"] is True and tcfg["gen_kwargs"]["top_k"] == 20 and tcfg["gen_kwargs"]["temperature"] == 0.9
+    assert "gen_do_sample" not in tcfg and tcfg["lanes"] == 3
     # importing the registry must not import the handler modules or torch-heavy engines
     for m in [k for k in sys.modules if k.startswith("speech_to_speech_amd.handlers") or k.endswith(".whisper") or k.endswith(".tts")]:
         del sys.modules[m]
