@@ -574,6 +574,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------
 
 
+// two f32 -> one dword of bf16 (round to nearest even) with the gfx950 pair conversion v_cvt_pk_bf16_f32
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const hw_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2_t));
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
     constexpr int KT = 64;                       // keys per tile
@@ -590,8 +598,22 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so with (q-block, head, session) in grid
+    // order the q-blocks of one (session, head) - which all stream the SAME K / V^T rows - would land on 8 different L2s and
+    // fetch them 8 times.  Re-map so that every q-block of a pair runs on one XCD (pair -> XCD pair % 8).
+    int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    {
+        const int nq = gridDim.x, npairs = gridDim.y * gridDim.z;
+        if ((npairs & 7) == 0) {
+            const int L = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z);      // dispatch order (x fastest)
+            const int xcd = L & 7, idx = L >> 3;
+            const int pair = (idx / nq) * 8 + xcd;
+            qblk = idx % nq;
+            h = pair % (int)gridDim.y;
+            b = pair / (int)gridDim.y;
+        }
+    }
+    const int q0 = qblk * 128 + wave * 32;
     const int kv = p.kv_len ? min(p.kv_len[b], p.Tk) : p.Tk;
 
     // Q fragments (B operand of S^T = K.Q^T): Q[q = l15 + 16*qf][d = kk*32 + lg*8 .. +7]
@@ -677,8 +699,47 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
         }
         // ---- online softmax per query column (lane-local column l15, rows = keys lg*4+r)
         bf16x8_t pf[2][2];   // [qf][kt32]
+        const bool fast = bias == nullptr && j0 + KT <= kv;      // whole tile valid, no additive bias (the Whisper encoder's case)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
+            if (fast) {
+                // The softmax is the VALU bottleneck of a d_h = 64 flash attention (32 scores per lane per tile against 32
+                // MFMAs per wave), so the common case is stripped to max / fma / v_exp_f32 / add per score and the
+                // hardware pair conversion to bf16: the scale is applied inside the exponent's fma (max over the raw scores,
+                // scale > 0), no masking, no bias.
+                float tmax = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
+#pragma unroll
+                for (int kf = 1; kf < 4; ++kf) tmax = fmaxf(tmax, fmaxf(fmaxf(s[kf][f][0], s[kf][f][1]), fmaxf(s[kf][f][2], s[kf][f][3])));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(mrun[f], tmax * p.scale_log2e);       // finite: the tile has 64 valid keys
+                const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);   // mrun = -inf -> 0
+                float psum = 0.f;
+                float pv[4][4];
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[kf][r] = __builtin_amdgcn_exp2f(fmaf(s[kf][f][r], p.scale_log2e, -mnew));
+                        psum += pv[kf][r];
+                    }
+                psum += __shfl_xor(psum, 16, 64);
+                psum += __shfl_xor(psum, 32, 64);
+                lrun[f] = lrun[f] * alpha + psum;
+                mrun[f] = mnew;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[f][dt] *= alpha;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    u32x4_t w;
+                    w[0] = pack_bf16x2(pv[2 * k2][0], pv[2 * k2][1]);
+                    w[1] = pack_bf16x2(pv[2 * k2][2], pv[2 * k2][3]);
+                    w[2] = pack_bf16x2(pv[2 * k2 + 1][0], pv[2 * k2 + 1][1]);
+                    w[3] = pack_bf16x2(pv[2 * k2 + 1][2], pv[2 * k2 + 1][3]);
+                    pf[f][k2] = __builtin_bit_cast(bf16x8_t, w);
+                }
+                continue;
+            }
             const int q = q0 + f * 16 + l15;
             float tmax = -INFINITY;
 #pragma unroll
