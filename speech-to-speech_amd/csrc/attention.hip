@@ -574,14 +574,6 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------
 
 
-// two f32 -> one dword of bf16 (round to nearest even) with the gfx950 pair conversion v_cvt_pk_bf16_f32
-typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const hw_f32x2_t f = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2_t));
-}
-
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
     constexpr int KT = 64;                       // keys per tile
@@ -732,10 +724,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     u32x4_t w;
-                    w[0] = pack_bf16x2(pv[2 * k2][0], pv[2 * k2][1]);
-                    w[1] = pack_bf16x2(pv[2 * k2][2], pv[2 * k2][3]);
-                    w[2] = pack_bf16x2(pv[2 * k2 + 1][0], pv[2 * k2 + 1][1]);
-                    w[3] = pack_bf16x2(pv[2 * k2 + 1][2], pv[2 * k2 + 1][3]);
+                    w[0] = pack_bf16x2_hw(pv[2 * k2][0], pv[2 * k2][1]);
+                    w[1] = pack_bf16x2_hw(pv[2 * k2][2], pv[2 * k2][3]);
+                    w[2] = pack_bf16x2_hw(pv[2 * k2 + 1][0], pv[2 * k2 + 1][1]);
+                    w[3] = pack_bf16x2_hw(pv[2 * k2 + 1][2], pv[2 * k2 + 1][3]);
                     pf[f][k2] = __builtin_bit_cast(bf16x8_t, w);
                 }
                 continue;

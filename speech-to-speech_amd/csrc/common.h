@@ -133,6 +133,14 @@ __device__ __forceinline__ float f32_unordered(unsigned int u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// two f32 -> one dword of bf16 (round to nearest even) with the gfx950 pair conversion v_cvt_pk_bf16_f32
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2_hw(float lo, float hi) {
+    const hw_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2_t));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -36,6 +36,34 @@ template <> struct MfmaTraits<float> {
     static constexpr int EPC = 4;
 };
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and five fmas instead of the ~35
+// instructions of erff.  Used where the result is rounded to bf16 anyway (resolution 4e-3): the GELU epilogue of the encoder's
+// fc1 GEMM runs 64 elements per thread with nothing else resident on the CU, so its cost is fully exposed.
+__device__ __forceinline__ float gelu_erf_bf16(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = pl * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);      // 1 - erf(z)
+    const float erf_abs = 1.0f - e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+template <typename CT>
+__device__ __forceinline__ float apply_act_t(float v, int act) {
+    if constexpr (sizeof(CT) == 2) {
+        if (act == S2S_ACT_GELU) return gelu_erf_bf16(v);
+    }
+    switch (act) {
+        case S2S_ACT_GELU: return gelu_erf(v);
+        case S2S_ACT_SILU: return v / (1.0f + expf(-v));
+        case S2S_ACT_RELU: return fmaxf(v, 0.f);
+        default: return v;
+    }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case S2S_ACT_GELU: return gelu_erf(v);
@@ -311,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                 u32x4_t pk;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    pk[q] = (unsigned)f32_to_bf16_bits(w[2 * q]) | ((unsigned)f32_to_bf16_bits(w[2 * q + 1]) << 16);
+                    pk[q] = pack_bf16x2_hw(w[2 * q], w[2 * q + 1]);
                 *reinterpret_cast<u32x4_t*>(dp) = pk;
             }
         } else {
@@ -328,7 +356,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    stg[(ii * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act(acc[h * 2 + ii][j][r] + bv[j], act) * rm.alpha;
+                    stg[(ii * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[h * 2 + ii][j][r] + bv[j], act) * rm.alpha;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -618,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act(acc[i][j][r] + bv[j], act) * rm.alpha;
+                    stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -671,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
                     u32x4_t pk;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        pk[q] = (unsigned)f32_to_bf16_bits(w[2 * q]) | ((unsigned)f32_to_bf16_bits(w[2 * q + 1]) << 16);
+                        pk[q] = pack_bf16x2_hw(w[2 * q], w[2 * q + 1]);
                     *reinterpret_cast<u32x4_t*>(dp) = pk;
                 }
             } else {
@@ -945,11 +973,15 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         const int tiles_m = cdiv(M, T3_M), tiles_n = cdiv(N, T3_N);
         constexpr int lds_bytes = T3_NST * T3_STAGE;
         const bool gen = g.tap_len > 0 || K % BK3 != 0;
-        static bool attr_set = false;      // per (T, CT) instantiation; benign race (idempotent)
-        if (!attr_set) {
+        // the dynamic-LDS limit is a per-DEVICE function attribute: one flag per device of this process (a pool per GPU may
+        // live in one process); per (T, CT) instantiation; benign race (idempotent)
+        static bool attr_set[64] = {};
+        int dev = 0;
+        S2S_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
             S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                        ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
