@@ -85,6 +85,7 @@ def parse(argv=None):
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=16.0, help="measurement window of one open-loop probe")
     ap.add_argument("--pool-lanes", type=int, default=3, help="TTS lanes of the SessionPool in the open-loop probe (measured: 6 lanes contend and are slower than 3)")
+    ap.add_argument("--pool-max-batch", type=int, default=None, help="largest STT / TTS batch the SessionPool of the open-loop probe may form (default: 128 for c3, else --sessions)")
     ap.add_argument("--ttfa-bound-ms", type=float, default=1000.0, help="p95 time-to-first-audio bound of the sustained-sessions search")
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the kernel-timestamp roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
@@ -506,13 +507,16 @@ def main():
     if args.reply_frames:
         n_frames = max(CHUNK_FRAMES, args.reply_frames // CHUNK_FRAMES * CHUNK_FRAMES)
     sessions = shard_sessions(B, rank)
+    # engine capacity: the turn-batches of the timed region stay at B sessions; the open-loop probe's SessionPool may batch more
+    # of the queued sessions per pass (measured on C3: 549 sustained sessions with batches of up to 128 vs 416 with 64)
+    MB = max(B, args.pool_max_batch or (128 if wl == "c3" else B))
     audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
     pcm, ns = pack_pcm(audios, dev)                                     # inputs resident in HBM before the timed region
 
     if wdims is not None:
         from speech_to_speech_amd.whisper import WhisperEngine
 
-        stt = WhisperEngine.from_random(wdims, torch.bfloat16, max_batch=B, device=dev, seed=rank)
+        stt = WhisperEngine.from_random(wdims, torch.bfloat16, max_batch=MB, device=dev, seed=rank)
         eos = wdims.vocab - 1
         prompt = [[1, 2, 3, 4]] * B
 
@@ -528,7 +532,7 @@ def main():
         from speech_to_speech_amd.synth_weights import parakeet_state_dict
 
         pd = ParakeetDims.tdt_0_6b()
-        stt = ParakeetEngine(pd, parakeet_state_dict(pd, seed=12, gain=1.0), dtype=torch.bfloat16, max_batch=B, max_seconds=utt_s, device=dev)
+        stt = ParakeetEngine(pd, parakeet_state_dict(pd, seed=12, gain=1.0), dtype=torch.bfloat16, max_batch=MB, max_seconds=utt_s, device=dev)
         ns_partial = [torch.full_like(ns, int(w * 16000)) for w in partial_windows]
 
         def stt_pass(n_dev, seconds):
@@ -548,7 +552,7 @@ def main():
     front = None
     if not args.stt_only:
         K = 1 if args.serial else max(1, args.tts_lanes)
-        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=B, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
+        tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=MB, max_prompt=128, max_frames=n_frames, max_codec_frames=33, device=dev, seed=rank)
         tts_replicas = [tts] + [tts.replica() for _ in range(K - 1)]
         g = torch.Generator().manual_seed(7)
         front = ByteTextFrontend((torch.randn(258, tdims.t_hidden, generator=g)).numpy())
@@ -747,7 +751,7 @@ def main():
             if B > 1:
                 best, tried = sustained_search(probe, value, args.ttfa_bound_ms)
             line["boundary"] = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, "
-                                        f"{lanes} TTS lanes) -> C ABI; uniform-phase staggered turn arrivals, {args.boundary_seconds:g} s window per probe",
+                                        f"batches of up to {MB} sessions, {lanes} TTS lanes) -> C ABI; uniform-phase staggered turn arrivals, {args.boundary_seconds:g} s window per probe",
                                 "ttfa_bound_ms": args.ttfa_bound_ms,
                                 "sustained_sessions": None if best is None else best["sessions"],
                                 "at_sustained": best, "single_session": single, "probes": tried,
