@@ -14,7 +14,7 @@ class MI355XWhisperSTTHandlerArguments:
     stt_model_name: str = field(default="openai/whisper-large-v3", metadata={"help": "Checkpoint directory / hub id (large-v3, distil-large-v3, tiny.en); 'synthetic:<dims>' uses seeded random weights."})
     stt_device: str = field(default="cuda:0", metadata={"help": "GPU whose session pool serves this pipeline unit."})
     stt_torch_dtype: str = field(default="bfloat16", metadata={"help": "bfloat16 (serving) or float32 (exact-f32 parity policy)."})
-    stt_max_batch: int = field(default=64, metadata={"help": "Sessions batched per engine pass on one GPU."})
+    stt_max_batch: int = field(default=128, metadata={"help": "Sessions batched per engine pass on one GPU (engine limit 128)."})
     stt_batch_window_ms: float = field(default=4.0, metadata={"help": "How long the pool waits for more sessions before launching a batch."})
     language: Optional[str] = field(default="en", metadata={"help": "Target language, or 'auto' for on-device language detection."})
     stt_gen_max_new_tokens: int = field(default=128)
@@ -28,7 +28,7 @@ class MI355XParakeetSTTHandlerArguments:
     parakeet_tdt_model_name: str = field(default="nvidia/parakeet-tdt-0.6b-v3")
     parakeet_tdt_device: str = field(default="cuda:0")
     parakeet_tdt_compute_type: str = field(default="bfloat16")
-    parakeet_tdt_max_batch: int = field(default=64)
+    parakeet_tdt_max_batch: int = field(default=128)
     parakeet_tdt_batch_window_ms: float = field(default=4.0)
     parakeet_tdt_max_seconds: float = field(default=30.0)
     language: Optional[str] = field(default="en")
@@ -45,7 +45,7 @@ class MI355XQwen3TTSHandlerArguments:
     qwen3_tts_streaming_chunk_size: int = field(default=8, metadata={"help": "Codec frames per streamed audio chunk (8 = 640 ms)."})
     qwen3_tts_max_new_tokens: int = field(default=1536)
     qwen3_tts_blocksize: int = field(default=512)
-    qwen3_tts_max_batch: int = field(default=64)
+    qwen3_tts_max_batch: int = field(default=128)
     qwen3_tts_batch_window_ms: float = field(default=4.0)
     qwen3_tts_lanes: int = field(default=3, metadata={"help": "TTS turn-batches in flight per GPU (engine replicas sharing the weights, one HIP stream each)."})
     qwen3_tts_codec_context_frames: int = field(default=25)
