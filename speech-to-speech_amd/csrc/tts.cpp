@@ -37,12 +37,9 @@ int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* ou
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
                  int dim, int accumulate, const void* addvec, int dtype);
 int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* h, long rows, int Q, int cb, int dim, int dtype);
-int snake(hipStream_t st, const void* x, void* y, const float* a, const float* invb, int B, int Tn, int C, int lpad_in, int lpad_out, int dtype);
 int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias, const float* g, const float* be, void* y, int B,
                int Tn, int C, int lpad, float eps, int dtype);
 int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, int skip, int n, int dtype);
-int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype);
-int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype);
 
 constexpr int DEC_ROWS = 1024;   // most rows (sessions x new tokens) of a norm-free decode pass: <= 128, or a multiple of 128 (gemm_dec row slabs)
 constexpr int SS_PARTS = 256;   // most column slabs of a residual projection (hidden / 16)
@@ -60,8 +57,9 @@ struct Stack {
     std::string prefix;      // weight name prefix, e.g. "talker."
     void *kc = nullptr, *vc = nullptr;          // [L][B][max_pos][Hk*D]
     const float *cosT = nullptr, *sinT = nullptr;
-    // bf16 decode path: per layer, the projections that consume a normed input with the RMSNorm weight folded into their
-    // columns (qkv <- ln1, gate/up <- ln2), so that the norm itself runs inside the GEMM (GemmArgs::a_f32_rms)
+    // bf16 decode path (norm-free layer, gemm_dec.hip): per layer, the projections that consume a normed input with the RMSNorm
+    // weight folded into their columns (qkv <- ln1, gate/up <- ln2); the reciprocal RMS is applied in their epilogue from the
+    // partial sums of squares the previous residual projection wrote
     std::vector<void*> qkv_n, gu_n;         // fragment-major, norm weight folded in
     std::vector<void*> o_f, down_f;          // fragment-major copies of the residual projections
 };

@@ -465,30 +465,6 @@ int code_embed_mean(hipStream_t st, const void* table, const int* codes, float* 
 
 // ---- codec decoder elementwise -------------------------------------------------------------------------
 // Activation buffers are time-major with `lpad` zero rows in front of every item: [B][lpad + T][C].
-// SnakeBeta: y = x + sin^2(x * a) * invb, a = exp(alpha), invb = 1 / (exp(beta) + 1e-9)   (per channel)
-template <typename T>
-__global__ void snake_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ a, const float* __restrict__ invb,
-                             int Tn, int C, int lpad_in, int lpad_out) {
-    const int b = blockIdx.y;
-    const long total = (long)Tn * C;
-    const T* xb = x + ((long)b * (lpad_in + Tn) + lpad_in) * C;
-    T* yb = y + ((long)b * (lpad_out + Tn) + lpad_out) * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const float v = Elem<T>::ld(xb + i);
-        const float s = sinf(v * a[c]);
-        Elem<T>::st(yb + i, v + s * s * invb[c]);
-    }
-}
-
-int snake(hipStream_t st, const void* x, void* y, const float* a, const float* invb, int B, int Tn, int C, int lpad_in, int lpad_out,
-          int dtype) {
-    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
-    S2S_DT(TT, (snake_kernel<TT><<<grid, 256, 0, st>>>((const TT*)x, (TT*)y, a, invb, Tn, C, lpad_in, lpad_out)));
-    S2S_LAUNCH_CHECK();
-    return S2S_OK;
-}
-
 // ConvNeXt head: causal depthwise conv k7 over time (channels-last) followed by LayerNorm over channels.
 // x [B][lpad+T][C] -> y [B][T][C] (no padding, GEMM input).  One wave per output row; C <= 2048.
 template <typename T>
@@ -542,41 +518,6 @@ int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias,
     S2S_REQUIRE(C <= 2048 && lpad >= 6, "convnext: C=%d lpad=%d unsupported", C, lpad);
     dim3 grid(cdiv(Tn, 4), B);
     S2S_DT(TT, (dwconv7_ln_kernel<TT><<<grid, 256, 0, st>>>((const TT*)x, w, bias, g, be, (TT*)y, Tn, C, lpad, eps)));
-    S2S_LAUNCH_CHECK();
-    return S2S_OK;
-}
-
-// x[b][lpad + t][c] += y[b][t][c]   (y unpadded, f32 or model dtype)
-template <typename T, typename Y>
-__global__ void add_into_padded_kernel(T* __restrict__ x, const Y* __restrict__ y, int Tn, int C, int lpad) {
-    const int b = blockIdx.y;
-    const long total = (long)Tn * C;
-    T* xb = x + ((long)b * (lpad + Tn) + lpad) * C;
-    const Y* yb = y + (long)b * total;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-        Elem<T>::st(xb + i, Elem<T>::ld(xb + i) + Elem<Y>::ld(yb + i));
-}
-
-// dst[b][lpad + t][c] = src[b][lpad + t][c] + y[b][t][c]   (dst, src padded model-dtype buffers; y f32 unpadded)
-template <typename T>
-__global__ void add_f32_padded_kernel(T* __restrict__ dst, const T* __restrict__ src, const float* __restrict__ y, int Tn, int C, int lpad) {
-    const int b = blockIdx.y;
-    const long total = (long)Tn * C;
-    const long off = ((long)b * (lpad + Tn) + lpad) * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-        Elem<T>::st(dst + off + i, Elem<T>::ld(src + off + i) + y[(long)b * total + i]);
-}
-
-int add_f32_padded(hipStream_t st, void* dst, const void* src, const float* y, int B, int Tn, int C, int lpad, int dtype) {
-    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
-    S2S_DT(TT, (add_f32_padded_kernel<TT><<<grid, 256, 0, st>>>((TT*)dst, (const TT*)src, y, Tn, C, lpad)));
-    S2S_LAUNCH_CHECK();
-    return S2S_OK;
-}
-
-int add_into_padded(hipStream_t st, void* x, const void* y, int B, int Tn, int C, int lpad, int dtype) {
-    dim3 grid((unsigned)std::min<long>(cdiv((long)Tn * C, 256), 2048), B);
-    S2S_DT(TT, (add_into_padded_kernel<TT, TT><<<grid, 256, 0, st>>>((TT*)x, (const TT*)y, Tn, C, lpad)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
