@@ -182,3 +182,61 @@ def test_tts_handler_splits_over_long_text_instead_of_truncating():
     assert len(pieces) >= 4 and all(len(p.encode()) <= 30 for p, _ in pieces)
     assert " ".join(p for p, _ in pieces).split() == text.split()          # nothing dropped, order kept
     assert [p for p, _ in h._build_prompts("short")] == ["short"]
+
+
+# ---- bench.py host logic (no GPU): the sustained-sessions search and the profile reducers ------------------------------------
+def _load_bench():
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location("s2s_bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_sustained_search_brackets_the_capacity():
+    """A fake pool that keeps p95 TTFA under the bound up to 500 sessions: the search must return the largest passing probe, never a
+    failing one, and must stop within its probe budget."""
+    bench = _load_bench()
+    calls = []
+
+    def probe(n):
+        calls.append(n)
+        ok = n <= 500
+        return {"sessions": n, "turns_arrived": n, "turns_completed": n if n <= 800 else n - 1, "p95_ttfa_ms": 400.0 + n if ok else 1000.0 + n,
+                "max_playback_lag_ms": 0.0}
+
+    best, tried = bench.sustained_search(probe, n_hint=1000, bound_ms=1000.0)
+    assert calls[0] == 700 and len(calls) <= 4 and len(tried) == len(calls)
+    assert best is not None and best["sustained"] and best["sessions"] <= 500
+    assert best["sessions"] == max(r["sessions"] for r in tried if r["sustained"])
+    assert all(r["sustained"] == (r["sessions"] <= 500) for r in tried)
+    # nothing passes: no sustained figure is reported
+    best, tried = bench.sustained_search(lambda n: {"sessions": n, "turns_arrived": 5, "turns_completed": 4, "p95_ttfa_ms": 10.0, "max_playback_lag_ms": 0.0},
+                                         n_hint=100, bound_ms=1000.0)
+    assert best is None and tried and not any(r["sustained"] for r in tried)
+
+
+def test_session_sharding_is_disjoint_and_complete():
+    bench = _load_bench()
+    shards = [bench.shard_sessions(64, r) for r in range(8)]
+    flat = [s for sh in shards for s in sh]
+    assert flat == list(range(8 * 64)) and all(len(sh) == 64 for sh in shards)
+
+
+def test_prof_families_reducer_on_a_synthetic_stats_csv(tmp_path):
+    """tools/prof_families.py recomputes the per-family kernel time from a rocprofv3 --stats CSV alone."""
+    import subprocess
+    import sys as _sys
+
+    csv_path = tmp_path / "k_kernel_stats.csv"
+    csv_path.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                        '"void s2s::(anonymous namespace)::gemm_dec_kernel<4, 1, false, 0, 4, true, true>(s2s::DecGemm)",1000,10000000,10000,50,1,2,0\n'
+                        '"void s2s::gemm_tile3_kernel<__hip_bfloat16, __hip_bfloat16, false>(__hip_bfloat16 const*)",10,5000000,500000,25,1,2,0\n'
+                        '"void s2s::attn_mfma_kernel<64>(s2s::AttnMfmaParams)",2,4000000,2000000,20,1,2,0\n'
+                        '"void s2s::attn_step_kernel<__hip_bfloat16, 128>(s2s::AttnStepParams)",100,1000000,10000,5,1,2,0\n')
+    root = __import__("pathlib").Path(__file__).resolve().parents[1]
+    out = subprocess.run([_sys.executable, str(root / "tools" / "prof_families.py"), str(csv_path), "2"], capture_output=True, text=True, check=True).stdout
+    assert "gemm_dec" in out and "5.00 ms per turn-batch" in out and "avg   10.00 us" in out.replace("avg    10.00", "avg   10.00")
+    assert "gemm_tile" in out and "2.50 ms per turn-batch" in out
