@@ -19,6 +19,7 @@
 //
 // Element types: bf16 inputs -> v_mfma_f32_16x16x32_bf16, f32 inputs ->
 // v_mfma_f32_16x16x4_f32 (exact f32, used by the parity policy).  Accumulation is f32.
+#include <type_traits>
 #include "ops.h"
 
 #include <algorithm>
@@ -735,6 +736,222 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     }
 }
 
+// ---- 256x256 tile GEMM: 4 waves of 128x128, 4-stage ring of 32-wide K slabs (bf16) -------------------------------------------
+// EXPERIMENTAL (S2S_TILE4=1; off by default: written at the end of round 2 without GPU time left to validate it - the
+// addressing is checked by tools/proto/tile4_addressing_check.py, parity and timing by tools/proto/tile4_check.py).
+// Why: gemm_tile3's 64x64 wave tiles need 32 flop per LDS byte - exactly what the LDS delivers (128 B/clk/CU against
+// 4069 flop/clk/CU) - so its main loop can not pass ~50 % of the MFMA peak.  Here every wave owns a 128x128 output block
+// (8x8 fragments, 256 accumulator registers, one wave per SIMD): 16 fragment reads feed 64 MFMAs per 32-wide K slab, i.e.
+// 64 flop per LDS byte.  The ring holds FOUR 32 KiB slabs (256 A rows + 256 W rows of 64 bytes), three of them in flight
+// behind the one being multiplied (1.3 us of look-ahead at full MFMA rate); loads past the end of K stream the zero page so
+// that the `s_waitcnt vmcnt(16)` before every slab is the same instruction for the whole loop.  LDS rows are 64 bytes = 4
+// chunks of 16; chunk p of row r holds logical chunk p ^ ((r >> 2) & 3), which makes the 16 rows x 16 bytes of one
+// fragment-read group hit 64 distinct banks (rows r, r+4, r+8, r+12 share a 64-byte bank window and take different chunks).
+constexpr int T4_M = 256, T4_N = 256, T4_BK = 32, T4_ROWB = 64, T4_A_BYTES = T4_M * T4_ROWB, T4_W_BYTES = T4_N * T4_ROWB,
+              T4_STAGE = T4_A_BYTES + T4_W_BYTES, T4_NST = 4, T4_PITCH = 132;
+
+template <typename CT>
+__global__ __launch_bounds__(256) void gemm_tile4_kernel(
+    const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
+    using T = __hip_bfloat16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
+    {
+        const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
+        A += z1 * rm.a_z1 + z2 * rm.a_z2;
+        W += z1 * rm.w_z1 + z2 * rm.w_z2;
+        C += z1 * rm.c_z1 + z2 * rm.c_z2;
+        if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
+    }
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(wg, tiles_m, (int)gridDim.x / tiles_m, tm, tn);
+    const int m0 = tm * T4_M, n0 = tn * T4_N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
+
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: each operand tile = 256 rows x 4 chunks of 16 bytes = 1024 chunks, 4 per thread; chunk c -> (row c >> 2, slot c & 3),
+    // LDS byte c * 16; the SOURCE chunk of slot p is p ^ ((row >> 2) & 3).  Rows past M / N stream the zero page with step 0.
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const T* pa[4];
+    const T* pw[4];
+    int sa[4], sw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256, row = c >> 2;
+        const int lch = (c & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row, n = n0 + row;
+        pa[i] = zero; sa[i] = 0;
+        pw[i] = zero; sw[i] = 0;
+        if (m < M) {
+            const T* rowp = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+            pa[i] = rowp + lch * 8;
+            sa[i] = T4_BK;
+        }
+        if (n < N) {
+            pw[i] = W + (long)n * rm.ldw + lch * 8;
+            sw[i] = T4_BK;
+        }
+    }
+    const int wave_base = __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto issue = [&](int stage, bool live) {
+        unsigned char* base = lds4 + stage * T4_STAGE + wave_base;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? pa[i] : zero),
+                                             (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+            pa[i] += sa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? pw[i] : zero),
+                                             (__attribute__((address_space(3))) void*)(base + T4_A_BYTES + i * 4096), 16, 0, 0);
+            pw[i] += sw[i];
+        }
+    };
+
+    const int nk = K / T4_BK;
+    issue(0, true);
+    issue(1, 1 < nk);
+    issue(2, 2 < nk);
+    // fragment byte offsets inside a stage (constant over the loop): row * 64 + ((lg ^ ((row >> 2) & 3)) << 4)
+    int offa[8], offw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm + i * 16 + l15, rw = wn + i * 16 + l15;
+        offa[i] = ra * T4_ROWB + ((lg ^ ((ra >> 2) & 3)) << 4);
+        offw[i] = T4_A_BYTES + rw * T4_ROWB + ((lg ^ ((rw >> 2) & 3)) << 4);
+    }
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        S2S_WAIT_VMCNT(16);                  // slab t has landed; the 8 + 8 loads of slabs t + 1 and t + 2 may still be in flight
+        __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading slab t - 1's stage
+        issue(stage >= 1 ? stage - 1 : T4_NST - 1, t + 3 < nk);      // (t + 3) % 4 == (t - 1) % 4
+        const unsigned char* sS = lds4 + stage * T4_STAGE;
+        bf16x8_t fa[8], fw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(sS + offa[i]);
+            fw[i] = *reinterpret_cast<const bf16x8_t*>(sS + offw[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+        stage = stage + 1 == T4_NST ? 0 : stage + 1;
+    }
+    S2S_WAIT_VMCNT(0);                       // the zero-page loads past the end of K still target the ring
+    __builtin_amdgcn_s_barrier();
+
+    // Epilogue: 8 passes of 16 rows per wave, staged through LDS (pitch 132 floats: conflict-free fragment writes) and read
+    // back row-wise so that every lane moves 16 contiguous bytes of one output row.  The residual values of a pass are
+    // fetched before its first store (the residual may alias C).
+    constexpr int VEC = 16 / (int)sizeof(CT);   // 8 (bf16) / 4 (f32)
+    constexpr int LPR = 128 / VEC;              // lanes per 128-column row: 16 / 32
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction: 4 / 2
+    constexpr int NIT = 16 / RPI;               // instructions per 16-row pass: 4 / 8
+    const bool grouped = rm.G < M;
+    const int cc = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc;
+    const bool full = n + VEC <= N;
+    float* stg = reinterpret_cast<float*>(lds4) + wave * (16 * T4_PITCH);
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int nc = n0 + wn + j * 16 + l15;
+        bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
+    }
+    auto row_off = [&](int m, long& coff, long& roff) {
+        if (grouped) {
+            const int mb = m / rm.G, mr = m - mb * rm.G;
+            coff = (long)mb * rm.c_bs + (long)mr * ldc;
+            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+        } else {
+            coff = (long)m * ldc;
+            roff = (long)m * rm.ldr;
+        }
+    };
+    // (the pass index must be a compile-time constant: a loop the compiler declines to unroll would index the accumulators
+    // dynamically and copy all 256 of them to scratch)
+    auto pass = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        float rres[NIT][VEC];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) rres[it][e] = 0.f;
+            const int m = m0 + wm + i * 16 + it * RPI + lane / LPR;
+            if (residual == nullptr || m >= M || n >= N) continue;
+            long coff, roff;
+            row_off(m, coff, roff);
+            const float* rp = residual + roff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
+                    rres[it][q * 4 + 0] = r4.x; rres[it][q * 4 + 1] = r4.y; rres[it][q * 4 + 2] = r4.z; rres[it][q * 4 + 3] = r4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] = rp[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stg[(lg * 4 + r) * T4_PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int prow = it * RPI + lane / LPR;      // row inside the staged pass
+            const int m = m0 + wm + i * 16 + prow;
+            if (m >= M || n >= N) continue;
+            long coff, roff;
+            row_off(m, coff, roff);
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + prow * T4_PITCH + cc + q * 4);
+                v[q * 4 + 0] = t4.x + rres[it][q * 4 + 0]; v[q * 4 + 1] = t4.y + rres[it][q * 4 + 1];
+                v[q * 4 + 2] = t4.z + rres[it][q * 4 + 2]; v[q * 4 + 3] = t4.w + rres[it][q * 4 + 3];
+            }
+            CT* dp = C + coff + n;
+            if (full && ((uintptr_t)dp & 15) == 0) {
+                if constexpr (sizeof(CT) == 4) {
+                    *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2_hw(v[2 * q], v[2 * q + 1]);
+                    *reinterpret_cast<u32x4_t*>(dp) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) Elem<CT>::st(dp + e, v[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();      // the next pass overwrites the staging rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
+    pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
+}
+
 // ---- skinny (decode) GEMM --------------------------------------------------
 // M <= 64 rows (one per live session): pure weight streaming.  One workgroup of 8 waves owns a 16-column slab of
 // W over the WHOLE of K; the 8 waves split K, so every weight element is read exactly once, straight from HBM into
@@ -911,6 +1128,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     }
 }
 
+// the experimental 256x256 kernel serves the encoder-sized bf16 projections when S2S_TILE4 is set
+template <typename T>
+static bool tile4_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
+    static const bool on = getenv("S2S_TILE4") != nullptr;
+    return on && sizeof(T) == 2 && !ext && g.tap_len == 0 && K % T4_BK == 0 && K >= 4 * T4_BK && M >= 2048 && N >= 512 &&
+           (long)cdiv(M, T4_M) * cdiv(N, T4_N) * nz >= 192;
+}
+
 static bool tile3_disabled() {
     static const bool off = getenv("S2S_NO_TILE3") != nullptr;   // A/B switch for tools/bench_ops.py
     return off;
@@ -985,6 +1210,22 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SK_MT
 #undef S2S_SK
 #undef S2S_SK1
+    } else if (tile4_ok<T>(g, M, N, K, nz, ext)) {
+        if constexpr (sizeof(T) == 2) {
+            const int tiles_m = cdiv(M, T4_M), tiles_n = cdiv(N, T4_N);
+            constexpr int lds_bytes = T4_NST * T4_STAGE;
+            static bool attr4[64] = {};
+            int dev = 0;
+            S2S_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr4[dev]) {
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+                if (dev >= 0 && dev < 64) attr4[dev] = true;
+            }
+            ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
+                           ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+            launch_k(gemm_tile4_kernel<CT>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+        }
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
                (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {
         const int tiles_m = cdiv(M, T3_M), tiles_n = cdiv(N, T3_N);
