@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.sampling import processed_probs      # pinned against transformers' logits processors in tests/test_oracle_sampling.py
 from speech_to_speech_amd import native
 
 pytestmark = pytest.mark.gpu
@@ -22,28 +23,6 @@ def sample(logits, temperature, top_k=0, top_p=1.0, rep=1.0, seed=1, hist=None):
     native.check(lib.s2s_op_sample_tokens(native.stream_handle(), native.ptr(lg), B, V, float(temperature), int(top_k), float(top_p), float(rep), int(seed),
                                           native.ptr(h), 0 if h is None else h.shape[1], native.ptr(out)), "s2s_op_sample_tokens")
     return out.cpu().numpy()
-
-
-def processed_probs(row, temperature, top_k, top_p, rep, hist):
-    """numpy restatement of transformers' RepetitionPenalty -> Temperature -> TopK -> TopP logits processors + softmax."""
-    x = row.astype(np.float64).copy()
-    if rep != 1.0 and hist is not None:
-        for t in set(int(i) for i in hist if i >= 0):
-            x[t] = x[t] / rep if x[t] > 0 else x[t] * rep
-    x = x / temperature
-    if 0 < top_k < len(x):
-        kth = np.sort(x)[-top_k]
-        x[x < kth] = -np.inf
-    if top_p < 1.0:
-        order = np.argsort(x, kind="stable")                  # ascending
-        p = np.exp(x[order] - x.max())
-        p /= p.sum()
-        remove = np.cumsum(p) <= 1.0 - top_p
-        remove[-1] = False
-        x[order[remove]] = -np.inf
-    p = np.exp(x - x[np.isfinite(x)].max())
-    p[~np.isfinite(x)] = 0.0
-    return p / p.sum()
 
 
 @pytest.mark.parametrize("V,temperature,top_k,top_p,rep", [(64, 1.0, 0, 1.0, 1.0), (2048, 0.9, 50, 1.0, 1.0), (3072, 1.0, 50, 0.8, 1.05), (2048, 0.7, 0, 0.9, 1.0),
