@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream")
     ap.add_argument("--tts-lanes", type=int, default=3, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
+    ap.add_argument("--tts-merge", type=int, default=1, help="STT turn-batches merged into ONE TTS run on a lane (2 x 64 sessions = 128 rows per decode kernel; "
+                    "experimental, default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=16.0, help="measurement window of one open-loop probe")
@@ -510,6 +512,10 @@ def main():
     # engine capacity: the turn-batches of the timed region stay at B sessions; the open-loop probe's SessionPool may batch more
     # of the queued sessions per pass (measured on C3: 549 sustained sessions with batches of up to 128 vs 416 with 64)
     MB = max(B, args.pool_max_batch or (128 if wl == "c3" else B))
+    merge = max(1, int(args.tts_merge))
+    MB = max(MB, merge * B)
+    if MB > 128:
+        raise SystemExit(f"--tts-merge {merge} x --sessions {B} exceeds the engines' batch limit of 128")
     audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
     pcm, ns = pack_pcm(audios, dev)                                     # inputs resident in HBM before the timed region
 
@@ -608,16 +614,22 @@ def main():
         ths = [threading.Thread(target=tts_worker, args=(e,)) for e in tts_replicas]
         [t.start() for t in ths]
         try:
-            for _ in range(n):
+            pending, t_first = [], None
+            for k in range(n):
                 if err:
                     break
                 t0 = time.perf_counter()
                 ids = run_stt()
                 with stage_lock:
                     stage["stt"] += time.perf_counter() - t0
+                pending.extend(ids)
+                t_first = t0 if t_first is None else t_first
+                if (k + 1) % merge and k + 1 < n:
+                    continue            # --tts-merge: the lane gets this turn-batch together with the next one
+                item, pending, t_first = (pending, t_first), [], None
                 while not err:
                     try:
-                        q.put((ids, t0), timeout=1.0)
+                        q.put(item, timeout=1.0)
                         break
                     except queue.Full:
                         pass
@@ -729,7 +741,7 @@ def main():
                                f"{n_frames} codec frames ({n_frames * FRAME_S:.2f} s reply) streamed in {CHUNK_FRAMES}-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames * FRAME_S,
                    "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
-                   "tts_lanes": len(tts_replicas), "decode_graphs": not args.no_graphs,
+                   "tts_lanes": len(tts_replicas), "tts_merge": merge, "decode_graphs": not args.no_graphs,
                    "schedule": "serial" if (args.serial or tts is None) else f"pipelined: STT legs back to back on one stream; TTS legs on {len(tts_replicas)} lane(s) (thread + HIP stream each) overlapping the following turn-batches",
                    "parallelism": f"session-pool x{world} (no collectives; gloo barrier + MAX of the step time)"},
         "xrt": round(value, 2),          # audio seconds (utterance in + reply out) processed per wall second, whole job
