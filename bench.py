@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream")
     ap.add_argument("--tts-lanes", type=int, default=3, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
+    ap.add_argument("--lane-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the TTS lanes (-1 = high: their short latency-bound "
+                    "kernels are dispatched ahead of the encoder's workgroups; experimental, default 0)")
     ap.add_argument("--tts-merge", type=int, default=1, help="STT turn-batches merged into ONE TTS run on a lane (2 x 64 sessions = 128 rows per decode kernel; "
                     "experimental, default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -601,7 +603,7 @@ def main():
         def tts_worker(eng):
             try:
                 torch.cuda.set_device(dev)
-                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=args.lane_priority)):
                     while True:
                         item = q.get()
                         if item is None:
@@ -741,7 +743,7 @@ def main():
                                f"{n_frames} codec frames ({n_frames * FRAME_S:.2f} s reply) streamed in {CHUNK_FRAMES}-frame chunks" + (" [STT only]" if args.stt_only else ""),
                    "sessions_per_gpu": B, "utterance_seconds": utt_s, "reply_seconds": 0.0 if args.stt_only else n_frames * FRAME_S,
                    "stages_ms_per_step": {k: round(v / args.steps * 1e3, 1) for k, v in stage.items()},
-                   "tts_lanes": len(tts_replicas), "tts_merge": merge, "decode_graphs": not args.no_graphs,
+                   "tts_lanes": len(tts_replicas), "tts_merge": merge, "lane_priority": args.lane_priority, "decode_graphs": not args.no_graphs,
                    "schedule": "serial" if (args.serial or tts is None) else f"pipelined: STT legs back to back on one stream; TTS legs on {len(tts_replicas)} lane(s) (thread + HIP stream each) overlapping the following turn-batches",
                    "parallelism": f"session-pool x{world} (no collectives; gloo barrier + MAX of the step time)"},
         "xrt": round(value, 2),          # audio seconds (utterance in + reply out) processed per wall second, whole job
