@@ -748,10 +748,13 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
 // chunks of 16; chunk p of row r holds logical chunk p ^ ((r >> 2) & 3), which makes the 16 rows x 16 bytes of one
 // fragment-read group hit 64 distinct banks (rows r, r+4, r+8, r+12 share a 64-byte bank window and take different chunks).
 constexpr int T4_M = 256, T4_N = 256, T4_BK = 32, T4_ROWB = 64, T4_A_BYTES = T4_M * T4_ROWB, T4_W_BYTES = T4_N * T4_ROWB,
-              T4_STAGE = T4_A_BYTES + T4_W_BYTES, T4_NST = 4, T4_PITCH = 132;
+              T4_STAGE = T4_A_BYTES + T4_W_BYTES, T4_NST = 4;
 
-template <typename CT>
-__global__ __launch_bounds__(256) void gemm_tile4_kernel(
+// NWN = 2: 4 waves (2 x 2), wave tile 128 x 128 (64 flop per LDS byte, one wave per SIMD).
+// NWN = 4: 8 waves (2 x 4), wave tile 128 x 64 (44 flop per LDS byte, 128 accumulator registers, TWO waves per SIMD that hide
+//          each other's fragment reads).  Which one wins is a measurement (S2S_TILE4=1 / =2).
+template <typename CT, int NWN>
+__global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
     using T = __hip_bfloat16;
@@ -769,23 +772,27 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
     const int m0 = tm * T4_M, n0 = tn * T4_N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
+    constexpr int NTH = 128 * NWN;              // threads
+    constexpr int WNF = 16 / NWN;               // 16-column fragments per wave: 8 / 4
+    constexpr int WCOLS = WNF * 16;             // wave tile width: 128 / 64
+    constexpr int CPT = 1024 / NTH;             // 16-byte chunks per thread and operand tile: 4 / 2
+    const int wm = (wave / NWN) * 128, wn = (wave % NWN) * WCOLS;
 
-    f32x4_t acc[8][8];
+    f32x4_t acc[8][WNF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WNF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // staging: each operand tile = 256 rows x 4 chunks of 16 bytes = 1024 chunks, 4 per thread; chunk c -> (row c >> 2, slot c & 3),
+    // staging: each operand tile = 256 rows x 4 chunks of 16 bytes = 1024 chunks, CPT per thread; chunk c -> (row c >> 2, slot c & 3),
     // LDS byte c * 16; the SOURCE chunk of slot p is p ^ ((row >> 2) & 3).  Rows past M / N stream the zero page with step 0.
     const T* zero = reinterpret_cast<const T*>(g_zero_page);
-    const T* pa[4];
-    const T* pw[4];
-    int sa[4], sw[4];
+    const T* pa[CPT];
+    const T* pw[CPT];
+    int sa[CPT], sw[CPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256, row = c >> 2;
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * NTH, row = c >> 2;
         const int lch = (c & 3) ^ ((row >> 2) & 3);
         const int m = m0 + row, n = n0 + row;
         pa[i] = zero; sa[i] = 0;
@@ -804,15 +811,15 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
     auto issue = [&](int stage, bool live) {
         unsigned char* base = lds4 + stage * T4_STAGE + wave_base;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? pa[i] : zero),
-                                             (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + i * (NTH * 16)), 16, 0, 0);
             pa[i] += sa[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? pw[i] : zero),
-                                             (__attribute__((address_space(3))) void*)(base + T4_A_BYTES + i * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + T4_A_BYTES + i * (NTH * 16)), 16, 0, 0);
             pw[i] += sw[i];
         }
     };
@@ -822,29 +829,32 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
     issue(1, 1 < nk);
     issue(2, 2 < nk);
     // fragment byte offsets inside a stage (constant over the loop): row * 64 + ((lg ^ ((row >> 2) & 3)) << 4)
-    int offa[8], offw[8];
+    int offa[8], offw[WNF];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int ra = wm + i * 16 + l15, rw = wn + i * 16 + l15;
+        const int ra = wm + i * 16 + l15;
         offa[i] = ra * T4_ROWB + ((lg ^ ((ra >> 2) & 3)) << 4);
-        offw[i] = T4_A_BYTES + rw * T4_ROWB + ((lg ^ ((rw >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < WNF; ++j) {
+        const int rw = wn + j * 16 + l15;
+        offw[j] = T4_A_BYTES + rw * T4_ROWB + ((lg ^ ((rw >> 2) & 3)) << 4);
     }
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-        S2S_WAIT_VMCNT(16);                  // slab t has landed; the 8 + 8 loads of slabs t + 1 and t + 2 may still be in flight
+        S2S_WAIT_VMCNT(4 * CPT);             // slab t has landed; the 2 x 2 CPT loads of slabs t + 1 and t + 2 may still be in flight
         __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading slab t - 1's stage
         issue(stage >= 1 ? stage - 1 : T4_NST - 1, t + 3 < nk);      // (t + 3) % 4 == (t - 1) % 4
         const unsigned char* sS = lds4 + stage * T4_STAGE;
-        bf16x8_t fa[8], fw[8];
+        bf16x8_t fa[8], fw[WNF];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(sS + offa[i]);
-            fw[i] = *reinterpret_cast<const bf16x8_t*>(sS + offw[i]);
-        }
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sS + offa[i]);
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(sS + offw[j]);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < WNF; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         stage = stage + 1 == T4_NST ? 0 : stage + 1;
     }
@@ -855,17 +865,18 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
     // back row-wise so that every lane moves 16 contiguous bytes of one output row.  The residual values of a pass are
     // fetched before its first store (the residual may alias C).
     constexpr int VEC = 16 / (int)sizeof(CT);   // 8 (bf16) / 4 (f32)
-    constexpr int LPR = 128 / VEC;              // lanes per 128-column row: 16 / 32
-    constexpr int RPI = 64 / LPR;               // rows per wave instruction: 4 / 2
-    constexpr int NIT = 16 / RPI;               // instructions per 16-row pass: 4 / 8
+    constexpr int PITCH = WCOLS + 4;            // 132 / 68 floats: conflict-free fragment writes
+    constexpr int LPR = WCOLS / VEC;            // lanes per output row of the wave tile
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int NIT = 16 / RPI;               // instructions per 16-row pass
     const bool grouped = rm.G < M;
     const int cc = (lane % LPR) * VEC;
     const int n = n0 + wn + cc;
     const bool full = n + VEC <= N;
-    float* stg = reinterpret_cast<float*>(lds4) + wave * (16 * T4_PITCH);
-    float bv[8];
+    float* stg = reinterpret_cast<float*>(lds4) + wave * (16 * PITCH);
+    float bv[WNF];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < WNF; ++j) {
         const int nc = n0 + wn + j * 16 + l15;
         bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
     }
@@ -906,10 +917,10 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < WNF; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                stg[(lg * 4 + r) * T4_PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
+                stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -923,7 +934,7 @@ __global__ __launch_bounds__(256) void gemm_tile4_kernel(
             float v[VEC];
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
-                const float4 t4 = *reinterpret_cast<const float4*>(stg + prow * T4_PITCH + cc + q * 4);
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + prow * PITCH + cc + q * 4);
                 v[q * 4 + 0] = t4.x + rres[it][q * 4 + 0]; v[q * 4 + 1] = t4.y + rres[it][q * 4 + 1];
                 v[q * 4 + 2] = t4.z + rres[it][q * 4 + 2]; v[q * 4 + 3] = t4.w + rres[it][q * 4 + 3];
             }
@@ -1218,13 +1229,19 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             int dev = 0;
             S2S_HIP_CHECK(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr4[dev]) {
-                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                 if (dev >= 0 && dev < 64) attr4[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                            ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-            launch_k(gemm_tile4_kernel<CT>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
-                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            static const bool eight_waves = atoi(getenv("S2S_TILE4")) >= 2;      // (tile4_ok: the variable is set)
+            if (eight_waves)
+                launch_k(gemm_tile4_kernel<CT, 4>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            else
+                launch_k(gemm_tile4_kernel<CT, 2>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
+                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
         }
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
                (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {

@@ -2,6 +2,7 @@
 NOT part of the test suite: the kernel was written at the end of round 2 without GPU time left; run this first in round 3.
 
     python tools/proto/tile4_check.py            parity vs float64 on ragged and encoder shapes, then timing with the switch ON
+    S2S_TILE4=2 python tools/proto/tile4_check.py    the 8-wave variant (wave tile 128 x 64, two waves per SIMD)
     S2S_TILE4_OFF=1 python tools/proto/tile4_check.py    same shapes on the current gemm_tile3 path (the A/B reference)
 
 Parity bar: f32 accumulation order only (<= 2e-4 of the row magnitude) plus one bf16 rounding (2^-8) for bf16 outputs.
@@ -11,7 +12,7 @@ import os
 import sys
 
 if not os.environ.get("S2S_TILE4_OFF"):
-    os.environ["S2S_TILE4"] = "1"
+    os.environ.setdefault("S2S_TILE4", "1")      # 1: 4 waves of 128 x 128;  2: 8 waves of 128 x 64
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
@@ -74,7 +75,7 @@ def timing():
         us = C.c_double()
         native.check(lib.s2s_graph_bench_end(2, 5, C.byref(us)), "end")
         t = us.value / n
-        print(f"{name:9s} M={M} N={N} K={K}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.1f} TFLOP/s  ({'tile3' if os.environ.get('S2S_TILE4_OFF') else 'tile4'})")
+        print(f"{name:9s} M={M} N={N} K={K}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.1f} TFLOP/s  ({'tile3' if os.environ.get('S2S_TILE4_OFF') else 'tile4 variant ' + os.environ['S2S_TILE4']})")
 
 
 if __name__ == "__main__":
