@@ -147,16 +147,24 @@ int32_t s2s_op_gemm_ex(void* stream, const void* A, int64_t lda, const void* W, 
  *   mode 0: C bf16 = act(out)   (glu != 0: C = silu(out_gate) * out_up)
  *   mode 1: C f32  = act(out)
  *   mode 2: X f32 [M][ldx] += out in place; XB (optional) = bf16 copy of the new rows; ss_out (optional)
- *           [s2s_op_gemm_dec_parts(M,N,nf)][ss_stride] = per-column-slab partial sums of squares of the new rows
- *           (the next projection's ss_in).  Deterministic: no atomics, fixed summation order.
- *   nf: 16-column fragments per workgroup (0 = chosen from the shape).
+ *           [s2s_op_gemm_dec_parts(M,N,K,nf,layout)][ss_stride] = per-column-slab partial sums of squares of the new rows
+ *           (the next projection's ss_in).  Deterministic: no atomics on data, fixed summation order.
+ *   Two kernels share this entry point.  Slabs of 33 .. 128 rows with fragment-major A run the column-block / K-slice kernel
+ *   (csrc/gemm_dec2.hip: a 4-wave workgroup owns 64 or 128 columns, the activations go through LDS once per workgroup, K is
+ *   split across workgroups and the slices are added in slice order by the one that arrives last); everything else runs
+ *   the 16-column kernel (csrc/gemm_dec.hip).  nf: 16-column fragments per workgroup of the latter (0 = chosen from the
+ *   shape; > 0 also keeps the call on it).
  * Replaces the rmsnorm -> linear pairs of the Qwen3 decoder layer (transformers qwen3/modeling_qwen3.py; sibling code
  * predictor qwen3_omni_moe/modeling_qwen3_omni_moe.py:2250-2620) on the decode path of TTS/qwen3_tts_handler.py:910-1003. */
 int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
                         int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
                         void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
                         int32_t nf, int32_t layout);
-int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t nf);
+int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t K, int32_t nf, int32_t layout);
+/* Tuning hook of the decode projections (microbenchmarks, parity sweeps): enable = 0 keeps every call on the 16-column kernel;
+ * splitk / nt > 0 force the K-slices per column block / the 16-column tiles per wave of the column-block kernel (0 = chosen
+ * from the shape).  Process-wide: not for use while engines are serving. */
+int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt);
 /* xb = bf16(x) (frag != 0: fragment-major [rows][cols]) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
 int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
                          int32_t frag);

@@ -1,7 +1,7 @@
 // Error plumbing and library-level queries of libs2s_mi355x.
 #include <algorithm>
 #include <cstdlib>
-#include "common.h"
+#include "ops.h"
 
 #include <stdarg.h>
 
@@ -161,6 +161,10 @@ static bool g_bench_capturing = false;
 extern "C" int32_t s2s_graph_bench_begin(void** out_stream) {
     S2S_REQUIRE(out_stream && !g_bench_capturing, "graph_bench_begin: bad state");
     if (!g_bench_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&g_bench_stream, hipStreamNonBlocking));
+    {   // the K-slice workspace of the decode projections cannot be allocated inside the capture
+        const int rc = s2s::dec2_ensure_default_ws();
+        if (rc) return rc;
+    }
     S2S_HIP_CHECK(hipStreamBeginCapture(g_bench_stream, hipStreamCaptureModeThreadLocal));
     g_bench_capturing = true;
     *out_stream = (void*)g_bench_stream;

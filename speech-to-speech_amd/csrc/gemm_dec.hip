@@ -389,6 +389,11 @@ int launch_dec_mt(hipStream_t st, const DecGemm& a, int NF) {
 
 int dec_parts(int N, int NF) { return cdiv(N, 16 * NF) * NF; }
 
+int dec_out_parts(const DecGemm& a) {
+    const int p2 = dec2_parts(a);
+    return p2 > 0 ? p2 : dec_parts(a.N, dec_nf(a));
+}
+
 int dec_nf(const DecGemm& a) {
     if (a.nf > 0) return a.nf;
     // enough workgroups to put one on every CU first; above that, two column fragments per workgroup halve the
@@ -408,6 +413,8 @@ int gemm_dec(hipStream_t st, const DecGemm& a) {
     const int NF = dec_nf(a);
     ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * a.M * a.N * a.K * (a.glu ? 2 : 1),
                    (double)a.N * a.K * 2 * (a.glu ? 2 : 1) + (double)a.M * a.K * 2 + (double)a.M * a.N * (a.mode == 0 ? 2 : 4));
+    // 33 .. 128-row slabs with fragment-major activations: the column-block / K-slice kernel (gemm_dec2.hip)
+    if (const int r2 = gemm_dec2(st, a)) return r2 < 0 ? r2 : S2S_OK;
     const int MT = cdiv(a.M, 16);
     if (MT <= 1) return launch_dec_mt<1>(st, a, NF);
     if (MT <= 2) return launch_dec_mt<2>(st, a, NF);
@@ -496,14 +503,20 @@ extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, con
     a.X = X; a.ldx = (long)ldx; a.XB = (__hip_bfloat16*)XB; a.ldxb = (long)ldxb; a.ss_out = ss_out;
     a.glu = glu != 0; a.nf = nf;
     a.a_frag = (layout & 1) != 0; a.c_frag = (layout & 2) != 0; a.xb_frag = (layout & 4) != 0; a.w_cached = (layout & 8) != 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
+        const int rc = s2s::dec2_ensure_default_ws();     // (never allocates inside a capture: s2s_graph_bench_begin does it first)
+        if (rc) return rc;
+    }
     return s2s::gemm_dec((hipStream_t)stream, a);
 }
 
-/* number of partial sums of squares per row s2s_op_gemm_dec (mode 2) writes for this shape (0 -> default nf) */
-extern "C" int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t nf) {
+/* number of partial sums of squares per row s2s_op_gemm_dec (mode 2) writes for this shape (nf 0 -> the library's choice); layout as
+ * in s2s_op_gemm_dec (only bit 1, fragment-major A, matters) */
+extern "C" int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t K, int32_t nf, int32_t layout) {
     s2s::DecGemm a{};
-    a.M = M; a.N = N; a.nf = nf; a.mode = 2;
-    return s2s::dec_parts(N, s2s::dec_nf(a));
+    a.M = M; a.N = N; a.K = K; a.nf = nf; a.mode = 2; a.a_frag = (layout & 1) != 0;
+    return s2s::dec_out_parts(a);
 }
 
 extern "C" int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,

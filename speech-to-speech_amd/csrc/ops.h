@@ -53,11 +53,21 @@ struct DecGemm {
     float* ss_out;                          // [dec_parts(N, nf)][ss_stride] partial sums of squares of the new X rows
     bool x_overwrite;                       // mode 2: X = out (no read of the old rows): projections that START a residual stream
     bool glu;                               // C = silu(gate) * up (mode 0)
-    int nf;                                 // 16-column fragments per workgroup (0: chosen from the shape)
+    int nf;                                 // 16-column fragments per workgroup of the 16-column kernel (0: chosen from the shape; > 0 also
+                                            // keeps the call on that kernel)
+    // K-slice workspace of the column-block kernel (gemm_dec2.hip): 16 KiB of arrival tickets (zero between launches) followed by the
+    // f32 partial tiles.  One per stream of launches (an engine owns its own); null: the process-wide default of the public op.
+    void* ws; size_t ws_bytes;
 };
 int gemm_dec(hipStream_t st, const DecGemm& a);
 int dec_nf(const DecGemm& a);
-int dec_parts(int N, int NF);               // partial sums gemm_dec writes per row for an N-column residual projection
+int dec_parts(int N, int NF);               // partial sums the 16-column kernel writes per row for an N-column residual projection
+int dec_out_parts(const DecGemm& a);        // partial sums per row gemm_dec(a) (mode 2) writes, whichever kernel it picks
+// column-block / K-slice kernel for 33 .. 128-row slabs (gemm_dec2.hip): 1 launched, 0 not eligible, < 0 error
+int gemm_dec2(hipStream_t st, const DecGemm& a);
+int dec2_parts(const DecGemm& a);           // column blocks (= partial sums per row) when gemm_dec2 takes the shape, else 0
+int dec2_ensure_default_ws();
+constexpr size_t DEC_WS_BYTES = (size_t)48 << 20;   // K-slice workspace an engine allocates per stream of decode launches
 int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag);
 int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K);
 

@@ -101,6 +101,7 @@ struct Tts {
     // norm-free decode path (gemm_dec.hip): bf16 copy of the residual rows + two partial-sum-of-squares buffers
     void* xb = nullptr;                // [DEC_ROWS][max hidden] model dtype
     float *ssA = nullptr, *ssB = nullptr;   // [SS_PARTS][DEC_ROWS]
+    void* dec_ws = nullptr;            // K-slice workspace of the decode projections (gemm_dec2.hip): tickets + partial tiles
     SampleParams sp_talker{0.f, 0, 1.f, 1.f, 0ull}, sp_pred{0.f, 0, 1.f, 1.f, 0ull};   // temperature 0: greedy (s2s_tts_set_sampling)
     PickDebug dbg{};                   // teacher forcing / logit capture (s2s_tts_generate_forced); null on the serving path
     int* forced_buf = nullptr;         // [max_batch][max_frames][G], allocated on first forced call
@@ -303,7 +304,9 @@ static int finalize(Tts* m) {
         S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * m->xb_width * e));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * SS_PARTS * DEC_ROWS));
         S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
-        m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB);
+        S2S_HIP_CHECK(hipMalloc(&m->dec_ws, DEC_WS_BYTES));
+        S2S_HIP_CHECK(hipMemset(m->dec_ws, 0, DEC_WS_BYTES));
+        m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB); m->owned.push_back(m->dec_ws);
         S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * m->xb_width * e));   // padding rows of fragment tiles must stay finite
         // The fragment-major copies ("<name>.f": s2s_op_to_frag of the projection, RMSNorm weight folded into qkv / gate-up / the
         // predictor heads) are made once by the host side and shared by every engine replica on the GPU; the norm-free decode
@@ -416,6 +419,7 @@ static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, 
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = s.prefix + std::to_string(l) + ".";
         DecGemm q{};
+        q.ws = m->dec_ws; q.ws_bytes = DEC_WS_BYTES;
         q.A = (const __hip_bfloat16*)m->xb; q.a_frag = true; q.W = (const __hip_bfloat16*)s.qkv_n[l]; q.M = M; q.N = nq; q.K = hid;
         q.ss_in = m->ssA; q.n_parts_in = m->ss_parts_A; q.ss_stride = DEC_ROWS; q.inv_dim = 1.0f / (float)hid; q.eps = c.eps;
         q.mode = 0; q.C = m->qkv; q.ldc = nq; q.act = S2S_ACT_NONE; q.w_cached = cached;
@@ -423,22 +427,25 @@ static int stack_forward_dec(Tts* m, hipStream_t st, Stack& s, float* x, int B, 
         bool att_frag = false;
         if ((rc = stack_attention(m, st, s, l, B, T_len, pos0, kv_cap, nullptr, &att_frag))) return rc;
         DecGemm o{};
+        o.ws = m->dec_ws; o.ws_bytes = DEC_WS_BYTES;
         o.A = (const __hip_bfloat16*)m->att; o.lda = (long)H * D; o.a_frag = att_frag; o.W = (const __hip_bfloat16*)s.o_f[l];
         o.M = M; o.N = hid; o.K = H * D; o.mode = 2; o.X = x; o.ldx = hid; o.XB = (__hip_bfloat16*)m->xb; o.ldxb = hid; o.xb_frag = true; o.ss_out = m->ssB;
         o.ss_stride = DEC_ROWS; o.act = S2S_ACT_NONE; o.w_cached = cached;
         if ((rc = gemm_dec(st, o))) return rc;
-        const int parts_o = dec_parts(hid, dec_nf(o));
+        const int parts_o = dec_out_parts(o);
         DecGemm g{};
+        g.ws = m->dec_ws; g.ws_bytes = DEC_WS_BYTES;
         g.A = (const __hip_bfloat16*)m->xb; g.a_frag = true; g.W = (const __hip_bfloat16*)s.gu_n[l]; g.M = M; g.N = c.ffn; g.K = hid;
         g.ss_in = m->ssB; g.n_parts_in = parts_o; g.ss_stride = DEC_ROWS; g.inv_dim = 1.0f / (float)hid; g.eps = c.eps;
         g.mode = 0; g.C = m->act; g.ldc = c.ffn; g.c_frag = true; g.act = S2S_ACT_NONE; g.glu = true; g.w_cached = cached;
         if ((rc = gemm_dec(st, g))) return rc;
         DecGemm d{};
+        d.ws = m->dec_ws; d.ws_bytes = DEC_WS_BYTES;
         d.A = (const __hip_bfloat16*)m->act; d.a_frag = true; d.W = (const __hip_bfloat16*)s.down_f[l];
         d.M = M; d.N = hid; d.K = c.ffn; d.mode = 2; d.X = x; d.ldx = hid; d.XB = (__hip_bfloat16*)m->xb; d.ldxb = hid; d.xb_frag = true; d.ss_out = m->ssA;
         d.ss_stride = DEC_ROWS; d.act = S2S_ACT_NONE; d.w_cached = cached;
         if ((rc = gemm_dec(st, d))) return rc;
-        m->ss_parts_A = dec_parts(hid, dec_nf(d));
+        m->ss_parts_A = dec_out_parts(d);
     }
     return S2S_OK;
 }
@@ -516,11 +523,12 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         if (P != E) {
             if (dec) {   // in_proj starts the predictor's residual rows and emits their bf16 copy + sums of squares in its epilogue
                 DecGemm ip{};
+                ip.ws = m->dec_ws; ip.ws_bytes = DEC_WS_BYTES;
                 ip.A = (const __hip_bfloat16*)m->pin_t; ip.a_frag = true; ip.W = (const __hip_bfloat16*)m->in_proj_f; ip.bias = TPF(m, "pred.in_proj.b");
                 ip.M = M; ip.N = P; ip.K = E; ip.mode = 2; ip.x_overwrite = true; ip.X = m->xp; ip.ldx = P; ip.XB = (__hip_bfloat16*)m->xb; ip.ldxb = P; ip.xb_frag = true;
                 ip.ss_out = m->ssA; ip.ss_stride = DEC_ROWS; ip.act = S2S_ACT_NONE; ip.w_cached = true;
                 if ((rc = gemm_dec(st, ip))) return rc;
-                m->ss_parts_A = dec_parts(P, dec_nf(ip));
+                m->ss_parts_A = dec_out_parts(ip);
             } else {
                 if ((rc = gemm(st, m->pin_t, E, TP(m, "pred.in_proj.w"), TPF(m, "pred.in_proj.b"), nullptr, m->xp, P, M, P, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
             }
@@ -538,6 +546,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
             // pred.norm (folded into the head's columns, scale from the down-proj partials) -> group head over all M rows; the
             // pick reads the last row of every session (row b * T_len + T_len - 1)
             DecGemm hg{};
+            hg.ws = m->dec_ws; hg.ws_bytes = DEC_WS_BYTES;
             hg.A = (const __hip_bfloat16*)m->xb; hg.a_frag = true; hg.W = (const __hip_bfloat16*)m->head_n[g];
             hg.M = M; hg.N = CB; hg.K = P;
             hg.ss_in = m->ssA; hg.n_parts_in = m->ss_parts_A; hg.ss_stride = DEC_ROWS; hg.inv_dim = 1.0f / (float)P; hg.eps = c.eps;

@@ -56,6 +56,7 @@ struct Whisper {
     std::map<int, hipGraphExec_t> step_graphs;
     // bf16 decode path on the fragment-major weight-streaming kernel (gemm_dec.hip): own pre-swizzled copies of the decoder matrices
     std::map<std::string, void*> fragw;
+    void* dec_ws = nullptr;       // K-slice workspace of the decode projections (gemm_dec2.hip)
     std::vector<void*> owned;
 };
 
@@ -193,6 +194,11 @@ static int finalize(Whisper* m) {
                   fragw(lname("dec", l, "co.w"), d, d) && fragw(lname("dec", l, "fc1.w"), c.ffn, d) && fragw(lname("dec", l, "fc2.w"), d, c.ffn);
         all = all && fragw("dec.tok", c.vocab, d);
         if (!all) m->fragw.clear();
+        else {
+            S2S_HIP_CHECK(hipMalloc(&m->dec_ws, DEC_WS_BYTES));
+            S2S_HIP_CHECK(hipMemset(m->dec_ws, 0, DEC_WS_BYTES));
+            m->owned.push_back(m->dec_ws);
+        }
     }
     m->finalized = true;
     return S2S_OK;
@@ -265,6 +271,7 @@ static int dec_proj(Whisper* m, hipStream_t st, const void* A, const std::string
     DecGemm a{};
     a.A = (const __hip_bfloat16*)A; a.a_frag = true; a.W = (const __hip_bfloat16*)m->fragw.at(w); a.bias = bias;
     a.M = B; a.N = N; a.K = K; a.mode = mode; a.C = C; a.ldc = N; a.c_frag = c_frag; a.act = act; a.X = X; a.ldx = N;
+    a.ws = m->dec_ws; a.ws_bytes = DEC_WS_BYTES;
     return gemm_dec(st, a);
 }
 

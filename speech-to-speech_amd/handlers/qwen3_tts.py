@@ -201,7 +201,10 @@ class MI355XQwen3TTSHandler(BaseHandler):
             blocker = AudioBlocker(self.blocksize)
             first, total = True, 0
             for piece, prompt in self._build_prompts(text):
-                chunks, cancel = self.pool.synthesize(prompt, self._estimate_max_new_tokens(piece))
+                budget = self._estimate_max_new_tokens(piece)
+                # min_new_tokens: benchmark knob (fixed-length replies, eos masked); 0 on the serving path
+                min_frames = min(budget, int(getattr(self, "min_new_tokens", 0) or 0))
+                chunks, cancel = (self.pool.synthesize(prompt, budget, min_frames=min_frames) if min_frames else self.pool.synthesize(prompt, budget))
                 for chunk in chunks:
                     if gen is not None and self.cancel_scope.is_stale(gen):
                         cancel.set()

@@ -73,7 +73,8 @@ _SIGNATURES = {
     "s2s_op_gemm_ex": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32],
     "s2s_op_gemm_dec": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _vp, _i64,
                         _vp, _i64, _vp, _i32, _i32, _i32],
-    "s2s_op_gemm_dec_parts": [_i32, _i32, _i32],
+    "s2s_op_gemm_dec_parts": [_i32, _i32, _i32, _i32, _i32],
+    "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
     "s2s_op_rows_prep": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32],
     "s2s_op_to_frag": [_vp, _vp, _i64, _vp, _vp, _i32, _i32],
     "s2s_graph_bench_begin": [C.POINTER(_vp)],

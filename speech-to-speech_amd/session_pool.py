@@ -45,6 +45,7 @@ class _STTRequest:
 class _TTSRequest:
     prompt: Any
     max_new_tokens: int
+    min_frames: int = 0             # eos is masked until the utterance has this many frames (throughput runs: SURVEY 8d forces full replies)
     chunks: "queue.Queue[Any]" = field(default_factory=queue.Queue)
     cancelled: threading.Event = field(default_factory=threading.Event)
     t_submit: float = field(default_factory=time.perf_counter)
@@ -156,11 +157,12 @@ class SessionPool:
             return None
         return self.transcribe(model, audio, **options)
 
-    def synthesize(self, prompt: Any, max_new_tokens: int) -> tuple[Iterator[np.ndarray], threading.Event]:
-        """-> (iterator over int16 16 kHz chunks of one utterance, cancel event)."""
+    def synthesize(self, prompt: Any, max_new_tokens: int, min_frames: int = 0) -> tuple[Iterator[np.ndarray], threading.Event]:
+        """-> (iterator over int16 16 kHz chunks of one utterance, cancel event).  min_frames > 0 masks eos until the utterance
+        has that many codec frames (benchmarks that need replies of a fixed length; 0 on the serving path)."""
         if self._stopping:
             raise RuntimeError("SessionPool is shut down")
-        req = _TTSRequest(prompt, int(max_new_tokens))
+        req = _TTSRequest(prompt, int(max_new_tokens), int(min_frames))
         self._tts_q.put(req)
         self._wake.set()
 
@@ -352,8 +354,9 @@ class SessionPool:
                 self.stats["tts_batches"] += 1
                 self.stats["tts_requests"] += len(batch)
             try:
+                kw = {"min_frames": max(r.min_frames for r in batch)} if any(r.min_frames for r in batch) else {}
                 gen = eng.stream([r.prompt for r in batch], [r.max_new_tokens for r in batch], chunk_size=self.tts_chunk_size,
-                                 ctx_frames=self.tts_ctx_frames)
+                                 ctx_frames=self.tts_ctx_frames, **kw)
                 for chunks in gen:
                     for r, ch in zip(batch, chunks):
                         if ch is not None and not r.cancelled.is_set():

@@ -1,0 +1,180 @@
+"""GPU parity at the depth and widths the bench RUNS: the bf16 serving engines at full depth against
+the float32 CPU oracle on the same seeded weights.
+
+test_true_dims_gpu.py builds 2 layers per stack; the bench runs 28 talker / 5 predictor layers, 32 + 32 Whisper layers and
+24 conformer layers in bf16 - the drift of the bf16 residual path over the whole depth, a Whisper self cache that grows over
+>= 16 decode steps, >= 16 generated codec frames and the C2 length (30 s -> 375 encoder frames at d = 1024) are covered here:
+
+* Qwen3-TTS-1.7B dims, 28 + 5 layers, 16 frames, B = 4: TEACHER-FORCED logits of all 16 code groups of every frame within
+  BF16_LOGIT_TOL x the frame's logit standard deviation, top-1 equal wherever the oracle's margin is clear;
+* Whisper-large-v3 dims, 32 + 32 layers, 16 decode steps, B = 4: encoder states within the bf16 tolerance, teacher-forced
+  logits with the same bar;
+* Parakeet-TDT-0.6B dims, 24 layers, one 30 s clip: encoder states within the bf16 tolerance, TDT steps identical until a
+  step whose oracle margin is below the bf16 logit tolerance.
+
+The tolerances are the ones of test_true_dims_gpu.py (0.08 sigma / zero clear-margin flips); they are restated below.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as OL
+from oracle import parakeet as OP
+from oracle import qwen3_tts as OT
+from oracle import whisper as OW
+from speech_to_speech_amd.synth import synth_audio
+from speech_to_speech_amd.synth_weights import (ParakeetDims, Qwen3TTSDims, WhisperDims, parakeet_state_dict, qwen3_tts_state_dict,
+                                                whisper_state_dict)
+
+pytestmark = pytest.mark.gpu
+
+BF16_LOGIT_TOL = 0.08        # max |logit_engine - logit_oracle| allowed, as a fraction of the step's logit standard deviation
+
+
+def _cpu_threads():
+    import os
+
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def test_tts_bf16_full_depth_teacher_forced_16_frames():
+    from speech_to_speech_amd.tts import TTSEngine, TTSPrompt
+
+    _cpu_threads()
+    dims = Qwen3TTSDims.tts_1_7b()                                       # 28 talker layers, 5 predictor layers, 16 groups
+    dims.c_layers = 1                                                    # (the codec decoder is covered at full width in test_true_dims_gpu.py)
+    sd = qwen3_tts_state_dict(dims, seed=21)
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randn(n, dims.t_hidden, generator=g) for n in (12, 7)]
+    pad = torch.randn(dims.t_hidden, generator=g) * 0.5
+    n_frames = 16
+    sup = [i for i in range(dims.codebook, dims.codec_vocab) if i != dims.codec_eos]
+    codes, logits = [], []
+    with torch.no_grad():
+        for p in prompts:
+            lo = []
+            c, _ = OT.talker_generate(sd, dims.talker_cfg(), dims.predictor_cfg(), p[None], dims.n_groups, n_frames, dims.codec_eos, suppress=sup,
+                                      pad_embed=pad, min_frames=n_frames, logits_out=lo)
+            codes.append(c[0])
+            logits.append(lo)
+    codes = torch.stack(codes)                                           # [2, F, G]
+    B = 4
+    eng = TTSEngine(dims, sd, dtype=torch.bfloat16, max_batch=B, max_prompt=16, max_frames=n_frames, max_codec_frames=8, pad_embed=pad)
+    eng.prefill([TTSPrompt(prompts[b % 2].numpy()) for b in range(B)])
+    forced = codes.to(torch.int32).repeat(B // 2, 1, 1)
+    emitted, lg = eng.generate_forced(forced, min_total_frames=n_frames)
+    assert torch.equal(emitted.cpu(), forced)
+    lg = lg.cpu()
+    worst, worst_at, flips, checked = 0.0, None, 0, 0
+    per_frame = []
+    for f in range(n_frames):
+        wf = 0.0
+        for b in range(B):
+            for gidx in range(dims.n_groups):
+                ref = logits[b % 2][f][gidx][0]
+                V = ref.numel()
+                got = lg[b, f, gidx, :V]
+                rel = ((got - ref).abs().max() / ref.std()).item()
+                wf = max(wf, rel)
+                if rel > worst:
+                    worst, worst_at = rel, (b, f, gidx)
+                top2 = torch.topk(ref, 2).values
+                if float(top2[0] - top2[1]) > 2 * BF16_LOGIT_TOL * float(ref.std()):
+                    checked += 1
+                    flips += int(torch.argmax(got).item() != torch.argmax(ref).item())
+        per_frame.append(round(wf, 4))
+    print(f"bf16 TTS at FULL depth ({dims.t_layers} talker + {dims.p_layers} predictor layers), {n_frames} teacher-forced frames x {B} sessions: "
+          f"worst max|err| / std = {worst:.4f} at (session, frame, group) {worst_at} (tol {BF16_LOGIT_TOL}); per frame {per_frame}; "
+          f"{checked} clear-margin picks, {flips} flips")
+    assert worst <= BF16_LOGIT_TOL
+    assert flips == 0
+    eng.close()
+
+
+WT = dict(eos=50257, sot=50258, lang_ids=[50259, 50260, 50261, 50262], transcribe=50360, notimestamps=50364,
+          suppress=[1, 2, 7, 50258, 50259, 50260, 50261, 50262, 50360, 50364], begin_suppress=[220, 50257], max_new=16)
+
+
+def test_whisper_bf16_full_depth_teacher_forced_16_tokens():
+    from speech_to_speech_amd.whisper import WhisperEngine
+
+    _cpu_threads()
+    dims = WhisperDims.large_v3()                                        # 32 encoder + 32 decoder layers, d = 1280, V = 51866
+    sd = whisper_state_dict(dims, seed=6, gain=1.0, pos_std=1.0)
+    audios = [synth_audio(n, 500 + i) for i, n in enumerate((160000, 96000))]
+    feats = torch.from_numpy(np.stack([OL.whisper_logmel(a, dims.n_mels) for a in audios]).astype(np.float32))
+    prompt = [[WT["sot"], -1, WT["transcribe"], WT["notimestamps"]]] * len(audios)
+    with torch.no_grad():
+        enc = OW.encode(sd, feats, dims.n_heads, dims.enc_layers)
+        ids, filled, logits = OW.greedy_decode(sd, enc, dims.n_heads, dims.dec_layers, prompt, WT["eos"], WT["max_new"], WT["suppress"],
+                                               WT["begin_suppress"], WT["lang_ids"], return_logits=True)
+    B = 4
+    eng = WhisperEngine(dims, sd, dtype=torch.bfloat16, max_batch=B)
+    eng.encode(eng.features([audios[b % 2] for b in range(B)]))
+    d = (eng.encoder_output().float().cpu()[:2] - enc).abs()
+    print(f"bf16 encoder at FULL depth (32 layers): max_abs_err {d.max():.3e} mean_abs_err {d.mean():.3e} (|enc| max {enc.abs().max():.2f}, mean {enc.abs().mean():.3f})")
+    assert d.max() < 8e-2 * max(1.0, enc.abs().max().item()) and d.mean() < 2e-2 * max(1.0, enc.abs().mean().item())
+    n_steps = min(len(ids[0]), len(ids[1]), len(logits))
+    assert n_steps >= 8, f"the oracle stopped after {n_steps} tokens"
+    worst, flips, checked = 0.0, 0, 0
+    for s in range(n_steps):
+        pr = [list(filled[b % 2]) + list(ids[b % 2][:s]) for b in range(B)]
+        _, _, lg = eng.decode(pr, WT["eos"], 1, WT["suppress"], WT["begin_suppress"] if s == 0 else None, return_logits=True)
+        lg = lg.cpu()
+        for b in range(B):
+            ref = logits[s][b % 2]
+            keep = torch.isfinite(ref)
+            rel = ((lg[b][keep] - ref[keep]).abs().max() / ref[keep].std()).item()
+            worst = max(worst, rel)
+            top2 = torch.topk(ref, 2).values
+            if float(top2[0] - top2[1]) > 2 * BF16_LOGIT_TOL * float(ref[keep].std()):
+                checked += 1
+                got = lg[b].clone()
+                got[~keep] = -float("inf")
+                flips += int(torch.argmax(got).item() != torch.argmax(ref).item())
+    print(f"bf16 Whisper at FULL depth (32 + 32 layers), {n_steps} teacher-forced steps x {B} sessions: worst max|err| / std = {worst:.4f} "
+          f"(tol {BF16_LOGIT_TOL}); {checked} clear-margin picks, {flips} flips")
+    assert worst <= BF16_LOGIT_TOL and flips == 0
+    eng.close()
+
+
+def test_parakeet_bf16_full_depth_30s_clip():
+    from speech_to_speech_amd.parakeet import ParakeetEngine
+
+    _cpu_threads()
+    dims = ParakeetDims.tdt_0_6b()                                       # 24 layers, d = 1024, 8 heads of 128
+    sd = parakeet_state_dict(dims, seed=12, gain=1.0)
+    n = 480000                                                           # C2: 30 s -> 3001 mel frames -> 375 (376) encoder frames
+    audios = [synth_audio(n, 700)]
+    tmax = n // 160 + 1
+    feats = torch.from_numpy(np.stack([OL.parakeet_logmel(a, 128, t_total=tmax)[0] for a in audios]).astype(np.float32))
+    flen = torch.tensor([n // 160])
+    with torch.no_grad():
+        enc, elen = OP.encode(sd, feats, flen, dims.n_heads, dims.layers)
+        toks, durs, frames, logits = OP.tdt_greedy(sd, enc, elen, dims.vocab, dims.blank, return_logits=True)
+    eng = ParakeetEngine(dims, sd, dtype=torch.bfloat16, max_batch=1, max_seconds=30.0)
+    f, nf, T = eng.features(audios)
+    eng.encode(f, nf)
+    got, glen = eng.encoder_output()
+    got = got.cpu()
+    assert glen.cpu().tolist() == elen.tolist() and int(elen[0]) >= 375
+    dd = (got[0, : int(elen[0])] - enc[0, : int(elen[0])]).abs()
+    print(f"bf16 Parakeet encoder at FULL depth (24 layers), 30 s clip -> {int(elen[0])} frames: max_abs_err {dd.max():.3e} mean_abs_err {dd.mean():.3e} "
+          f"(|enc| max {enc.abs().max():.2f}, mean {enc.abs().mean():.3f})")
+    assert dd.max() < 8e-2 * max(1.0, enc.abs().max().item()) and dd.mean() < 2e-2 * max(1.0, enc.abs().mean().item())
+    gt, gd, gf = eng.tdt_greedy()
+    V = dims.vocab
+    same = 0
+    for s in range(min(len(gt[0]), len(toks[0]))):
+        if gt[0][s] == toks[0][s] and gd[0][s] == durs[0][s]:
+            same += 1
+            continue
+        lg = logits[s][0]
+        t2, d2 = torch.topk(lg[:V], 2).values, torch.topk(lg[V:], 2).values
+        margin = min(float(t2[0] - t2[1]), float(d2[0] - d2[1]))
+        print(f"bf16 Parakeet divergence at step {s}/{len(toks[0])}: oracle margin {margin:.4f} (logit std {float(lg[:V].std()):.3f})")
+        assert margin < 2 * BF16_LOGIT_TOL * float(lg[:V].std())
+        break
+    print(f"bf16 Parakeet TDT: {same} of {len(toks[0])} steps identical to the f32 oracle before the first low-margin divergence")
+    eng.close()

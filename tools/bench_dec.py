@@ -6,7 +6,8 @@ numbers are device time per kernel including the in-graph kernel boundary.
 
     python tools/bench_dec.py floor            trivial-kernel boundary cost inside a graph
     python tools/bench_dec.py gemm             single decode GEMMs, weights cycled through > 256 MB (HBM, not MALL)
-    python tools/bench_dec.py layer [M]        norm-free decoder layer chains (talker 2048/6144 x 28, predictor 1024/3072 x 5 x 15)
+    python tools/bench_dec.py layer [M]        norm-free decoder layer chains (talker 2048/6144 x 28, predictor 1024/3072 x 5 x 15), both kernels
+    python tools/bench_dec.py sweep [M]        single GEMMs: 16-column kernel vs the column-block kernel at every K-slice count / block width
 `gemm-old` / `layer-old` time the r1 skinny kernel (row-major operands, rmsnorm launches) on the same shapes.
 """
 import ctypes as C
@@ -40,7 +41,7 @@ def to_frag(W):
 
 def dec(st, A, Wf, M, N, K, *, ss=None, parts=0, mode=0, Cb=None, X=None, XB=None, sso=None, glu=False, nf=0, bias=None, layout=7, ldc=None, ldxb=None):
     """Wf: fragment-major weights; layout bits: 1 A fragment-major, 2 C fragment-major, 4 XB fragment-major."""
-    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), K, native.ptr(Wf), K, native.ptr(bias), M, N, K, native.ptr(ss), parts, 128,
+    native.check(lib.s2s_op_gemm_dec(st, native.ptr(A), K, native.ptr(Wf), K, native.ptr(bias), M, N, K, native.ptr(ss), parts, max(128, M),
                                      1.0 / K, 1e-6, mode, native.ptr(Cb), ldc or N, 0, native.ptr(X), 0 if X is None else X.stride(0),
                                      native.ptr(XB), ldxb or N, native.ptr(sso), 1 if glu else 0, nf, layout), "gemm_dec")
 
@@ -66,7 +67,12 @@ def gemm_shapes(M):
             ("w.fc2", M, 1280, 5120, 2, False), ("w.logits", M, 51866, 1280, 1, False)]
 
 
-def gemm(M=64, old=False):
+def tune(enable=1, splitk=0, nt=0):
+    native.check(lib.s2s_op_gemm_dec_tune(enable, splitk, nt), "tune")
+
+
+def gemm(M=64, old=False, sweep=False):
+    """per shape: the 16-column kernel (nf = 1), the column-block kernel with the library's choice, and (sweep) every K-slice count / block width"""
     for name, M_, N, K, mode, glu in gemm_shapes(M):
         rows = 2 * N if glu else N
         wbytes = rows * K * 2
@@ -75,15 +81,20 @@ def gemm(M=64, old=False):
         if not old:
             Ws = [to_frag(W) for W in Ws]
         A = torch.randn(max(M_, 16 * ((M_ + 15) // 16)), K, device=dev).to(torch.bfloat16)      # same bytes either layout
-        ss = torch.rand(128, 128, device=dev)
+        ss = torch.rand(128, max(128, M_), device=dev)
         Cb = torch.zeros(M_, N, dtype=torch.bfloat16 if mode == 0 else torch.float32, device=dev)
         X = torch.zeros(M_, N, device=dev)
         XB = torch.zeros(16 * ((M_ + 15) // 16), N, dtype=torch.bfloat16, device=dev)
-        sso = torch.zeros(4096, 128, device=dev)
+        sso = torch.zeros(4096, max(128, M_), device=dev)
+        chunks = K // 32 // (8 if min(M_, 128) <= 64 else 4)
+        variants = [("old", None)] if old else [("nf=1", (0, 0, 0)), ("dec2", (1, 0, 0))]
+        if sweep and not old:
+            variants += [(f"sk{sk}/nt{nt}", (1, sk, nt)) for sk in (1, 2, 3, 4, 5, 6, 8, 12) if chunks % sk == 0 for nt in ((1,) if glu else (1, 2))]
         res = []
-        for nf in ((0,) if old else (1, 2)):
-            if M_ > 64 and nf == 2:
-                continue
+        for tag, tn in variants:
+            if tn is not None:
+                tune(*tn)
+            nf = 1 if tag == "nf=1" else 0
 
             def fn(st):
                 for W in Ws:
@@ -95,12 +106,13 @@ def gemm(M=64, old=False):
                     elif mode == 2:
                         dec(st, A, W, M_, N, K, mode=2, X=X, XB=XB, sso=sso, nf=nf, layout=5)
                     else:
-                        dec(st, A, W, M_, N, K, ss=ss, parts=128, mode=mode, Cb=Cb, glu=glu, nf=nf, layout=1)
+                        dec(st, A, W, M_, N, K, ss=ss, parts=32, mode=mode, Cb=Cb, glu=glu, nf=nf, layout=1)
                 return len(Ws)
 
             us, n = graph_time(fn)
-            res.append(f"nf={nf}: {us / n:6.2f} us {wbytes / (us / n * 1e-6) / 1e12:5.2f} TB/s")
-        print(f"{name:9s} M={M_:3d} N={N:6d} K={K:5d} {wbytes / 1e6:6.1f} MB x{nbuf:2d}  " + "   ".join(res))
+            res.append(f"{tag}: {us / n:6.2f} us {wbytes / (us / n * 1e-6) / 1e12:5.2f} TB/s")
+        tune(1, 0, 0)
+        print(f"{name:9s} M={M_:3d} N={N:6d} K={K:5d} {wbytes / 1e6:6.1f} MB x{nbuf:2d}  " + "   ".join(res), flush=True)
 
 
 def layer(M=64, old=False):
@@ -108,25 +120,28 @@ def layer(M=64, old=False):
         def w(r, c):
             return (torch.randn(r, c, device=dev) * c ** -0.5).to(torch.bfloat16)
 
-        cv = (lambda t: t) if old else to_frag
+        cv = (lambda t: t) if old is True else to_frag
         Wq = [cv(w(nq, hid)) for _ in range(L)]
         Wo = [cv(w(hid, hd)) for _ in range(L)]
         Wg = [cv(w(2 * ffn, hid)) for _ in range(L)]
         Wd = [cv(w(hid, ffn)) for _ in range(L)]
+        Mp = max(128, M)
         X = torch.randn(M, hid, device=dev) * 0.1
-        XB = torch.zeros(128, hid, dtype=torch.bfloat16, device=dev)
+        XB = torch.zeros(Mp, hid, dtype=torch.bfloat16, device=dev)
         H = torch.zeros(M, hid, dtype=torch.bfloat16, device=dev)
         g = torch.ones(hid, device=dev)
-        ssA = torch.ones(256, 128, device=dev)
-        ssB = torch.ones(256, 128, device=dev)
-        qkv = torch.zeros(128, nq, dtype=torch.bfloat16, device=dev)
-        act = torch.zeros(128, ffn, dtype=torch.bfloat16, device=dev)
-        parts = lib.s2s_op_gemm_dec_parts(M, hid, 0)
+        ssA = torch.ones(256, Mp, device=dev)
+        ssB = torch.ones(256, Mp, device=dev)
+        qkv = torch.zeros(Mp, nq, dtype=torch.bfloat16, device=dev)
+        act = torch.zeros(Mp, ffn, dtype=torch.bfloat16, device=dev)
+        tune(0 if old == "nf1" else 1, 0, 0)
+        parts = lib.s2s_op_gemm_dec_parts(M, hid, hd, 0, 1)
+        old_k = old is True
 
         def fn(st):
             for _ in range(steps):
                 for l in range(L):
-                    if old:
+                    if old_k:
                         native.check(lib.s2s_op_rmsnorm(st, native.ptr(X), native.ptr(g), native.ptr(H), M, hid, 1e-6, native.S2S_BF16), "norm")
                         native.check(lib.s2s_op_gemm_ex(st, native.ptr(H), hid, native.ptr(Wq[l]), None, None, native.ptr(qkv), nq, M, nq, hid, 1, 1, 0, 0, 0.0), "q")
                         native.check(lib.s2s_op_gemm_ex(st, native.ptr(qkv), nq, native.ptr(Wo[l]), None, native.ptr(X), native.ptr(X), hid, M, hid, hd, 1, 0, 0, 0, 0.0), "o")
@@ -142,7 +157,9 @@ def layer(M=64, old=False):
 
         us, n = graph_time(fn, warm=2, reps=10)
         wb = (nq * hid + hid * hd + 2 * ffn * hid + hid * ffn) * 2
-        print(f"{tag:9s} layer chain M={M} ({'r1: 2 norms + 4 skinny GEMMs' if old else '4 gemm_dec, no norms'}; attention not included): {us / n:7.2f} us per layer, "
+        tune(1, 0, 0)
+        kind = 'r1: 2 norms + 4 skinny GEMMs' if old is True else ('4 gemm_dec (16-column kernel), no norms' if old == 'nf1' else '4 gemm_dec (column-block kernel), no norms')
+        print(f"{tag:9s} layer chain M={M} ({kind}; attention not included): {us / n:7.2f} us per layer, "
               f"{wb / 1e6:.1f} MB weights -> {wb / (us / n * 1e-6) / 1e12:.2f} TB/s")
 
 
@@ -153,7 +170,10 @@ if __name__ == "__main__":
         floor()
     if which in ("all", "gemm"):
         gemm(M)
+    if which in ("sweep",):
+        gemm(M, sweep=True)
     if which in ("all", "layer"):
+        layer(M, old="nf1")
         layer(M, old=False)
     if which in ("layer-old",):
         layer(M, old=True)
