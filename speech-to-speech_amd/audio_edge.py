@@ -28,18 +28,6 @@ def resample_fir(up: int, down: int, dtype=np.float32) -> np.ndarray:
     return h
 
 
-def reference_resample(audio_int16: bytes, from_rate: int, to_rate: int) -> bytes:
-    """The reference's own function (api/openai_realtime/utils.py:5-12), restated for the parity tests."""
-    from scipy.signal import resample_poly
-
-    if from_rate == to_rate:
-        return audio_int16
-    samples = np.frombuffer(audio_int16, dtype=np.int16).astype(np.float32) / 32768.0
-    g = np.gcd(to_rate, from_rate)
-    resampled = resample_poly(samples, up=to_rate // g, down=from_rate // g)
-    return np.clip(resampled * 32768, -32768, 32767).astype(np.int16).tobytes()
-
-
 class EdgeResampler:
     """Batched int16 resampling between a client rate and the pipeline rate on one GPU."""
 

@@ -30,6 +30,8 @@
 // bf16 copy and ONE partial sum of squares per column block (n_parts = N / BN instead of N / 16).
 #include "ops.h"
 
+#include <type_traits>
+
 namespace s2s {
 
 namespace {
@@ -54,7 +56,7 @@ struct Dec2Plan {
     unsigned* cnt;      // [row slab][cb] arrival tickets (zero between launches)
 };
 
-template <int MT, int NT, bool GLU, int KC, bool NTL>
+template <int MT, int NT, bool GLU, int KC, bool NTL, int NCH>      // NCH: chunks per slice known at compile time (1, 2: every load up front, straight-line), 0: any
 __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Plan p) {
     constexpr int NS = NT * (GLU ? 2 : 1);            // weight streams per wave
     constexpr int APW = MT * KC / D2_NW;              // activation blocks a wave stages per chunk
@@ -84,34 +86,49 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     }
     const int cb = blockIdx.x % p.ncb, ks = blockIdx.x / p.ncb;
     const int steps = a.K >> 5;
-    const int nch = p.nch;
+    const int nch = NCH > 0 ? NCH : p.nch;
     const int s0 = ks * nch * KC;                       // first k-step of this slice
     const int ntiles = (a.N + 15) >> 4;
     const int mtiles = (a.M + 15) >> 4;
     const int t0 = (cb * D2_NW + wave) * NT;            // this wave's first column tile
 
-    // reciprocal RMS of the input rows (gamma is folded into W): 4 threads per row, their loads issued first and all at once, so
-    // waiting for them never waits for the HBM stream behind them
-    if (a.ss_in) {
-        const int ssrs = a.ss_rs > 0 ? a.ss_rs : 1;
-        constexpr int RP = 16;                           // prefetched parts per thread (4 x 16 = 64 parts; the rest: tail loop)
+    // reciprocal RMS of the input rows (gamma is folded into W): 4 threads per row, <= 64 partial sums per row.  The loads are issued
+    // HERE, ahead of the weight stream, and reduced once the stream is in flight (they are the oldest loads: waiting for them never
+    // waits for HBM).  Branch-free on purpose - without ss_in the same loads read row 0 of A and the result is ignored: a branch
+    // around loads makes hipcc's wait counts conservative (vmcnt(0)) for everything issued after it.
+    constexpr int RH = (MT * 16 * 4 + D2_NW * 64 - 1) / (D2_NW * 64);
+    constexpr int RP = 16;
+    float sv[RH][RP];
+    {
+        const bool has = a.ss_in != nullptr;
+        const float* base = has ? a.ss_in : reinterpret_cast<const float*>(a.A);
+        const long ssrs = has ? (a.ss_rs > 0 ? a.ss_rs : 1) : 0, sst = has ? a.ss_stride : 0;
+        const int np1 = has ? a.n_parts_in - 1 : 0;
 #pragma unroll
-        for (int h = 0; h < (MT * 16 * 4 + D2_NW * 64 - 1) / (D2_NW * 64); ++h) {
+        for (int h = 0; h < RH; ++h) {
+            const int e = h * D2_NW * 64 + tid;
+            const float* src = base + (long)min(e >> 2, a.M - 1) * ssrs;
+#pragma unroll
+            for (int j = 0; j < RP; ++j) sv[h][j] = src[(long)min((e & 3) + 4 * j, np1) * sst];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto rstd_reduce = [&]() {
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
             const int e = h * D2_NW * 64 + tid;
             const int row = e >> 2, sub = e & 3;
-            const float* src = a.ss_in + (long)min(row, a.M - 1) * ssrs;
-            float sv[RP];
-#pragma unroll
-            for (int j = 0; j < RP; ++j) sv[j] = src[(long)min(sub + 4 * j, a.n_parts_in - 1) * a.ss_stride];
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < RP; ++j) v += sub + 4 * j < a.n_parts_in ? sv[j] : 0.f;
-            for (int q = sub + 4 * RP; q < a.n_parts_in; q += 4) v += src[(long)q * a.ss_stride];
+            for (int j = 0; j < RP; ++j) {
+                const unsigned keep = sub + 4 * j < a.n_parts_in ? 0xffffffffu : 0u;      // (a mask, not a select: a select lets hipcc sink each load under a branch)
+                v += __uint_as_float(__float_as_uint(sv[h][j]) & keep);
+            }
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
-            if (sub == 0 && row < MT * 16) rstd_s[row] = rsqrtf(v * a.inv_dim + a.eps);
+            if (sub == 0 && row < MT * 16) rstd_s[row] = a.ss_in ? rsqrtf(v * a.inv_dim + a.eps) : 1.0f;
         }
-    }
+    };
 
     const char* wt[NS];
 #pragma unroll
@@ -134,11 +151,12 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int q = 0; q < NS; ++q) acc[i][q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    u32x4_t fw[2][KC][NS], ra[APW];
+    u32x4_t fw[2][KC][NS], ra[2][APW];
 
-    // chunk c of the slice; c >= nch reads chunk 0 again (L1 / L2 hits, never used)
+    // every load below is unconditional and straight-line inside its region (prologue, steady-state trip, tail), so the compiler's
+    // vmcnt accounting is exact: a wait for chunk c never drains the loads of chunks c + 1 / c + 2 issued after it
     auto load_w = [&](int c, int buf) {
-        const long off = (long)(c < nch ? c : 0) * KC * 1024;
+        const long off = (long)c * KC * 1024;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const char* b = uptr(wt[q] + off);
@@ -148,49 +166,122 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
                 else fw[buf][u][q] = *reinterpret_cast<const u32x4_t*>(b + u * 1024 + loff);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);       // issued HERE: the scheduler must not sink loads behind the MFMAs that follow
     };
-    auto load_a = [&](int c) {
-        const long off = (long)(c < nch ? c : 0) * KC * 1024;
+    auto load_a = [&](int c, int rb) {
+        const long off = (long)c * KC * 1024;
 #pragma unroll
-        for (int j = 0; j < APW; ++j) ra[j] = *reinterpret_cast<const u32x4_t*>(uptr(at[j] + off) + loff);
-        __builtin_amdgcn_sched_barrier(0);       // the chunk's loads are issued HERE, ahead of the MFMAs that follow
+        for (int j = 0; j < APW; ++j) ra[rb][j] = *reinterpret_cast<const u32x4_t*>(uptr(at[j] + off) + loff);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int rb, int buf) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) *reinterpret_cast<u32x4_t*>(lds + buf * ABYTES + (wave * APW + j) * 1024 + loff) = ra[j];
+        for (int j = 0; j < APW; ++j) *reinterpret_cast<u32x4_t*>(lds + buf * ABYTES + (wave * APW + j) * 1024 + loff) = ra[rb][j];
     };
-    auto compute = [&](int buf) {
+    // MFMAs of the chunks [b0, b0 + nb) as ONE sequence of k-steps (LDS image / weight registers b hold chunk b).  One wave per SIMD:
+    // nothing but the wave's own instruction stream hides LDS latency, and hipcc reads each fragment right before its MFMA - so the
+    // fragments of k-step u + PD are read while the MFMAs of k-step u issue, with the order pinned by scheduling barriers.
+    auto compute_seq = [&](auto b0c, auto nbc) {
+        constexpr int b0 = decltype(b0c)::value, nb = decltype(nbc)::value;
+        constexpr int PD = MT >= 8 ? 1 : 2;          // k-steps of fragments in flight ahead of the MFMAs
+        constexpr int NU = nb * KC;
+        u32x4_t fa[PD + 1][MT];
+        auto rd = [&](int u, int i) {
+            const int b = b0 + u / KC, uu = u % KC;
+            return *reinterpret_cast<const u32x4_t*>(lds + b * ABYTES + (uu * MT + i) * 1024 + loff);
+        };
 #pragma unroll
-        for (int u = 0; u < KC; ++u) {
+        for (int u = 0; u < PD && u < NU; ++u)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const u32x4_t fa = *reinterpret_cast<const u32x4_t*>(lds + buf * ABYTES + (u * MT + i) * 1024 + loff);
+            for (int i = 0; i < MT; ++i) fa[u][i] = rd(u, i);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + PD < NU) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[(u + PD) % (PD + 1)][i] = rd(u + PD, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[buf][u][q]),
-                                                                        __builtin_bit_cast(bf16x8_t, fa), acc[i][q], 0, 0, 0);
-            }
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[b0 + u / KC][u % KC][q]),
+                                                                        __builtin_bit_cast(bf16x8_t, fa[u % (PD + 1)][i]), acc[i][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    auto compute = [&](int buf) {
+        if (buf == 0) compute_seq(I0{}, I1{});
+        else compute_seq(I1{}, I1{});
+    };
 
-    load_a(0);
-    load_w(0, 0);
-    load_w(1, 1);
-    store_a(0);
-    __syncthreads();
-    for (int c = 0;; c += 2) {
-        load_a(c + 1);
+    if constexpr (NCH == 1) {
+        load_a(0, 0);
+        load_w(0, 0);
+        rstd_reduce();
+        store_a(0, 0);
+        __syncthreads();
         compute(0);
-        if (c + 1 >= nch) break;
-        store_a(1);
+    } else if constexpr (NCH == 2) {
+        // the whole slice in flight at once: activations (L2) first, then the weight stream; ONE barrier
+        load_a(0, 0);
+        load_a(1, 1);
+        load_w(0, 0);
+        load_w(1, 1);
+        rstd_reduce();
+        store_a(0, 0);
+        store_a(1, 1);
         __syncthreads();
-        load_w(c + 2, 0);
-        load_a(c + 2);
-        compute(1);
-        if (c + 2 >= nch) break;
-        store_a(0);
+        compute_seq(I0{}, I2{});
+    } else if (nch == 1) {
+        load_a(0, 0);
+        load_w(0, 0);
+        rstd_reduce();
+        store_a(0, 0);
         __syncthreads();
-        load_w(c + 3, 1);
+        compute(0);
+    } else {
+        // two chunks in flight from the start; in the steady state the activations run two chunks ahead of the MFMAs (registers
+        // -> LDS one chunk ahead) and the weights one to two chunks ahead
+        load_a(0, 0);
+        load_w(0, 0);
+        load_a(1, 1);
+        load_w(1, 1);
+        rstd_reduce();
+        store_a(0, 0);
+        __syncthreads();
+        int c = 0;
+        for (; c + 3 < nch; c += 2) {
+            load_a(c + 2, 0);
+            compute(0);
+            load_w(c + 2, 0);
+            store_a(1, 1);
+            __syncthreads();
+            load_a(c + 3, 1);
+            compute(1);
+            load_w(c + 3, 1);
+            store_a(0, 0);
+            __syncthreads();
+        }
+        if (nch - c == 2) {
+            compute(0);
+            store_a(1, 1);
+            __syncthreads();
+            compute(1);
+        } else {
+            load_a(c + 2, 0);
+            compute(0);
+            load_w(c + 2, 0);
+            store_a(1, 1);
+            __syncthreads();
+            compute(1);
+            store_a(0, 0);
+            __syncthreads();
+            compute(0);
+        }
     }
 
     // ---- K-slices: publish, ticket, last arriver adds the slabs in slice order --------------------------------------
@@ -216,17 +307,31 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < NS; ++q) acc[i][q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splitk; ++s) {
-            const unsigned so = (unsigned)(((long)s * D2_NW + wave) * slab_f * 4) + lane * 16;
-            u32x4_t part[MT][NS];
+        // slabs in slice order, SG slices' loads in flight at a time (slices past the end re-read the last one and are masked off)
+        constexpr int SG = MT * NS >= 16 ? 1 : (MT * NS >= 8 ? 2 : 4);
+        for (int sb = 0; sb < p.splitk; sb += SG) {
+            u32x4_t part[SG][MT][NS];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int g = 0; g < SG; ++g) {
+                const unsigned so = (unsigned)(((long)min(sb + g, p.splitk - 1) * D2_NW + wave) * slab_f * 4) + lane * 16;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) part[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (unsigned)((i * NS + q) * 1024), 0, 16);   // sc1
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                    for (int q = 0; q < NS; ++q) part[g][i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (unsigned)((i * NS + q) * 1024), 0, 16);   // sc1
+            }
 #pragma unroll
-                for (int q = 0; q < NS; ++q) acc[i][q] += __builtin_bit_cast(f32x4_t, part[i][q]);
+            for (int g = 0; g < SG; ++g) {
+                const unsigned keep = sb + g < p.splitk ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        u32x4_t v = part[g][i][q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] &= keep;
+                        acc[i][q] += __builtin_bit_cast(f32x4_t, v);
+                    }
+            }
         }
     }
 
@@ -238,7 +343,7 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + l15;
         const bool mok = m < a.M;
-        const float rsd = a.ss_in ? rstd_s[m] : 1.0f;
+        const float rsd = rstd_s[m];
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int tile = t0 + q;
@@ -367,11 +472,17 @@ DefaultWs& default_ws() {
     return w;
 }
 
+template <int MT, int NT, bool GLU, int KC, int NCH>
+void launch3(hipStream_t st, const DecGemm& a, const Dec2Plan& p, int rslabs) {
+    const dim3 grid(p.ncb * p.splitk, rslabs), block(D2_NW * 64);
+    if (a.w_cached) launch_k(gemm_dec2_kernel<MT, NT, GLU, KC, false, NCH>, grid, block, 0, st, a, p);
+    else launch_k(gemm_dec2_kernel<MT, NT, GLU, KC, true, NCH>, grid, block, 0, st, a, p);
+}
 template <int MT, int NT, bool GLU, int KC>
 void launch2(hipStream_t st, const DecGemm& a, const Dec2Plan& p, int rslabs) {
-    const dim3 grid(p.ncb * p.splitk, rslabs), block(D2_NW * 64);
-    if (a.w_cached) launch_k(gemm_dec2_kernel<MT, NT, GLU, KC, false>, grid, block, 0, st, a, p);
-    else launch_k(gemm_dec2_kernel<MT, NT, GLU, KC, true>, grid, block, 0, st, a, p);
+    if (p.nch == 1) launch3<MT, NT, GLU, KC, 1>(st, a, p, rslabs);
+    else if (p.nch == 2) launch3<MT, NT, GLU, KC, 2>(st, a, p, rslabs);
+    else launch3<MT, NT, GLU, KC, 0>(st, a, p, rslabs);
 }
 
 }  // namespace
@@ -400,6 +511,7 @@ static Dec2Choice dec2_choose(const DecGemm& a) {
     const Tune& t = tune();
     if (!t.enable || a.nf > 0 || a.M < t.min_m || !a.a_frag || (a.M > 128 && a.M % 128 != 0)) return c;
     if (a.glu && a.N % 16 != 0) return c;
+    if (a.ss_in && a.n_parts_in > 64) return c;        // (the RMS prologue prefetches at most 64 partial sums per row)
     if (a.K % 32 != 0 || a.K < 256) return c;
     const int Mslab = a.M > 128 ? 128 : a.M;
     c.rslabs = a.M > 128 ? a.M / 128 : 1;
@@ -414,15 +526,22 @@ static Dec2Choice dec2_choose(const DecGemm& a) {
     if (a.glu) nt = 1;
     c.NT = nt;
     c.ncb = (ntiles + D2_NW * nt - 1) / (D2_NW * nt);
-    // K-slices: fill about one workgroup per CU (256), never more than 8 slabs per tile
+    // K-slices: slices of one or two chunks run the straight-line schedule (every load of the slice in flight at once); among those
+    // the fewest slices that still give about one workgroup per CU.  Shapes that cannot be cut that way (few chunks that do not
+    // divide, or so many column blocks that one slice per block fills the chip) run the chunk loop.
     int sk = 1;
     if (t.splitk > 0) sk = t.splitk;
     else {
         const int items = c.ncb * c.rslabs;
-        while (sk < 8 && items * sk < 192 && chunks % (sk * 2) == 0) sk *= 2;
-        if (items * sk < 192 && sk < 8) {     // odd factors (K = 6144: 24 chunks, K = 1280: 5)
-            for (int f = sk + 1; f <= 12; ++f)
-                if (chunks % f == 0 && items * f >= 192) { sk = f; break; }
+        int best = 0;
+        for (int f = 1; f <= 12; ++f) {
+            if (chunks % f != 0 || chunks / f > 2) continue;
+            best = f;
+            if (items * f >= 192) break;
+        }
+        if (best > 0 && items < 512) sk = best;
+        else {
+            while (sk < 8 && items * sk < 192 && chunks % (sk * 2) == 0) sk *= 2;
         }
     }
     if (sk < 1 || chunks % sk != 0) sk = 1;

@@ -316,7 +316,7 @@ __device__ int block_sample_256(const float* __restrict__ row, int V, const unsi
     for (int w = 0; w < (tid >> 6); ++w) base += red[w];
     const float excl = base + inc - loc;
     __shared__ int chosen;
-    if (tid == 0) chosen = -1;
+    if (tid == 0) chosen = 0x7fffffff;
     __syncthreads();
     if (loc > 0.f && u >= excl && u < excl + loc) {
         float c = excl;
@@ -329,10 +329,11 @@ __device__ int block_sample_256(const float* __restrict__ row, int V, const unsi
                 if (u < c) break;
             }
         }
-        chosen = pick;
+        // float rounding can make two threads' [excl, excl + loc) intervals overlap by an ulp: the lowest index wins, always
+        if (pick >= 0) atomicMin(&chosen, pick);
     }
     __syncthreads();
-    if (chosen < 0) {        // u fell on a rounding seam: take the most likely kept token
+    if (chosen == 0x7fffffff) {        // u fell on a rounding seam: take the most likely kept token
         __syncthreads();
         int best = block_argmax_256(sl, V, nullptr, nullptr);
         return best;

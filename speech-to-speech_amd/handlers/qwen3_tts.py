@@ -74,7 +74,11 @@ def build_tts_engine(model_name: str, device: str, dtype: str, max_batch: int, m
         if "text.proj.0.weight" in text:
             proj = [(text["text.proj.0.weight"].numpy(), text["text.proj.0.bias"].numpy()), (text["text.proj.1.weight"].numpy(), text["text.proj.1.bias"].numpy())]
         tok = load_tokenizer(key)
-        eng.text_frontend = TableTextFrontend(text["text.embedding.weight"].numpy(), layout, tok if hasattr(tok, "encode") and not isinstance(tok, __import__("speech_to_speech_amd.text", fromlist=["IdTextCodec"]).IdTextCodec) else None, proj)
+        from ..text import IdTextCodec
+
+        eng.text_frontend = TableTextFrontend(text["text.embedding.weight"].numpy(), layout,
+                                              tok if hasattr(tok, "encode") and not isinstance(tok, IdTextCodec) else None, proj,
+                                              codec_table=sd["talker.model.codec_embedding.weight"].float().numpy())
         return eng
     dims = TTS_DIMS[key]()
     sd = qwen3_tts_state_dict(dims, seed=seed or 5)
@@ -155,7 +159,11 @@ class MI355XQwen3TTSHandler(BaseHandler):
 
     def _build_prompt(self, text: str) -> TTSPrompt:
         eng = self.pool.engine("tts")
-        return TTSPrompt(eng.text_frontend.embed(text, eng.max_prompt))
+        fe = eng.text_frontend
+        if getattr(fe, "layout", None) is not None:      # checkpoint front-end: the session's voice / language select codec-side control rows
+            lang = getattr(self, "language", None)
+            return TTSPrompt(fe.embed(text, eng.max_prompt, speaker=getattr(self, "speaker", None), language=None if lang in (None, "auto") else lang))
+        return TTSPrompt(fe.embed(text, eng.max_prompt))
 
     def _build_prompts(self, text: str) -> list[tuple[str, TTSPrompt]]:
         """One prompt per piece of text that fits the engine's prefill budget.  An over-long input is split at sentence ends, then at

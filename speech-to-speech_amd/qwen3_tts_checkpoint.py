@@ -115,6 +115,7 @@ def required_names(dims: Qwen3TTSDims) -> list[str]:
 def remap_names(sd: Mapping[str, torch.Tensor], extra_rules: Mapping[str, str] | None = None) -> dict[str, torch.Tensor]:
     rules = [(re.compile(k), v) for k, v in (extra_rules or {}).items()] + [(re.compile(k), v) for k, v in NAME_RULES]
     out: dict[str, torch.Tensor] = {}
+    origin: dict[str, str] = {}
     for name, t in sd.items():
         cur = name
         for _ in range(4):                      # rules chain (e.g. un-nest the predictor, then rename its in-projection)
@@ -127,7 +128,10 @@ def remap_names(sd: Mapping[str, torch.Tensor], extra_rules: Mapping[str, str] |
             if new == cur:
                 break
             cur = new
+        if cur in out:                          # two checkpoint tensors landing on one engine tensor: never pick one silently
+            raise KeyError(f"name mapping collision: checkpoint tensors {origin[cur]!r} and {name!r} both map to {cur!r}; fix name_map.json")
         out[cur] = t
+        origin[cur] = name
     return out
 
 
@@ -149,9 +153,64 @@ def load_qwen3_tts_checkpoint(path: str):
     if missing:
         raise KeyError(f"{path}: {len(missing)} tensors the engine needs are missing after name mapping (first: {missing[:6]}); "
                        "add rules to name_map.json (see speech-to-speech_amd/qwen3_tts_checkpoint.py)")
+    _check_shapes_cheap(sd, dims, need)
     text = {k: sd[k] for k in ("text.embedding.weight", "text.proj.0.weight", "text.proj.0.bias", "text.proj.1.weight", "text.proj.1.bias", "text.pad_embed")
             if k in sd}
+    if cfg.get("format") != "s2s-mi355x" and not os.path.exists(os.path.join(path, "prompt_layout.json")):
+        # a foreign checkpoint's prompt (control tokens, speaker / language rows) cannot be guessed: wrong rows give fluent-sounding wrong audio
+        raise FileNotFoundError(f"{path}: prompt_layout.json is required for a checkpoint that is not in this repo's export format "
+                                "(see TTSPromptLayout in speech-to-speech_amd/qwen3_tts_checkpoint.py)")
     return dims, {k: sd[k] for k in need}, TTSPromptLayout.load(path), text or None
+
+
+def _expected_shapes(dims: Qwen3TTSDims) -> dict[str, tuple]:
+    """name -> shape of every tensor the converter reads, from the dims alone (no allocation)."""
+    E, P, H, G, CB = dims.t_hidden, dims.p_hidden, dims.c_hidden, dims.n_groups, dims.codebook
+    out: dict[str, tuple] = {}
+
+    def stack(prefix, hidden, layers, heads, kv, hd, ffn, qk_norm, layer_scale):
+        for l in range(layers):
+            p = f"{prefix}layers.{l}."
+            out[p + "self_attn.q_proj.weight"] = (heads * hd, hidden)
+            out[p + "self_attn.k_proj.weight"] = (kv * hd, hidden)
+            out[p + "self_attn.v_proj.weight"] = (kv * hd, hidden)
+            out[p + "self_attn.o_proj.weight"] = (hidden, heads * hd)
+            if qk_norm:
+                out[p + "self_attn.q_norm.weight"] = (hd,)
+                out[p + "self_attn.k_norm.weight"] = (hd,)
+            out[p + "mlp.gate_proj.weight"] = (ffn, hidden)
+            out[p + "mlp.up_proj.weight"] = (ffn, hidden)
+            out[p + "mlp.down_proj.weight"] = (hidden, ffn)
+            out[p + "input_layernorm.weight"] = (hidden,)
+            out[p + "post_attention_layernorm.weight"] = (hidden,)
+            if layer_scale:
+                out[p + "self_attn_layer_scale.scale"] = (hidden,)
+                out[p + "mlp_layer_scale.scale"] = (hidden,)
+
+    stack("talker.model.", E, dims.t_layers, dims.t_heads, dims.t_kv_heads, dims.t_head_dim, dims.t_ffn, True, False)
+    out["talker.model.norm.weight"] = (E,)
+    out["talker.model.codec_embedding.weight"] = (dims.codec_vocab, E)
+    out["talker.codec_head.weight"] = (dims.codec_vocab, E)
+    stack("code_predictor.model.", P, dims.p_layers, dims.p_heads, dims.p_kv_heads, dims.p_head_dim, dims.p_ffn, True, False)
+    out["code_predictor.model.norm.weight"] = (P,)
+    if P != E:
+        out["code_predictor.in_proj.weight"] = (P, E)
+        out["code_predictor.in_proj.bias"] = (P,)
+    for g in range(G - 1):
+        out[f"code_predictor.model.codec_embedding.{g}.weight"] = (CB, E)
+        out[f"code_predictor.lm_head.{g}.weight"] = (CB, P)
+    out["code2wav.code_embedding.weight"] = (CB * G, H)
+    stack("code2wav.pre_transformer.", H, dims.c_layers, dims.c_heads, dims.c_heads, H // dims.c_heads, dims.c_ffn, False, True)
+    out["code2wav.pre_transformer.norm.weight"] = (H,)
+    return out
+
+
+def _check_shapes_cheap(sd: Mapping[str, torch.Tensor], dims: Qwen3TTSDims, need: list[str]) -> None:
+    want = _expected_shapes(dims)
+    bad = [(k, tuple(sd[k].shape), want[k]) for k in need if k in want and k in sd and tuple(sd[k].shape) != want[k]]
+    if bad:
+        k, got, shp = bad[0]
+        raise ValueError(f"{len(bad)} checkpoint tensors do not match config.json (first: {k} has shape {got}, the config implies {shp})")
 
 
 def save_synthetic_checkpoint(path: str, dims: Qwen3TTSDims, sd: Mapping[str, torch.Tensor], text_table: np.ndarray | None = None,
@@ -175,24 +234,59 @@ class TableTextFrontend:
     """Text side of the prompt for a checkpoint: token ids (tokenizer.json when present, UTF-8 bytes otherwise) -> rows of the text
     embedding table, through the 2-layer projection when the checkpoint has one (text width != talker width)."""
 
-    def __init__(self, table: np.ndarray, layout: TTSPromptLayout, tokenizer: Any = None, proj: list | None = None):
+    def __init__(self, table: np.ndarray, layout: TTSPromptLayout, tokenizer: Any = None, proj: list | None = None,
+                 codec_table: np.ndarray | None = None):
         self.table, self.layout, self.tokenizer, self.proj = table.astype(np.float32), layout, tokenizer, proj
+        self.codec_table = None if codec_table is None else np.asarray(codec_table, dtype=np.float32)
+        lay = layout
+        if (lay.codec_prefix or lay.codec_bos is not None or lay.speaker_ids or lay.language_ids) and self.codec_table is None:
+            # the layout asks for codec-side rows: without the codec embedding table they would silently be missing from the prefill
+            raise ValueError("prompt_layout.json sets codec-side fields (codec_prefix / codec_bos / speaker_ids / language_ids) but the front-end "
+                             "was built without the talker's codec embedding table")
+
+    def _text_rows(self, ids: list[int]) -> np.ndarray:
+        rows = self.table[np.asarray(ids, dtype=np.int64)]
+        if self.proj:
+            (w0, b0), (w1, b1) = self.proj
+            h = rows @ w0.T + b0
+            rows = (h / (1.0 + np.exp(-h))) @ w1.T + b1              # SiLU MLP
+        return rows.astype(np.float32)
 
     def _ids(self, text: str) -> list[int]:
         if self.tokenizer is not None:
             return list(self.tokenizer.encode(text))
         return list(text.encode("utf-8"))
 
-    def embed(self, text: str, max_tokens: int) -> np.ndarray:
+    def embed(self, text: str, max_tokens: int, speaker: str | None = None, language: str | None = None) -> np.ndarray:
+        """Prefill rows, row i = text_side[i] + codec_side[i] (TTSPromptLayout):
+            [codec control rows: codec_prefix, then the language and the speaker token when given; text side = text_pad]
+            [text rows: text_bos, the text tokens, text_eos; no codec side]
+            [codec_bos row; text side = text_pad]
+        An unknown speaker / language name is an error (never a silent default voice)."""
         lay = self.layout
+        ctrl = list(lay.codec_prefix)
+        if language and language != "auto":
+            if lay.language_ids:
+                if language not in lay.language_ids:
+                    raise ValueError(f"language {language!r} is not in prompt_layout.json's language_ids {sorted(lay.language_ids)}")
+                ctrl.append(lay.language_ids[language])
+        if speaker:
+            if speaker not in lay.speaker_ids:
+                raise ValueError(f"speaker {speaker!r} is not in prompt_layout.json's speaker_ids {sorted(lay.speaker_ids)[:16]}")
+            ctrl.append(lay.speaker_ids[speaker])
+        tail = [lay.codec_bos] if lay.codec_bos is not None else []
         ids = self._ids(text)
-        budget = min(lay.max_text_tokens, max_tokens - (lay.text_bos is not None) - (lay.text_eos is not None))
+        n_fixed = (lay.text_bos is not None) + (lay.text_eos is not None) + len(ctrl) + len(tail)
+        budget = min(lay.max_text_tokens, max_tokens - n_fixed)
         if len(ids) > budget:
             raise ValueError(f"TTS input of {len(ids)} text tokens exceeds the prompt budget of {budget}; split the text into shorter sentences")
         ids = ([lay.text_bos] if lay.text_bos is not None else []) + ids + ([lay.text_eos] if lay.text_eos is not None else [])
-        rows = self.table[np.asarray(ids)]
-        if self.proj:
-            (w0, b0), (w1, b1) = self.proj
-            h = rows @ w0.T + b0
-            rows = (h / (1.0 + np.exp(-h))) @ w1.T + b1              # SiLU MLP
-        return rows.astype(np.float32)
+        rows = self._text_rows(ids)
+        if not ctrl and not tail:
+            return rows
+        pad = self._text_rows([lay.text_pad])[0] if lay.text_pad is not None else np.zeros(rows.shape[1], np.float32)
+        if self.codec_table.shape[1] != rows.shape[1]:
+            raise ValueError(f"codec embedding width {self.codec_table.shape[1]} != text row width {rows.shape[1]}")
+        head = self.codec_table[np.asarray(ctrl, dtype=np.int64)] + pad if ctrl else np.zeros((0, rows.shape[1]), np.float32)
+        foot = self.codec_table[np.asarray(tail, dtype=np.int64)] + pad if tail else np.zeros((0, rows.shape[1]), np.float32)
+        return np.concatenate([head, rows, foot]).astype(np.float32)

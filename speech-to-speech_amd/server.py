@@ -97,6 +97,11 @@ def create_app(pool: Any, stt_model: str = "whisper", tokenizer: Any = None, stt
         language = (form.get("language") or form.get("languages[]") or default_language or "auto")
         opts = dict(stt_options or {})
         if stt_model == "whisper":
+            # a language the vocabulary does not know would raise inside the BATCH and fail every co-batched session: refuse it here
+            vocab = opts.get("vocab")
+            known = getattr(vocab, "lang_to_id", None)
+            if language != "auto" and known and language not in known:
+                raise HTTPException(status_code=400, detail=f"unsupported language {language!r}")
             opts.setdefault("language", language)
         try:
             res = await run_in_threadpool(lambda: pool.transcribe(stt_model, audio, **opts))
@@ -117,14 +122,34 @@ def create_app(pool: Any, stt_model: str = "whisper", tokenizer: Any = None, stt
         if not text:
             raise HTTPException(status_code=400, detail="missing 'input'")
         fmt = body.get("response_format", "pcm")
-        chunks, _cancel = pool.synthesize(tts_prompt(text), int(body.get("max_new_tokens", tts_max_new_tokens)))
+        if fmt not in ("pcm", "wav"):
+            raise HTTPException(status_code=400, detail="response_format must be 'pcm' or 'wav'")
+        # the frame budget of one request must fit the engine, or the whole lane batch it joins would fail ("frame budget exceeded")
+        cap = int(getattr(pool.engine("tts"), "max_frames", tts_max_new_tokens))
+        try:
+            budget = int(body.get("max_new_tokens", tts_max_new_tokens))
+        except (TypeError, ValueError):
+            raise HTTPException(status_code=400, detail="max_new_tokens must be an integer")
+        budget = max(1, min(budget, cap, int(tts_max_new_tokens)))
+        try:
+            prompt = tts_prompt(text)
+        except ValueError as e:
+            raise HTTPException(status_code=400, detail=f"input too long: {e}")
+        chunks, cancel = pool.synthesize(prompt, budget)
         if fmt == "wav":
-            pcm = await run_in_threadpool(lambda: np.concatenate([np.asarray(c, dtype=np.int16) for c in chunks] or [np.zeros(0, np.int16)]))
+            try:
+                pcm = await run_in_threadpool(lambda: np.concatenate([np.asarray(c, dtype=np.int16) for c in chunks] or [np.zeros(0, np.int16)]))
+            except BaseException:
+                cancel.set()
+                raise
             return Response(float_pcm16_wav(pcm), media_type="audio/wav")
 
         def gen():
-            for c in chunks:
-                yield np.asarray(c, dtype="<i2").tobytes()
+            try:
+                for c in chunks:
+                    yield np.asarray(c, dtype="<i2").tobytes()
+            finally:
+                cancel.set()         # client gone (generator closed) or stream complete: the lane stops generating for this request
 
         return StreamingResponse(gen(), media_type="audio/pcm")
 

@@ -86,7 +86,9 @@ class WhisperVocab:
 
     def validate(self, vocab_size: int) -> "WhisperVocab":
         """Every id must index the model's vocabulary (an out-of-range suppress / language id would write past the masks)."""
-        ids = [self.sot, self.eot, self.transcribe, self.notimestamps, *self.lang_to_id.values(), *self.suppress, *self.begin_suppress]
+        ids = [self.sot, self.eot, self.notimestamps, *self.lang_to_id.values(), *self.suppress, *self.begin_suppress]
+        if self.lang_to_id:
+            ids.append(self.transcribe)      # English-only checkpoints never emit a task token (prompt() skips it): -1 / absent is fine
         bad = [i for i in ids if not 0 <= int(i) < vocab_size]
         if bad:
             raise ValueError(f"Whisper vocabulary ids {sorted(set(bad))[:8]} are outside the model's {vocab_size}-token vocabulary; "

@@ -7,7 +7,8 @@ import base64
 import numpy as np
 import pytest
 
-from speech_to_speech_amd.audio_edge import EdgeResampler, PcmChunker, encode_audio_chunks, reference_resample
+from oracle.audio_edge import reference_resample
+from speech_to_speech_amd.audio_edge import EdgeResampler, PcmChunker, encode_audio_chunks
 
 pytestmark = pytest.mark.gpu
 

@@ -145,10 +145,35 @@ def test_qwen3_tts_checkpoint_directory_round_trip_and_name_rules(tmp_path):
     got_dims, got_sd, layout, text = load_qwen3_tts_checkpoint(str(d))
     assert got_dims == dims and set(got_sd) == set(sd) and all(torch.equal(got_sd[k], sd[k]) for k in sd)
     assert layout.speaker_ids == {"aiden": 3} and layout.max_text_tokens == 40 and np.array_equal(text["text.embedding.weight"].numpy(), table)
-    fe = TableTextFrontend(table, layout)
+    # the layout names a speaker: the front-end needs the talker's codec embedding table to build that row, and refuses to run without it
+    with pytest.raises(ValueError, match="codec embedding table"):
+        TableTextFrontend(table, layout)
+    codec_table = got_sd["talker.model.codec_embedding.weight"].numpy()
+    fe = TableTextFrontend(table, layout, codec_table=codec_table)
     assert fe.embed("hi", 64).shape == (4, dims.t_hidden) and np.array_equal(fe.embed("hi", 64)[1], table[ord("h")])
+    spoken = fe.embed("hi", 64, speaker="aiden")                     # [speaker row | bos h i eos]
+    assert spoken.shape == (5, dims.t_hidden) and np.array_equal(spoken[0], codec_table[3]) and np.array_equal(spoken[1:], fe.embed("hi", 64))
+    with pytest.raises(ValueError, match="speaker"):
+        fe.embed("hi", 64, speaker="nobody")
     with pytest.raises(ValueError):
         fe.embed("x" * 41, 64)
+    # codec control rows in front, codec bos behind, text pad row added to every codec-only position
+    lay2 = TTSPromptLayout(text_bos=256, text_eos=257, text_pad=0, codec_prefix=[5, 6], codec_bos=7, language_ids={"en": 2}, max_text_tokens=40)
+    fe2 = TableTextFrontend(table, lay2, codec_table=codec_table)
+    rows = fe2.embed("a", 64, language="en")
+    assert rows.shape == (2 + 1 + 3 + 1, dims.t_hidden)
+    assert np.allclose(rows[0], codec_table[5] + table[0]) and np.allclose(rows[2], codec_table[2] + table[0]) and np.allclose(rows[-1], codec_table[7] + table[0])
+    assert np.array_equal(rows[4], table[ord("a")])
+    # a config / weights mismatch is reported by name
+    bad_shape = dict(foreign)
+    bad_shape["talker.codec_head.weight"] = torch.zeros(dims.codec_vocab + 1, dims.t_hidden)
+    save_synthetic_checkpoint(str(tmp_path / "badshape"), dims, bad_shape, text_table=table)
+    (tmp_path / "badshape" / "name_map.json").write_text(json.dumps({"^vq[.]codebooks$": "code2wav.code_embedding.weight"}))
+    with pytest.raises(ValueError, match="codec_head"):
+        load_qwen3_tts_checkpoint(str(tmp_path / "badshape"))
+    # two checkpoint tensors mapping onto one engine tensor is an error, not a silent overwrite
+    with pytest.raises(KeyError, match="collision"):
+        remap_names({"code_predictor.in_proj.weight": 1, "code_predictor.small_to_mtp_projection.weight": 2})
     # a missing tensor is an error that names it
     del foreign["talker.codec_head.weight"]
     save_synthetic_checkpoint(str(tmp_path / "bad"), dims, foreign, text_table=table)
