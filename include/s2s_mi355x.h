@@ -104,6 +104,16 @@ int32_t s2s_logmel_whisper_tm(void* frontend, void* stream, const float* pcm_dev
                               int64_t pcm_stride, const int32_t* n_samples_dev, int32_t B,
                               void* out_dev, int32_t out_dtype);
 
+/* Whisper features of a shorter window with optional zero-mean / unit-variance waveform normalisation: the feature half of the
+ * reference's Smart-Turn end-of-turn check (VAD/smart_turn.py:130-143 = WhisperFeatureExtractor(chunk_length=8)(...,
+ * do_normalize=True, max_length=128000); the ONNX classifier itself stays on the host).  window_samples: a multiple of 160 in
+ * [400, 480000]; rows longer than the window are truncated to their FIRST window_samples samples (the extractor's rule; Smart-Turn
+ * keeps the LAST 8 s before calling it, smart_turn.py:123-128 - the host adapter does that).  normalize != 0: every row is
+ * replaced by (x - mean) / sqrt(var + 1e-7) over its valid samples, padding stays 0.  out_dev: [B][n_mels][window_samples / 160]. */
+int32_t s2s_logmel_whisper_window(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
+                                  const int32_t* n_samples_dev, int32_t B, int32_t window_samples, int32_t normalize,
+                                  void* out_dev, int32_t out_dtype);
+
 /* out_dev: [B][t_max][n_mels] (time-major, zero beyond each row's valid
  * frames), n_frames_dev: int32[B] valid frames (= n_samples / 160).
  * t_max must be >= max(n_samples)/160 + 1. */
@@ -165,6 +175,8 @@ int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t K, int32_t nf, int32
  * splitk / nt > 0 force the K-slices per column block / the 16-column tiles per wave of the column-block kernel (0 = chosen
  * from the shape).  Process-wide: not for use while engines are serving. */
 int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt);
+/* development: per-workgroup phase timestamps of the column-block decode kernel (8 x u64 per workgroup, 100 MHz), null = off */
+int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
 /* xb = bf16(x) (frag != 0: fragment-major [rows][cols]) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
 int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
                          int32_t frag);
@@ -348,10 +360,32 @@ int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_de
  * min_total_frames frames; *all_done_host (optional, forces a stream sync) = 1 when every session has ended. */
 int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t min_total_frames, int32_t* codes_dev,
                          int32_t* n_frames_dev, int32_t* all_done_host);
+/* Continuous batching of the frame loop.  The reference streams every session on its own (TTS/qwen3_tts_handler.py:695-749:
+ * `_stream()` per request, independent generators); here the rows ("slots", 0 .. max_batch - 1) of ONE frame loop are shared, and
+ * sessions join and leave at chunk boundaries while the others keep generating - every slot has its own frame index, eos gate,
+ * frame budget and sampler key on the device.
+ *   s2s_tts_admit       prefill n prompts (layout of s2s_tts_prefill) into the slots [slot0, slot0 + n); the other slots are not
+ *                       touched.  min_frames_dev / budget_dev: optional int32[n] per session, else min_frames / max_new_frames for all
+ *                       (a slot retires itself at eos or after its budget).  utterance_id0 + i keys session i's sampler stream.
+ *   s2s_tts_step        n_frames passes of the frame body over the slots [0, rows) (captured graph per row count); finished / idle
+ *                       slots stand still.
+ *   s2s_tts_read_codes  frames [frame0, frame0 + n_frames) of the slots [slot0, slot0 + n) -> codes_dev int32 [n][n_frames][n_groups]
+ *                       (-1 after a session's end); n_frames_dev (optional) int32[n] valid frames so far; valid_samples_dev (optional)
+ *                       int32[n] = how many of the chunk's chunk_samples 24 kHz codec samples belong to valid frames (the resampler
+ *                       treats the rest as silence, so a session's last samples do not depend on what its batch-mates still generate).
+ *   s2s_tts_release     the slots [slot0, slot0 + n) become idle.
+ * s2s_tts_prefill = release every slot + admit into slots 0 .. B-1; s2s_tts_generate = step + read of the frames of that call. */
+int32_t s2s_tts_admit(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev, int32_t n, int32_t Tp,
+                      int32_t slot0, const int32_t* min_frames_dev, const int32_t* budget_dev, int32_t min_frames, int32_t max_new_frames,
+                      int32_t utterance_id0);
+int32_t s2s_tts_step(void* model, void* stream, int32_t rows, int32_t n_frames);
+int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, int32_t n, int32_t frame0, int32_t n_frames, int32_t* codes_dev,
+                           int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev);
+int32_t s2s_tts_release(void* model, void* stream, int32_t slot0, int32_t n);
 /* Sampling of the frame loop (the reference's backend samples; greedy is the parity policy and the default).  which: 0 = talker
  * (codebook 0; the repetition penalty covers the utterance's earlier codebook-0 picks), 1 = code predictor (residual groups).
  * Processor order = transformers generate(): repetition penalty -> temperature -> top-k -> top-p -> seeded multinomial
- * (counter-based uniform of (seed, session, frame, group): reproducible, independent of batch composition).  temperature <= 0
+ * (counter-based uniform of (seed, utterance id, frame, group): reproducible, independent of batch composition and of the slot).  temperature <= 0
  * restores greedy.  Re-captures the frame graphs on the next generate call. */
 int32_t s2s_tts_set_sampling(void* model, int32_t which, float temperature, int32_t top_k, float top_p, float repetition_penalty,
                              uint64_t seed);
@@ -378,6 +412,12 @@ int64_t s2s_codec_samples(void* model, int32_t F);
 int32_t s2s_codec_stream_reset(void* model);
 int32_t s2s_codec_stream_decode(void* model, void* stream, const int32_t* codes_dev, int32_t B, int32_t F, float* wav_dev,
                                 int32_t n_samples);
+/* The same continuation for a COHORT of a continuously batched engine: rows [slot0, slot0 + n) of the engine's codec state (history
+ * rows, pre-transformer cache), frames_done frames already decoded for them (0: their stream starts with this call).  codes_dev
+ * int32 [n][F][n_groups]; n_samples = s2s_codec_samples(F) for the first call of a stream, F * total_upsample afterwards.  Cohorts on
+ * disjoint row ranges stream independently of each other (sessions admitted at different chunk boundaries). */
+int32_t s2s_codec_decode_rows(void* model, void* stream, const int32_t* codes_dev, int32_t slot0, int32_t n, int32_t F, int32_t frames_done,
+                              float* wav_dev, int32_t n_samples);
 /* Post-processing of Qwen3TTSHandler._stream (TTS/qwen3_tts_handler.py:612-613,674-680): per-chunk
  * scipy.signal.resample_poly(x, up=2, down=3) then clip(x*32768).astype(int16).
  *   pcm24_dev f32 [B][in_stride], n_in_dev optional int32 [B] (else in_stride samples), fir_dev f32 [taps] the

@@ -113,3 +113,33 @@ def parakeet_logmel(audio: np.ndarray, n_mels: int = 128, t_total: int | None = 
     out = np.zeros_like(mel)
     out[:n_valid] = (valid - mean) / (np.sqrt(var) + 1e-5)
     return out, n_valid
+
+
+def whisper_logmel_window(audio: np.ndarray, n_mels: int = 80, window_samples: int = WHISPER_N_SAMPLES, normalize: bool = False) -> np.ndarray:
+    """float64 [n_mels, window_samples // 160]: WhisperFeatureExtractor(chunk_length=window_samples / 16000) features, optionally
+    with do_normalize=True (feature_extraction_whisper.py: zero_mean_unit_var_norm over the valid samples - population variance,
+    + 1e-7 under the root, padding left at 0 - applied BEFORE the STFT).  The Smart-Turn feature path of the reference
+    (VAD/smart_turn.py:130-143) is window_samples = 128000, normalize = True, n_mels = 80."""
+    n_frames = window_samples // HOP
+    x = np.zeros(window_samples, dtype=np.float64)
+    n = min(len(audio), window_samples)
+    v = np.asarray(audio[:n], dtype=np.float32)
+    if normalize and n > 0:
+        v = ((v - v.mean()) / np.sqrt(v.var() + 1e-7)).astype(np.float32)      # the extractor normalises in float32
+    x[:n] = v.astype(np.float64)
+    xp = np.pad(x, (WHISPER_N_FFT // 2, WHISPER_N_FFT // 2), mode="reflect")
+    window = np.hanning(WHISPER_N_FFT + 1)[:-1]
+    fr = _frames(xp, n_frames + 1, WHISPER_N_FFT) * window[None, :]
+    power = np.abs(np.fft.rfft(fr, n=WHISPER_N_FFT, axis=1)) ** 2
+    filt = mel_filter_bank_slaney(WHISPER_N_FFT // 2 + 1, n_mels, fmax=8000.0)
+    log_spec = np.log10(np.maximum(1e-10, power @ filt).T)[:, :-1]
+    log_spec = np.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+def smart_turn_prepare_audio(audio: np.ndarray, max_samples: int = 128000) -> np.ndarray:
+    """reference VAD/smart_turn.py:103-128 at 16 kHz: keep the LAST 8 s, left-pad shorter audio with zeros."""
+    a = np.asarray(audio, dtype=np.float32)
+    if a.size > max_samples:
+        return a[-max_samples:]
+    return np.pad(a, (max_samples - a.size, 0), mode="constant")

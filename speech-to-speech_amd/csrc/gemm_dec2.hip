@@ -54,6 +54,7 @@ struct Dec2Plan {
     int nch;            // chunks of KC k-steps per slice
     float* slabs;       // [row slab][cb][slice][wave][MT * NS][256] f32 partial tiles
     unsigned* cnt;      // [row slab][cb] arrival tickets (zero between launches)
+    unsigned long long* dbg;   // development: 8 phase timestamps (100 MHz) per workgroup, or null
 };
 
 template <int MT, int NT, bool GLU, int KC, bool NTL, int NCH>      // NCH: chunks per slice known at compile time (1, 2: every load up front, straight-line), 0: any
@@ -71,6 +72,23 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rs = blockIdx.y;
+    // development timestamps: kept in scalar registers and written out at the END (a store in flight would change what the wait
+    // counts of the phases being measured mean)
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) {
+        if (p.dbg) {
+            __builtin_amdgcn_sched_barrier(0);
+            ts[i] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stamps_out = [&]() {
+        if (p.dbg && tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ts[i];
+        }
+    };
+    stamp(0);
     if (gridDim.y > 1) {             // M > 128: independent 128-row problems on shifted row pointers
         const long r0 = (long)rs * 128;
         a.A += r0 * (long)a.K;
@@ -222,8 +240,10 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         load_a(0, 0);
         load_w(0, 0);
         rstd_reduce();
+        stamp(7);
         store_a(0, 0);
         __syncthreads();
+        stamp(1);
         compute(0);
     } else if constexpr (NCH == 2) {
         // the whole slice in flight at once: activations (L2) first, then the weight stream; ONE barrier
@@ -232,16 +252,20 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         load_w(0, 0);
         load_w(1, 1);
         rstd_reduce();
+        stamp(7);
         store_a(0, 0);
         store_a(1, 1);
         __syncthreads();
+        stamp(1);
         compute_seq(I0{}, I2{});
     } else if (nch == 1) {
         load_a(0, 0);
         load_w(0, 0);
         rstd_reduce();
+        stamp(7);
         store_a(0, 0);
         __syncthreads();
+        stamp(1);
         compute(0);
     } else {
         // two chunks in flight from the start; in the steady state the activations run two chunks ahead of the MFMAs (registers
@@ -251,8 +275,10 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         load_a(1, 1);
         load_w(1, 1);
         rstd_reduce();
+        stamp(7);
         store_a(0, 0);
         __syncthreads();
+        stamp(1);
         int c = 0;
         for (; c + 3 < nch; c += 2) {
             load_a(c + 2, 0);
@@ -284,6 +310,8 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         }
     }
 
+    stamp(2);
+
     // ---- K-slices: publish, ticket, last arriver adds the slabs in slice order --------------------------------------
     if (p.splitk > 1) {
         const int tile = rs * p.ncb + cb;
@@ -299,9 +327,14 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][q]), rsrc, my + (unsigned)((i * NS + q) * 1024), 0, 16);   // sc1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
         __syncthreads();
+        stamp(3);
         if (tid == 0) *flag_s = __hip_atomic_fetch_add(p.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (*flag_s != (unsigned)(p.splitk - 1)) return;
+        stamp(4);
+        if (*flag_s != (unsigned)(p.splitk - 1)) {
+            stamps_out();
+            return;
+        }
         if (tid == 0) __hip_atomic_store(p.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket for the next launch
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -333,6 +366,7 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
                     }
             }
         }
+        stamp(5);
     }
 
     // ---- epilogue on the accumulator layout: lane = (row m = 16 i + l15, columns n .. n + 3 with n = tile * 16 + 4 lg) ----
@@ -444,6 +478,11 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
             a.ss_out[(long)cb * a.ss_stride + tid] = q;
         }
     }
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(6);
+        stamps_out();
+    }
 }
 
 struct Tune {
@@ -451,6 +490,7 @@ struct Tune {
     int splitk = 0;       // 0: chosen from the shape
     int nt = 0;           // 0: chosen from the shape
     int min_m = 33;
+    unsigned long long* dbg = nullptr;
 };
 Tune& tune() {
     static Tune t = [] {
@@ -497,6 +537,8 @@ int dec2_ensure_default_ws() {
     return S2S_OK;
 }
 
+void dec2_set_debug(unsigned long long* dbg) { tune().dbg = dbg; }
+
 void dec2_set_tune(int enable, int splitk, int nt) {
     Tune& t = tune();
     t.enable = enable;
@@ -513,6 +555,14 @@ static Dec2Choice dec2_choose(const DecGemm& a) {
     if (a.glu && a.N % 16 != 0) return c;
     if (a.ss_in && a.n_parts_in > 64) return c;        // (the RMS prologue prefetches at most 64 partial sums per row)
     if (a.K % 32 != 0 || a.K < 256) return c;
+    // Measured (profiles/r03_microbench_decode_gemm.txt): the 16-column kernel wins while ONE round of its N / 16 workgroups covers the
+    // chip and K is short (its cost is 2.2 us + 2.2 us per 1024 of K per round); this kernel wins on long K (>= 4096; >= 3072 above 64
+    // rows) and when the 16-column kernel would need more than one round (N / 16 > 256 workgroups).  enable = 2 forces it everywhere.
+    if (t.enable == 1 && t.splitk == 0 && t.nt == 0) {
+        const int wgs16 = (a.N + 15) / 16;
+        const bool long_k = a.K >= (a.M > 64 ? 3072 : 4096);
+        if (!long_k && wgs16 <= 256) return c;
+    }
     const int Mslab = a.M > 128 ? 128 : a.M;
     c.rslabs = a.M > 128 ? a.M / 128 : 1;
     c.MT = Mslab <= 64 ? 4 : 8;
@@ -564,6 +614,7 @@ int gemm_dec2(hipStream_t st, const DecGemm& a) {
     p.ncb = c.ncb;
     p.splitk = c.splitk;
     p.nch = c.nch;
+    p.dbg = tune().dbg;
     if (c.splitk > 1) {
         void* ws = a.ws;
         size_t wsb = a.ws_bytes;
@@ -597,6 +648,13 @@ int gemm_dec2(hipStream_t st, const DecGemm& a) {
 
 /* Tuning hook of the decode projections (microbenchmarks / parity sweeps): enable = 0 forces the 16-column kernel,
  * splitk / nt = 0 let the library choose.  Process-wide; not for use while engines are serving. */
+/* Development hook: 8 phase timestamps (100 MHz counter) per workgroup of every following column-block launch are written to
+ * dbg (device memory, >= 8 * workgroups u64), null switches it off. */
+extern "C" int32_t s2s_op_gemm_dec_debug(void* dbg) {
+    s2s::dec2_set_debug(reinterpret_cast<unsigned long long*>(dbg));
+    return S2S_OK;
+}
+
 extern "C" int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt) {
     s2s::dec2_set_tune(enable, splitk, nt);
     return S2S_OK;

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     const float* __restrict__ pcm, long pcm_stride, const int* __restrict__ n_samples,
     const float* __restrict__ basis, const float* __restrict__ melw,
     const float* __restrict__ window, int n_bin_tiles, int n_mel_tiles, int mel_ksteps,
-    int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax, int time_major) {
+    int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax, int time_major,
+    int window_samples, const float* __restrict__ norm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* raw = smem;                       // RAW_LDS floats; later reused as the out stage
     float* win = smem + RAW_LDS;             // TAPS
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
 
     const float* x = pcm + (long)b * pcm_stride;
     int n = n_samples[b];
-    if (KIND == S2S_FRONTEND_WHISPER) n = min(n, WHISPER_SAMPLES);
+    if (KIND == S2S_FRONTEND_WHISPER) n = min(n, window_samples);
+    // zero-mean / unit-variance waveform normalisation (the Smart-Turn feature path): {mean, 1 / sqrt(var + 1e-7)} per item
+    const float nmean = norm ? norm[2 * b] : 0.f, nrstd = norm ? norm[2 * b + 1] : 1.f;
 
     // ---- stage the PCM segment ------------------------------------------------
     const int s0 = t0 * HOP - TAPS / 2;
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
         int s = s0 + i;
         float v = 0.f;
         if (KIND == S2S_FRONTEND_WHISPER) {
-            // zero-pad to 30 s, then centre/reflect padding of the padded signal
+            // zero-pad to the window (30 s; 8 s for Smart-Turn), then centre/reflect padding of the padded signal
             if (s < 0) s = -s;
-            else if (s >= WHISPER_SAMPLES) s = 2 * (WHISPER_SAMPLES - 1) - s;
-            if (s < n) v = x[s];
+            else if (s >= window_samples) s = 2 * (window_samples - 1) - s;
+            if (s < n) v = norm ? __fmul_rn(__fsub_rn(x[s], nmean), nrstd) : x[s];
         } else {
             // pre-emphasis on the unpadded signal, zero ("constant") centre padding
             if (s >= 0 && s < n) {
@@ -308,6 +311,46 @@ __global__ void parakeet_normalize_kernel(const float* __restrict__ x, const int
     }
 }
 
+// Waveform statistics of the first min(n_samples, window) samples of every item: {mean, 1 / sqrt(var + 1e-7)} (population variance),
+// what WhisperFeatureExtractor(do_normalize=True) applies before the STFT (feature_extraction_whisper.py zero_mean_unit_var_norm;
+// reference VAD/smart_turn.py:135-143).  One workgroup per item, float64 accumulation, two passes.
+__global__ __launch_bounds__(256) void waveform_stats_kernel(const float* __restrict__ pcm, long pcm_stride, const int* __restrict__ n_samples,
+                                                             int window_samples, float* __restrict__ norm) {
+    __shared__ double red[256];
+    __shared__ double mean_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = pcm + (long)b * pcm_stride;
+    const int n = min(n_samples[b], window_samples);
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)x[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) mean_s = n > 0 ? red[0] / (double)n : 0.0;
+    __syncthreads();
+    const double mean = mean_s;
+    double q = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double d = (double)x[i] - mean;
+        q += d * d;
+    }
+    __syncthreads();
+    red[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double var = n > 0 ? red[0] / (double)n : 0.0;
+        norm[2 * b] = (float)mean;
+        norm[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-7));
+    }
+}
+
 static size_t tile_lds_bytes(const Frontend* f) {
     const size_t pstride = (size_t)f->n_bin_tiles * 16 + 1;
     size_t stage = (size_t)FT * (f->n_mels + 1);
@@ -416,9 +459,48 @@ extern "C" int32_t s2s_logmel_whisper(void* frontend, void* stream, const float*
     dim3 grid(cdiv(WHISPER_FRAMES, FT), B);
     logmel_tile_kernel<S2S_FRONTEND_WHISPER><<<grid, 256, tile_lds_bytes(f), st>>>(
         pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
-        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 0);
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 0, WHISPER_SAMPLES, nullptr);
     S2S_LAUNCH_CHECK();
     const long per_item = (long)f->n_mels * WHISPER_FRAMES;
+    const long total = per_item * B;
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+    if (out_dtype == S2S_F32)
+        whisper_finalize_kernel<float><<<blocks, 256, 0, st>>>(f->scratch, (float*)out_dev, f->wmax, per_item, total);
+    else
+        whisper_finalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(f->scratch, (__hip_bfloat16*)out_dev, f->wmax, per_item, total);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+/* Whisper log-mel of a SHORTER window with optional waveform normalisation - the Smart-Turn end-of-turn feature path
+ * (reference VAD/smart_turn.py:130-143: WhisperFeatureExtractor(chunk_length=8), do_normalize=True, padding to 8 s).
+ * out [B][n_mels][window_samples / 160]; window_samples a multiple of 160, <= 480000. */
+extern "C" int32_t s2s_logmel_whisper_window(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
+                                             const int32_t* n_samples_dev, int32_t B, int32_t window_samples, int32_t normalize,
+                                             void* out_dev, int32_t out_dtype) {
+    Frontend* f = (Frontend*)frontend;
+    S2S_REQUIRE(f && f->kind == S2S_FRONTEND_WHISPER, "not a Whisper front-end");
+    S2S_REQUIRE(B >= 0 && B <= f->max_batch, "batch %d exceeds max_batch %d", B, f->max_batch);
+    S2S_REQUIRE(window_samples >= TAPS && window_samples <= WHISPER_SAMPLES && window_samples % HOP == 0,
+                "window of %d samples unsupported (a multiple of 160 in [400, 480000])", window_samples);
+    S2S_REQUIRE(out_dtype == S2S_F32 || out_dtype == S2S_BF16, "bad out_dtype %d", out_dtype);
+    if (B == 0) return S2S_OK;
+    S2S_REQUIRE(pcm_dev && n_samples_dev && out_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_frames = window_samples / HOP;
+    S2S_HIP_CHECK(hipMemsetAsync(f->wmax, 0, (size_t)B * sizeof(unsigned int), st));
+    float* norm = nullptr;
+    if (normalize) {
+        norm = f->stats;          // [max_batch][2 * n_mels] floats: the first 2 * B hold {mean, rstd}
+        waveform_stats_kernel<<<B, 256, 0, st>>>(pcm_dev, (long)pcm_stride, n_samples_dev, window_samples, norm);
+        S2S_LAUNCH_CHECK();
+    }
+    dim3 grid(cdiv(n_frames, FT), B);
+    logmel_tile_kernel<S2S_FRONTEND_WHISPER><<<grid, 256, tile_lds_bytes(f), st>>>(
+        pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, n_frames, f->scratch, f->wmax, 0, window_samples, norm);
+    S2S_LAUNCH_CHECK();
+    const long per_item = (long)f->n_mels * n_frames;
     const long total = per_item * B;
     const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
     if (out_dtype == S2S_F32)
@@ -443,7 +525,7 @@ extern "C" int32_t s2s_logmel_whisper_tm(void* frontend, void* stream, const flo
     dim3 grid(cdiv(WHISPER_FRAMES, FT), B);
     logmel_tile_kernel<S2S_FRONTEND_WHISPER><<<grid, 256, tile_lds_bytes(f), st>>>(
         pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
-        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 1);
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, WHISPER_FRAMES, f->scratch, f->wmax, 1, WHISPER_SAMPLES, nullptr);
     S2S_LAUNCH_CHECK();
     const long total = (long)B * (WHISPER_FRAMES + 2) * f->n_mels;
     const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
@@ -470,7 +552,7 @@ extern "C" int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float
     dim3 grid(cdiv(t_max, FT), B);
     logmel_tile_kernel<S2S_FRONTEND_PARAKEET><<<grid, 256, tile_lds_bytes(f), st>>>(
         pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
-        f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, f->scratch, nullptr, 1);
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, f->scratch, nullptr, 1, 0, nullptr);
     S2S_LAUNCH_CHECK();
     parakeet_stats_kernel<<<dim3(cdiv(f->n_mels, 32), B), dim3(32, 8), 0, st>>>(
         f->scratch, n_samples_dev, t_max, f->n_mels, f->stats);

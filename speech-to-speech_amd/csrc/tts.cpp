@@ -26,13 +26,18 @@ int kv_append_rows(hipStream_t st, const void* src, long src_rs, int k_off, int 
 int swiglu(hipStream_t st, const void* gu, void* out, long rows, int ffn, int dtype);
 int add_int(hipStream_t st, int* p, int v, int n);
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
-                const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
+                const int* frame_b, const int* min_b, const int* utt_b, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
                 const PickDebug& dbg, const SampleParams& sp);
-int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_b, const int* utt_b, const int* finished, int* codes_out, int max_frames, int G,
               int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg,
               const SampleParams& sp);
-int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B);
+int tts_frame_end(hipStream_t st, int* pos_t, int* frame_b, int* finished, const int* budget_b, int max_pos, int B);
+int tts_slots_set(hipStream_t st, int* pos_t, int* frame_b, int* min_b, int* budget_b, int* utt_b, int* finished, int* n_frames, int* code0,
+                  const int* prompt_len, const int* min_frames, const int* budget, int min_all, int budget_all, int utt0, int max_frames, int slot0,
+                  int n, bool live);
+int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, int F, int* out);
+int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* out);
 int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
                  int dim, int accumulate, const void* addvec, int dtype);
@@ -93,7 +98,10 @@ struct Tts {
     int codec_frames_done = 0;
     int* host_flag = nullptr;
     // decode-frame graph: one captured frame body per batch size, replayed once per frame (all per-frame state lives on the device)
-    int *frame_dev = nullptr, *min_dev = nullptr;
+    // per-SLOT frame state (device): frame index, eos gate threshold, frame budget, utterance id (sampler key).  A slot is one row of
+    // the frame loop; sessions are admitted into / released from slots while the others keep generating (s2s_tts_admit / _release)
+    int *frame_b = nullptr, *min_b = nullptr, *budget_b = nullptr, *utt_b = nullptr;
+    int next_utt = 1;                  // utterance ids handed out by the legacy prefill
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
     std::vector<void*> head_n;         // code-predictor heads, fragment-major with pred.norm folded in (bf16 decode path)
@@ -235,7 +243,7 @@ static int finalize(Tts* m) {
     T(B * E * 4);                              // 10 xnext
     T(B * 2 * E * 4);                          // 11 pin
     T(((B * 2 + 15) / 16 * 16) * E * e);       // 12 pin_t (whole 16-row tiles when fragment-major)
-    T((9 * B + 16) * 4);                       // 13 ints
+    T((12 * B + 32) * 4);                      // 13 ints
     T(B * (size_t)c.max_frames * G * 4);       // 14 codes_out
     T((size_t)c.codec_vocab);                  // 15 sup_mask
     for (Stack* s : {&m->talker, &m->pred, &m->codec}) {   // 16..21 caches
@@ -263,7 +271,8 @@ static int finalize(Tts* m) {
     m->logits = (float*)(b0 + o[9]); m->xnext = (float*)(b0 + o[10]); m->pin = (float*)(b0 + o[11]); m->pin_t = b0 + o[12];
     int* ints = (int*)(b0 + o[13]);
     m->pos_t = ints; m->code0 = ints + 2 * B; m->finished = ints + 3 * B; m->n_frames = ints + 4 * B;
-    m->frame_dev = ints + 7 * B + 1; m->min_dev = ints + 7 * B + 2;   // device-side frame counter / eos gate threshold
+    m->frame_b = ints + 5 * B; m->min_b = ints + 6 * B;               // per-slot frame index / eos gate threshold
+    m->budget_b = ints + 10 * B + 16; m->utt_b = ints + 11 * B + 16;  // per-slot frame budget / utterance id
     m->codes_out = (int*)(b0 + o[14]);
     m->sup_mask = (unsigned char*)(b0 + o[15]);
     m->talker.kc = b0 + o[16]; m->talker.vc = b0 + o[17];
@@ -506,8 +515,8 @@ static int talker_head(Tts* m, hipStream_t st, int B) {
     if ((rc = rmsnorm_ex(st, m->x, E, TPF(m, "talker.norm"), m->hn_t, m->hn, B, E, c.eps, dt))) return rc;
     if ((rc = gemm(st, m->hn_t, E, TP(m, "talker.head.w"), nullptr, nullptr, m->logits, c.codec_vocab, B, c.codec_vocab, E, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
     // x's hidden rows are consumed (hn); the pick writes the next talker input over them
-    return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_dev,
-                       m->min_dev, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
+    return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_b,
+                       m->min_b, m->utt_b, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
                        TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg, m->sp_talker);
 }
 
@@ -559,7 +568,7 @@ static int predictor_frame(Tts* m, hipStream_t st, int B) {
         }
         // dec: logits hold all M rows (row b * T_len + T_len - 1 is session b's); the next pass's input row is written fragment-major
         const bool next_dec = g + 1 < G - 1 && dec_fusion_ok(m, m->pred, B) && P != E;
-        if ((rc = pred_pick(st, dec ? m->logits + (size_t)(T_len - 1) * CB : m->logits, CB, dec ? (long)T_len * CB : (long)CB, m->frame_dev, m->finished, m->codes_out,
+        if ((rc = pred_pick(st, dec ? m->logits + (size_t)(T_len - 1) * CB : m->logits, CB, dec ? (long)T_len * CB : (long)CB, m->frame_b, m->utt_b, m->finished, m->codes_out,
                             c.max_frames, G, g + 1, TP(m, "pred.emb." + std::to_string(g)), m->x, m->pin, m->pin_t, E, next_dec, B, dt, m->dbg, m->sp_pred))) return rc;
     }
     return S2S_OK;
@@ -580,7 +589,7 @@ static int frame_body(Tts* m, hipStream_t st, int B) {
     } else {
         if ((rc = stack_forward(m, st, m->talker, m->x, B, 1, m->pos_t, m->talker.c.max_pos, nullptr))) return rc;
     }
-    return tts_frame_end(st, m->pos_t, m->frame_dev, B);
+    return tts_frame_end(st, m->pos_t, m->frame_b, m->finished, m->budget_b, m->talker.c.max_pos, B);
 }
 
 // captured frame body for batch size B (built on first use; the arena and the weights never move after finalize)
@@ -669,28 +678,115 @@ extern "C" int64_t s2s_tts_workspace_bytes(void* model) {
     return m ? (int64_t)m->arena_bytes : 0;
 }
 
-// Prefill: prompt_embeds_dev f32 [B][Tp][E] (right-padded), prompt_len_dev int32 [B].
+// Admission of n sessions into the slots [slot0, slot0 + n) of the frame loop (the others keep their state): talker prefill of the
+// n prompts straight into those slots' cache rows, then the slots' bookkeeping (position = prompt length, frame 0, eos gate, budget,
+// utterance id) and their first input row (hidden of the last prompt position).  The prefill uses the shared scratch rows m->x, whose
+// first max_batch rows are the frame loop's state: they are parked in m->xnext around it.
+static int tts_admit_impl(Tts* m, hipStream_t st, const float* prompt_embeds_dev, const int32_t* prompt_len_dev, int n, int Tp, int slot0,
+                          const int32_t* min_frames_dev, const int32_t* budget_dev, int min_all, int budget_all, int utt0) {
+    const auto& c = m->cfg;
+    const int E = c.t_hidden, G = c.n_groups, e = m->esz;
+    int rc;
+    S2S_HIP_CHECK(hipMemcpyAsync(m->xnext, m->x, sizeof(float) * (size_t)m->max_batch * E, hipMemcpyDeviceToDevice, st));
+    S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)n * Tp * E, hipMemcpyDeviceToDevice, st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->codes_out + (size_t)slot0 * c.max_frames * G, 0xff, sizeof(int) * (size_t)n * c.max_frames * G, st));
+    // the same stack, its cache rows shifted to the first admitted slot (row b of the prefill batch = slot slot0 + b)
+    Stack pre = m->talker;
+    const size_t slot_bytes = (size_t)pre.c.max_pos * pre.c.kv_heads * pre.c.head_dim * e;
+    pre.kc = at(m->talker.kc, slot0 * slot_bytes);
+    pre.vc = at(m->talker.vc, slot0 * slot_bytes);
+    // padded rows beyond a session's prompt are cached too but never attended: kv_len = prompt_len
+    if ((rc = stack_forward(m, st, pre, m->x, n, Tp, nullptr, Tp, prompt_len_dev))) return rc;
+    last_row_kernel<<<n, 256, 0, st>>>(m->x, prompt_len_dev, Tp, E, m->xnext + (size_t)slot0 * E);
+    S2S_LAUNCH_CHECK();
+    // the frame body always reads the hidden of the last processed position of slot b from x[b]
+    S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)m->max_batch * E, hipMemcpyDeviceToDevice, st));
+    return tts_slots_set(st, m->pos_t, m->frame_b, m->min_b, m->budget_b, m->utt_b, m->finished, m->n_frames, m->code0, prompt_len_dev, min_frames_dev,
+                         budget_dev, min_all, budget_all, utt0, c.max_frames, slot0, n, true);
+}
+
+// Prefill: prompt_embeds_dev f32 [B][Tp][E] (right-padded), prompt_len_dev int32 [B].  Starts a fresh batch in slots 0 .. B-1
+// (every other slot idle).
 extern "C" int32_t s2s_tts_prefill(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev,
                                    int32_t B, int32_t Tp) {
     Tts* m = (Tts*)model;
     S2S_REQUIRE(m && m->finalized, "tts_prefill: model not finalized");
     S2S_REQUIRE(B > 0 && B <= m->max_batch && Tp >= 1 && Tp <= m->cfg.max_prompt && prompt_embeds_dev && prompt_len_dev, "tts_prefill: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const int E = m->cfg.t_hidden;
     int rc;
-    S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)B * Tp * E, hipMemcpyDeviceToDevice, st));
-    S2S_HIP_CHECK(hipMemsetAsync(m->pos_t, 0, sizeof(int) * (8 * (size_t)m->max_batch + 8), st));
-    S2S_HIP_CHECK(hipMemsetAsync(m->codes_out, 0xff, sizeof(int) * (size_t)m->max_batch * m->cfg.max_frames * m->cfg.n_groups, st));
-    // padded rows beyond a session's prompt are cached too but never attended: kv_len = prompt_len
-    if ((rc = stack_forward(m, st, m->talker, m->x, B, Tp, nullptr, Tp, prompt_len_dev))) return rc;
-    S2S_HIP_CHECK(hipMemcpyAsync(m->pos_t, prompt_len_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
-    last_row_kernel<<<B, 256, 0, st>>>(m->x, prompt_len_dev, Tp, E, m->xnext);
-    S2S_LAUNCH_CHECK();
-    // the frame body always reads the hidden of the last processed position from x[0 .. B)
-    S2S_HIP_CHECK(hipMemcpyAsync(m->x, m->xnext, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st));
+    if ((rc = tts_slots_set(st, m->pos_t, m->frame_b, m->min_b, m->budget_b, m->utt_b, m->finished, m->n_frames, m->code0, nullptr, nullptr, nullptr, 0, 0, 0,
+                            m->cfg.max_frames, 0, m->max_batch, false))) return rc;
+    if ((rc = tts_admit_impl(m, st, prompt_embeds_dev, prompt_len_dev, B, Tp, 0, nullptr, nullptr, 0, m->cfg.max_frames, m->next_utt))) return rc;
+    m->next_utt += B;
     m->cur_B = B;
     m->prompt_max = Tp;
     m->frames_done = 0;
+    return S2S_OK;
+}
+
+/* Continuous batching (the reference streams every session independently, TTS/qwen3_tts_handler.py:695-749; here sessions share the
+ * launches of one frame loop and join / leave it at chunk boundaries):
+ *   s2s_tts_admit    n prompts -> slots [slot0, slot0 + n) while the other slots keep generating.  min_frames_dev / budget_dev:
+ *                    optional int32[n] per session (else min_frames / max_new_frames for all); a slot retires itself after
+ *                    budget frames or at eos.  utterance_id0 + i keys session i's sampler stream.
+ *   s2s_tts_step     n_frames frames for the slots [0, rows): every slot advances by its OWN frame index.
+ *   s2s_tts_read_codes   codes of frames [frame0, frame0 + n_frames) of slots [slot0, slot0 + n) -> int32 [n][n_frames][G] (-1 after
+ *                    a session's end), valid frames so far per slot -> n_frames_dev int32[n] (optional).
+ *   s2s_tts_release  slots [slot0, slot0 + n) become idle (their rows are still computed, nothing is emitted). */
+extern "C" int32_t s2s_tts_admit(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev, int32_t n, int32_t Tp,
+                                 int32_t slot0, const int32_t* min_frames_dev, const int32_t* budget_dev, int32_t min_frames, int32_t max_new_frames,
+                                 int32_t utterance_id0) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "tts_admit: model not finalized");
+    S2S_REQUIRE(n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch && Tp >= 1 && Tp <= m->cfg.max_prompt && prompt_embeds_dev && prompt_len_dev,
+                "tts_admit: bad arguments (slots %d..%d of %d, Tp %d)", slot0, slot0 + n, m->max_batch, Tp);
+    S2S_REQUIRE(max_new_frames >= 1 && min_frames >= 0, "tts_admit: bad frame limits");
+    m->cur_B = std::max(m->cur_B, slot0 + n);
+    return tts_admit_impl(m, (hipStream_t)stream, prompt_embeds_dev, prompt_len_dev, n, Tp, slot0, min_frames_dev, budget_dev, min_frames, max_new_frames,
+                          utterance_id0);
+}
+
+extern "C" int32_t s2s_tts_release(void* model, void* stream, int32_t slot0, int32_t n) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && slot0 >= 0 && n >= 0 && slot0 + n <= m->max_batch, "tts_release: bad arguments");
+    return tts_slots_set((hipStream_t)stream, m->pos_t, m->frame_b, m->min_b, m->budget_b, m->utt_b, m->finished, m->n_frames, m->code0, nullptr, nullptr,
+                         nullptr, 0, 0, 0, m->cfg.max_frames, slot0, n, false);
+}
+
+// n_frames passes of the frame body over the slots [0, rows): a captured graph per row count, replayed per frame
+static int tts_step_impl(Tts* m, hipStream_t st, int rows, int n_frames, bool allow_graph) {
+    int rc;
+    hipGraphExec_t exec = nullptr;
+    if (allow_graph && graphs_enabled() && !prof_active() && frame_graph(m, rows, &exec) != S2S_OK) {
+        // the capture was refused or invalidated (HIP aborts a capture when another thread touches the legacy stream): not fatal -
+        // clear the sticky error and run this call as plain stream launches; the next call captures again
+        (void)hipGetLastError();
+        exec = nullptr;
+    }
+    if (exec) {
+        for (int f = 0; f < n_frames; ++f) S2S_HIP_CHECK(hipGraphLaunch(exec, st));
+    } else {
+        for (int f = 0; f < n_frames; ++f)
+            if ((rc = frame_body(m, st, rows))) return rc;
+    }
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_tts_step(void* model, void* stream, int32_t rows, int32_t n_frames) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && rows >= 1 && rows <= m->max_batch && n_frames >= 1, "tts_step: bad arguments");
+    return tts_step_impl(m, (hipStream_t)stream, rows, n_frames, true);
+}
+
+extern "C" int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, int32_t n, int32_t frame0, int32_t n_frames, int32_t* codes_dev,
+                                      int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && slot0 >= 0 && n >= 1 && slot0 + n <= m->max_batch && frame0 >= 0 && n_frames >= 1 && codes_dev, "tts_read_codes: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = tts_read_codes(st, m->codes_out, m->cfg.max_frames, m->cfg.n_groups, slot0, n, frame0, n_frames, codes_dev))) return rc;
+    if (n_frames_dev) S2S_HIP_CHECK(hipMemcpyAsync(n_frames_dev, m->n_frames + slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    if (valid_samples_dev && (rc = tts_valid_samples(st, m->n_frames, slot0, n, frame0, n_frames, m->cfg.total_upsample, chunk_samples, valid_samples_dev))) return rc;
     return S2S_OK;
 }
 
@@ -706,21 +802,9 @@ static int32_t tts_generate_impl(Tts* m, hipStream_t st, int32_t n_frames, int32
     const int B = m->cur_B, G = c.n_groups;
     int rc;
     const int f0 = m->frames_done;
-    fill_int_kernel<<<1, 64, 0, st>>>(m->min_dev, min_total_frames, 1);
+    fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->min_b, min_total_frames, B);
     S2S_LAUNCH_CHECK();
-    hipGraphExec_t exec = nullptr;
-    if (allow_graph && graphs_enabled() && !prof_active() && frame_graph(m, B, &exec) != S2S_OK) {
-        // the capture was refused or invalidated (HIP aborts a capture when another thread touches the legacy stream): not fatal -
-        // clear the sticky error and run this call as plain stream launches; the next call captures again
-        (void)hipGetLastError();
-        exec = nullptr;
-    }
-    if (exec) {
-        for (int f = 0; f < n_frames; ++f) S2S_HIP_CHECK(hipGraphLaunch(exec, st));
-    } else {
-        for (int f = 0; f < n_frames; ++f)
-            if ((rc = frame_body(m, st, B))) return rc;
-    }
+    if ((rc = tts_step_impl(m, st, B, n_frames, allow_graph))) return rc;
     m->frames_done = f0 + n_frames;
     if (codes_dev)
         S2S_HIP_CHECK(hipMemcpy2DAsync(codes_dev, sizeof(int) * n_frames * G, m->codes_out + (size_t)f0 * G, sizeof(int) * c.max_frames * G,
@@ -812,10 +896,15 @@ namespace s2s {
 // are left context whose samples are dropped (the sibling's chunked_decode pattern).  streaming = true: exact causal
 // continuation of the previous call - every convolution's history rows and the transformer's KV cache are carried
 // over, so the concatenated chunks equal one decode of the whole utterance and nothing is recomputed.
-static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F, int ctx, bool streaming, float* wav_dev, int n_samples) {
+// row0 / frames_done_io: the streaming state (history rows, pre-transformer cache) of the batch rows lives in rows [row0, row0 + B) of the
+// engine's codec state and the stream has *frames_done_io frames behind it (updated) - cohorts of sessions admitted at different
+// times stream independently from disjoint row ranges (continuous batching); null: the engine-wide stream of the legacy entry points.
+static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F, int ctx, bool streaming, float* wav_dev, int n_samples, int row0 = 0,
+                     int* frames_done_io = nullptr) {
     const auto& c = m->cfg;
     const int dt = c.dtype, e = m->esz, H = c.c_hidden, G = c.n_groups;
-    const bool first = !streaming || m->codec_frames_done == 0;
+    int& frames_done = frames_done_io ? *frames_done_io : m->codec_frames_done;
+    const bool first = !streaming || frames_done == 0;
     const int saveB = m->cur_B;
     m->cur_B = B;
     int rc;
@@ -827,12 +916,12 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         const int sl = slot++;
         hipError_t er;
         if (first) er = hipMemset2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, 0, (size_t)LPAD * Cn * e, B, st);
-        else er = hipMemcpy2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, m->cstate[sl], (size_t)LPAD * Cn * e, (size_t)LPAD * Cn * e, B, hipMemcpyDeviceToDevice, st);
+        else er = hipMemcpy2DAsync(buf, (size_t)(LPAD + Tn) * Cn * e, at(m->cstate[sl], (size_t)row0 * LPAD * Cn * e), (size_t)LPAD * Cn * e, (size_t)LPAD * Cn * e, B, hipMemcpyDeviceToDevice, st);
         return er == hipSuccess ? sl : fail(S2S_ERR_HIP, "codec history load: %s", hipGetErrorString(er));
     };
     auto hist_save = [&](void* buf, int Tn, int Cn, int sl) -> int {
         if (!streaming) return S2S_OK;
-        hipError_t er = hipMemcpy2DAsync(m->cstate[sl], (size_t)LPAD * Cn * e, at(buf, (size_t)Tn * Cn * e), (size_t)(LPAD + Tn) * Cn * e,
+        hipError_t er = hipMemcpy2DAsync(at(m->cstate[sl], (size_t)row0 * LPAD * Cn * e), (size_t)LPAD * Cn * e, at(buf, (size_t)Tn * Cn * e), (size_t)(LPAD + Tn) * Cn * e,
                                          (size_t)LPAD * Cn * e, B, hipMemcpyDeviceToDevice, st);
         return er == hipSuccess ? S2S_OK : fail(S2S_ERR_HIP, "codec history save: %s", hipGetErrorString(er));
     };
@@ -846,17 +935,23 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
     };
     // code embeddings -> sliding-window transformer (KV cache continues across streamed chunks)
     if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
-    const int f0 = streaming ? m->codec_frames_done : 0;
+    const int f0 = streaming ? frames_done : 0;
     if (streaming) {
         fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->pos_c, f0, B);
         S2S_LAUNCH_CHECK();
     }
-    if (dec_fusion_ok(m, m->codec, B * F)) {
+    Stack cs = m->codec;         // the pre-transformer's cache rows of this row range
+    {
+        const size_t row_bytes = (size_t)cs.c.max_pos * cs.c.kv_heads * cs.c.head_dim * e;
+        cs.kc = at(m->codec.kc, row0 * row_bytes);
+        cs.vc = at(m->codec.vc, row0 * row_bytes);
+    }
+    if (dec_fusion_ok(m, cs, B * F)) {
         if ((rc = rows_prep(st, m->cx, H, m->xb, H, m->ssA, B * F, H, true))) return done(rc);
         m->ss_parts_A = 1;
-        if ((rc = stack_forward_dec(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F))) return done(rc);
+        if ((rc = stack_forward_dec(m, st, cs, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F))) return done(rc);
     } else {
-        if ((rc = stack_forward(m, st, m->codec, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
+        if ((rc = stack_forward(m, st, cs, m->cx, B, F, streaming ? m->pos_c : nullptr, f0 + F, nullptr))) return done(rc);
     }
     stage_ok("transformer", 0, 0);
     if ((rc = rmsnorm(st, m->cx, TPF(m, "codec.norm"), m->h, B * F, H, c.c_eps, dt))) return done(rc);
@@ -978,7 +1073,7 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
     const long skip = (long)ctx * c.total_upsample;
     S2S_REQUIRE(n_samples == T - skip, "codec_decode: n_samples %d != %ld", n_samples, T - skip);
     if ((rc = wav_out(st, tmp, wav_dev, B, T, LPAD, (int)skip, n_samples, dt))) return done(rc);
-    if (streaming) m->codec_frames_done += F;
+    if (streaming) frames_done += F;
     return done(S2S_OK);
 }
 
@@ -1010,6 +1105,20 @@ extern "C" int32_t s2s_codec_stream_decode(void* model, void* stream, const int3
     S2S_REQUIRE(B > 0 && B <= m->max_batch && F >= 1 && F <= m->cfg.max_codec_frames && codes_dev && wav_dev, "codec_stream_decode: bad arguments");
     S2S_REQUIRE(m->codec_frames_done + F <= m->codec.c.max_pos, "codec_stream_decode: %d frames exceed the stream capacity %d", m->codec_frames_done + F, m->codec.c.max_pos);
     return codec_run(m, (hipStream_t)stream, codes_dev, B, F, 0, true, wav_dev, n_samples);
+}
+
+/* Streaming continuation of a COHORT: rows [slot0, slot0 + n) of the engine's codec state, frames_done frames already decoded for
+ * them (0: the stream starts here).  codes_dev int32 [n][F][G]; wav_dev f32 [n][n_samples] with n_samples = s2s_codec_samples(F) for
+ * the first call of a stream and F * total_upsample afterwards.  Cohorts on disjoint row ranges stream independently. */
+extern "C" int32_t s2s_codec_decode_rows(void* model, void* stream, const int32_t* codes_dev, int32_t slot0, int32_t n, int32_t F, int32_t frames_done,
+                                         float* wav_dev, int32_t n_samples) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "codec_decode_rows: model not finalized");
+    S2S_REQUIRE(slot0 >= 0 && n > 0 && slot0 + n <= m->max_batch && F >= 1 && F <= m->cfg.max_codec_frames && frames_done >= 0 && codes_dev && wav_dev,
+                "codec_decode_rows: bad arguments");
+    S2S_REQUIRE(frames_done + F <= m->codec.c.max_pos, "codec_decode_rows: %d frames exceed the stream capacity %d", frames_done + F, m->codec.c.max_pos);
+    int fd = frames_done;
+    return codec_run(m, (hipStream_t)stream, codes_dev, n, F, 0, true, wav_dev, n_samples, slot0, &fd);
 }
 
 extern "C" int64_t s2s_codec_samples(void* model, int32_t F) {

@@ -348,28 +348,33 @@ __device__ int block_sample_256(const float* __restrict__ row, int V, const unsi
 template <typename T>
 __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restrict__ logits, int V, const unsigned char* __restrict__ sup_mask,
                                                           const unsigned char* __restrict__ eos_mask, int eos,
-                                                          const int* __restrict__ frame_dev, const int* __restrict__ min_dev,
+                                                          const int* __restrict__ frame_b, const int* __restrict__ min_b, const int* __restrict__ utt_b,
                                                           int* __restrict__ code0, int* __restrict__ finished, int* __restrict__ n_frames,
                                                           int* __restrict__ codes_out, int max_frames, int G,
                                                           const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
                                                           float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E,
                                                           int pin_frag, PickDebug dbg, SampleParams sp) {
     const int b = blockIdx.x;
-    const int frame = *frame_dev;
+    const int frame = frame_b[b];       // this SLOT's frame index: sessions admitted at different times share the launch
+    const bool gate = frame < min_b[b];
     int code;
-    if (sp.temperature > 0.f)      // seeded sampling; the repetition penalty looks at this session's earlier code-0 picks
-        code = block_sample_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr, codes_out + (long)b * max_frames * G, frame, G, sp,
-                                ((unsigned long long)b << 40) ^ ((unsigned long long)frame << 8));
+    if (sp.temperature > 0.f)      // seeded sampling, keyed on (seed, utterance id, frame): independent of the slot the session landed in;
+                                   // the repetition penalty looks at this session's earlier code-0 picks
+        code = block_sample_256(logits + (long)b * V, V, sup_mask, gate ? eos_mask : nullptr, codes_out + (long)b * max_frames * G, frame, G, sp,
+                                ((unsigned long long)(unsigned)utt_b[b] << 40) ^ ((unsigned long long)frame << 8));
     else
-        code = block_argmax_256(logits + (long)b * V, V, sup_mask, frame < *min_dev ? eos_mask : nullptr);
+        code = block_argmax_256(logits + (long)b * V, V, sup_mask, gate ? eos_mask : nullptr);
     pick_debug(dbg, logits + (long)b * V, V, b, frame, 0, max_frames, G, code);
     if (threadIdx.x == 0) {
         int f = finished[b];
         if (!f && code == eos) f = 1;
         finished[b] = f;
         code0[b] = code;
-        codes_out[((long)b * max_frames + frame) * G] = f ? -1 : code;
-        if (!f) n_frames[b] = frame + 1;
+        // a finished / idle slot writes nothing: its frame index stands on its last frame (codes_out is -1 from the admission on)
+        if (!f) {
+            codes_out[((long)b * max_frames + frame) * G] = code;
+            n_frames[b] = frame + 1;
+        }
     }
     const T* row = emb + (long)code * E;
     for (int i = threadIdx.x; i < E; i += 256) {
@@ -386,20 +391,21 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
 // Code-predictor pick for residual group g (one block per session): code = argmax, stored (or -1 once finished), and its
 // embedding row both accumulated into the next talker input and written as the predictor's next input row.
 template <typename T>
-__global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, long logits_rs, const int* __restrict__ frame_dev,
-                                                        const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
+__global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict__ logits, int V, long logits_rs, const int* __restrict__ frame_b,
+                                                        const int* __restrict__ utt_b, const int* __restrict__ finished, int* __restrict__ codes_out, int max_frames,
                                                         int G, int g, const T* __restrict__ emb, float* __restrict__ xnext,
                                                         float* __restrict__ pin, T* __restrict__ pin_t, int E, int pin_frag, PickDebug dbg,
                                                         SampleParams sp) {
     const int b = blockIdx.x;
+    const int frame = frame_b[b];
     int code;
     if (sp.temperature > 0.f)
         code = block_sample_256(logits + (long)b * logits_rs, V, nullptr, nullptr, nullptr, 0, 0, sp,
-                                ((unsigned long long)b << 40) ^ ((unsigned long long)(*frame_dev) << 8) ^ (unsigned long long)g);
+                                ((unsigned long long)(unsigned)utt_b[b] << 40) ^ ((unsigned long long)frame << 8) ^ (unsigned long long)g);
     else
         code = block_argmax_256(logits + (long)b * logits_rs, V, nullptr, nullptr);
-    pick_debug(dbg, logits + (long)b * logits_rs, V, b, *frame_dev, g, max_frames, G, code);
-    if (threadIdx.x == 0) codes_out[((long)b * max_frames + *frame_dev) * G + g] = finished[b] ? -1 : code;
+    pick_debug(dbg, logits + (long)b * logits_rs, V, b, frame, g, max_frames, G, code);
+    if (threadIdx.x == 0 && !finished[b]) codes_out[((long)b * max_frames + frame) * G + g] = code;
     const T* row = emb + (long)code * E;
     for (int i = threadIdx.x; i < E; i += 256) {
         const float e = Elem<T>::ld(row + i);
@@ -409,38 +415,109 @@ __global__ __launch_bounds__(256) void pred_pick_kernel(const float* __restrict_
     }
 }
 
-__global__ void tts_frame_end_kernel(int* pos_t, int* frame_dev, int B) {
+// End of a frame, per slot: a live slot advances its cache position and frame index and retires itself when its frame budget is
+// used up; a finished / idle slot stands still (its rows keep being computed - the launch geometry is fixed - but its position never
+// leaves the cache and its frame index never leaves codes_out).
+__global__ void tts_frame_end_kernel(int* pos_t, int* frame_b, int* finished, const int* budget_b, int max_pos, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) pos_t[b] += 1;
-    if (b == 0) *frame_dev += 1;
+    if (b >= B || finished[b]) return;
+    pos_t[b] = min(pos_t[b] + 1, max_pos - 1);
+    const int f = frame_b[b] + 1;
+    if (f >= budget_b[b]) finished[b] = 1;      // budget reached: frame_b stays on the last written frame
+    else frame_b[b] = f;
+}
+
+// Slot bookkeeping of the continuous-batching frame loop (admission / release of slots [slot0, slot0 + n)).
+__global__ void tts_slots_set_kernel(int* pos_t, int* frame_b, int* min_b, int* budget_b, int* utt_b, int* finished, int* n_frames, int* code0,
+                                     const int* prompt_len, const int* min_frames, const int* budget, int min_all, int budget_all, int utt0,
+                                     int max_frames, int slot0, int n, int live) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = slot0 + i;
+    if (live) {
+        pos_t[s] = prompt_len[i];
+        frame_b[s] = 0;
+        min_b[s] = min_frames ? min_frames[i] : min_all;
+        budget_b[s] = min(budget ? budget[i] : budget_all, max_frames);
+        utt_b[s] = utt0 + i;
+        finished[s] = 0;
+        n_frames[s] = 0;
+        code0[s] = 0;
+    } else {
+        finished[s] = 1;
+    }
+}
+
+// codes of frames [frame0, frame0 + F) of slots [slot0, slot0 + n): out [n][F][G]
+__global__ void tts_read_codes_kernel(const int* __restrict__ codes_out, int max_frames, int G, int slot0, int frame0, int F, int* __restrict__ out, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % G);
+    const long r = i / G;
+    const int f = (int)(r % F), b = (int)(r / F);
+    const int fr = frame0 + f;
+    out[i] = fr < max_frames ? codes_out[((long)(slot0 + b) * max_frames + fr) * G + g] : -1;
 }
 
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
-                const int* frame_dev, const int* min_dev, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
+                const int* frame_b, const int* min_b, const int* utt_b, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
                 const PickDebug& dbg, const SampleParams& sp) {
     S2S_REQUIRE(sp.temperature <= 0.f || V <= 4096, "talker_pick: sampling supports vocabularies up to 4096 entries");
     const size_t lds = sp.temperature > 0.f ? sizeof(float) * (V + 8) : 0;
-    S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, sup_mask, eos_mask, eos, frame_dev, min_dev, code0, finished, n_frames,
+    S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, sup_mask, eos_mask, eos, frame_b, min_b, utt_b, code0, finished, n_frames,
                                                            codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E,
                                                            pin_frag ? 1 : 0, dbg, sp)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
-int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_dev, const int* finished, int* codes_out, int max_frames, int G,
+int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_b, const int* utt_b, const int* finished, int* codes_out, int max_frames, int G,
               int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg,
               const SampleParams& sp) {
     S2S_REQUIRE(sp.temperature <= 0.f || V <= 4096, "pred_pick: sampling supports vocabularies up to 4096 entries");
     const size_t lds = sp.temperature > 0.f ? sizeof(float) * (V + 8) : 0;
-    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, logits_rs, frame_dev, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
+    S2S_DT(TT, (pred_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, logits_rs, frame_b, utt_b, finished, codes_out, max_frames, G, g, (const TT*)emb, xnext,
                                                          pin, (TT*)pin_t, E, pin_frag ? 1 : 0, dbg, sp)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
-int tts_frame_end(hipStream_t st, int* pos_t, int* frame_dev, int B) {
-    tts_frame_end_kernel<<<cdiv(B, 64), 64, 0, st>>>(pos_t, frame_dev, B);
+int tts_frame_end(hipStream_t st, int* pos_t, int* frame_b, int* finished, const int* budget_b, int max_pos, int B) {
+    tts_frame_end_kernel<<<cdiv(B, 64), 64, 0, st>>>(pos_t, frame_b, finished, budget_b, max_pos, B);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int tts_slots_set(hipStream_t st, int* pos_t, int* frame_b, int* min_b, int* budget_b, int* utt_b, int* finished, int* n_frames, int* code0,
+                  const int* prompt_len, const int* min_frames, const int* budget, int min_all, int budget_all, int utt0, int max_frames, int slot0,
+                  int n, bool live) {
+    if (n <= 0) return S2S_OK;
+    tts_slots_set_kernel<<<cdiv(n, 64), 64, 0, st>>>(pos_t, frame_b, min_b, budget_b, utt_b, finished, n_frames, code0, prompt_len, min_frames, budget,
+                                                     min_all, budget_all, utt0, max_frames, slot0, n, live ? 1 : 0);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// 24 kHz samples of this chunk that belong to VALID frames of each slot: chunk_samples when all F frames are valid, else what the
+// valid frames contribute (a first chunk is shorter than F * up by the codec's left trim)
+__global__ void tts_valid_samples_kernel(const int* __restrict__ n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int valid = min(max(n_frames[slot0 + i] - frame0, 0), F);
+    out[i] = valid >= F ? chunk_samples : max(0, valid * up - (F * up - chunk_samples));
+}
+
+int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* out) {
+    tts_valid_samples_kernel<<<cdiv(n, 64), 64, 0, st>>>(n_frames, slot0, n, frame0, F, up, chunk_samples, out);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, int F, int* out) {
+    const long total = (long)n * F * G;
+    if (total <= 0) return S2S_OK;
+    tts_read_codes_kernel<<<(unsigned)cdiv(total, 256), 256, 0, st>>>(codes_out, max_frames, G, slot0, frame0, F, out, total);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

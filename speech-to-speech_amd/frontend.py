@@ -112,6 +112,20 @@ class LogMelFrontend:
             )
         return out
 
+    def whisper_window(self, pcm: torch.Tensor, n_samples: torch.Tensor, window_samples: int, normalize: bool = False,
+                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """Features of a shorter window (Smart-Turn: 8 s, normalised waveform) -> [B, n_mels, window_samples // 160]."""
+        assert self.kind == "whisper"
+        B = pcm.shape[0]
+        out = torch.empty((B, self.n_mels, int(window_samples) // HOP), dtype=out_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(
+                self._lib.s2s_logmel_whisper_window(self._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0), native.ptr(n_samples), B,
+                                                    int(window_samples), int(bool(normalize)), native.ptr(out), native.dtype_code(out_dtype)),
+                "s2s_logmel_whisper_window",
+            )
+        return out
+
     def parakeet(self, pcm: torch.Tensor, n_samples: torch.Tensor, t_max: int,
                  out_dtype: torch.dtype = torch.float32):
         """-> (features [B, t_max, n_mels] zero beyond valid frames, n_frames int32 [B])."""

@@ -75,6 +75,7 @@ _SIGNATURES = {
                         _vp, _i64, _vp, _i32, _i32, _i32],
     "s2s_op_gemm_dec_parts": [_i32, _i32, _i32, _i32, _i32],
     "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
+    "s2s_op_gemm_dec_debug": [_vp],
     "s2s_op_rows_prep": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32],
     "s2s_op_to_frag": [_vp, _vp, _i64, _vp, _vp, _i32, _i32],
     "s2s_graph_bench_begin": [C.POINTER(_vp)],
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "s2s_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_logmel_whisper_tm": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
+    "s2s_logmel_whisper_window": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32],
     "s2s_op_conv1d_tm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "s2s_op_conv1d_causal_tm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "s2s_op_attention": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
@@ -109,6 +111,10 @@ _SIGNATURES = {
     "s2s_tts_workspace_bytes": [_vp],
     "s2s_tts_prefill": [_vp, _vp, _vp, _vp, _i32, _i32],
     "s2s_tts_generate": [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_i32)],
+    "s2s_tts_admit": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32],
+    "s2s_tts_step": [_vp, _vp, _i32, _i32],
+    "s2s_tts_read_codes": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
+    "s2s_tts_release": [_vp, _vp, _i32, _i32],
     "s2s_op_sample_tokens": [_vp, _vp, _i32, _i32, _f32, _i32, _f32, _f32, C.c_uint64, _vp, _i32, _vp],
     "s2s_tts_set_sampling": [_vp, _i32, _f32, _i32, _f32, _f32, C.c_uint64],
     "s2s_tts_generate_forced": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
@@ -116,6 +122,7 @@ _SIGNATURES = {
     "s2s_codec_samples": [_vp, _i32],
     "s2s_codec_stream_reset": [_vp],
     "s2s_codec_stream_decode": [_vp, _vp, _vp, _i32, _i32, _vp, _i32],
+    "s2s_codec_decode_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32],
     "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_resample_poly_int16": [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

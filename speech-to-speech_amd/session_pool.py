@@ -79,8 +79,11 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1):
         self.device = device
+        self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
+        self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
+        self._lane_live: dict[int, int] = {}     # live sessions per continuous lane (load balancing between lanes)
         self.tts_lanes = max(1, int(tts_lanes))
         self.max_batch = int(max_batch)
         self.batch_window_s = batch_window_ms * 1e-3
@@ -93,7 +96,8 @@ class SessionPool:
         self._wake = threading.Event()
         self._engine_lock = threading.Lock()
         self._building: dict[str, Future] = {}
-        self.stats = {"stt_batches": 0, "stt_requests": 0, "tts_batches": 0, "tts_requests": 0, "max_stt_batch": 0, "tts_lanes_used": 0}
+        self.stats = {"stt_batches": 0, "stt_requests": 0, "tts_batches": 0, "tts_requests": 0, "max_stt_batch": 0, "tts_lanes_used": 0,
+                      "stt_busy_s": 0.0, "tts_rounds": 0, "tts_round_s": 0.0, "tts_admit_s": 0.0, "tts_row_rounds": {}}
         self._stats_lock = threading.Lock()
         self._thread = threading.Thread(target=self._run, name=f"s2s-pool-{device}", daemon=True)
         self._lanes: list[threading.Thread] = []
@@ -101,6 +105,12 @@ class SessionPool:
         self._warm_requested = False
         self._stopping = False
         self._thread.start()
+        # extra STT workers (thread + HIP stream + engine replica each): final-STT batches of different workers overlap on the device, which
+        # halves the queueing in front of every session's first audio when one worker is saturated (bench.py open-loop probe)
+        self.stt_workers = max(1, int(stt_workers))
+        self._stt_extra = [threading.Thread(target=self._run_stt_extra, args=(k,), name=f"s2s-pool-{device}-stt{k}", daemon=True) for k in range(1, self.stt_workers)]
+        for t in self._stt_extra:
+            t.start()
         self._ensure_lanes(self.tts_lanes)
 
     def _ensure_lanes(self, n: int) -> None:
@@ -203,7 +213,7 @@ class SessionPool:
             self._tts_q.put(_STOP)
         self._wake.set()
         self._thread.join(timeout=10)
-        for t in self._lanes:
+        for t in self._stt_extra + self._lanes:
             t.join(timeout=10)
         self._fail_pending()
         for e in (list(self._engines.values()) if close_engines else []) + self._lane_replicas:
@@ -226,7 +236,7 @@ class SessionPool:
         """STT worker (also builds the engines, so that model loading stays on one thread).  Like the TTS lanes it issues all its GPU
         work - including the host-to-device copies of the utterances - on its own HIP stream: anything on the legacy default stream
         would collide with (and poison) a lane's stream capture."""
-        ctx = self._lane_stream_ctx()
+        ctx = self._lane_stream_ctx(self.stt_priority)
         ctx.__enter__()
         while True:
             try:
@@ -260,6 +270,42 @@ class SessionPool:
             if self._stopping and self._stt_q.empty():
                 return
 
+    def _run_stt_extra(self, k: int) -> None:
+        """STT worker k > 0: same batching as the first worker, on replicas that share the engines' weights.  Engine builds, and requests for
+        engines that cannot be replicated, stay with the first worker."""
+        ctx = self._lane_stream_ctx(self.stt_priority)
+        ctx.__enter__()
+        replicas: dict[str, Any] = {}
+        while not self._stopping:
+            try:
+                first = self._stt_q.get(timeout=0.05)
+            except queue.Empty:
+                continue
+            if not isinstance(first, _STTRequest) or not hasattr(self._engines.get(first.model), "replica"):
+                self._stt_q.put(first)               # builds / stop / non-replicable engines: the first worker's
+                if first is _STOP:
+                    return
+                time.sleep(0.002)
+                continue
+            if self.batch_window_s > 0:
+                time.sleep(self.batch_window_s)
+            model = first.model
+            try:
+                if model not in replicas:
+                    replicas[model] = self._engines[model].replica()
+                    self._lane_replicas.append(replicas[model])
+            except BaseException as e:  # noqa: BLE001
+                logger.error("STT worker %d could not build its %s replica: %s", k, model, e, exc_info=True)
+                self._stt_q.put(first)
+                return
+            eng = replicas[model]
+            reqs, back = [first], []
+            for it in self._drain(self._stt_q, int(getattr(eng, "max_batch", self.max_batch)) - 1):
+                (reqs if isinstance(it, _STTRequest) and it.model == model else back).append(it)
+            for it in back:
+                self._stt_q.put(it)
+            self._run_stt(reqs, model, eng)
+
     def _lane_engine(self, lane: int) -> Any:
         """Lane 0 streams on the pool's TTS engine; further lanes on replicas that share its weights (built on first use,
         on the lane's own thread).  An engine without ``replica()`` (a test double) is served by lane 0 only."""
@@ -272,7 +318,7 @@ class SessionPool:
         self._lane_replicas.append(rep)
         return rep
 
-    def _lane_stream_ctx(self):
+    def _lane_stream_ctx(self, priority: int = 0):
         """Every lane issues its GPU work on its own HIP stream (no-op for devices torch does not know, e.g. test doubles)."""
         import contextlib
 
@@ -284,7 +330,7 @@ class SessionPool:
                 torch.cuda.set_device(dev)
                 # (no device-wide synchronise here: it would collide with another lane's stream capture; the worker that builds an
                 # engine synchronises ITS stream before the build is reported done)
-                return torch.cuda.stream(torch.cuda.Stream(device=dev))
+                return torch.cuda.stream(torch.cuda.Stream(device=dev, priority=priority))
         except Exception:  # noqa: BLE001
             pass
         return contextlib.nullcontext()
@@ -319,6 +365,65 @@ class SessionPool:
                 logger.error("TTS lane %d warm-up failed: %s", lane, e, exc_info=True)
         return eng, ctx
 
+    def _run_tts_lane_continuous(self, lane: int, eng: Any, first: Any, ready: threading.Event | None = None) -> None:
+        """One lane as a continuously batched engine: at every chunk boundary finished sessions leave, queued requests are prefilled into
+        free slots, and the frame loop goes on for everybody (speech-to-speech_amd/tts_continuous.py).  Several lanes share the request
+        queue; a busy lane only takes new requests while it is among the least loaded ones, idle lanes block on the queue."""
+        from .tts_continuous import ROW_BUCKETS, ContinuousTTS
+
+        cb = ContinuousTTS(eng, chunk_size=self.tts_chunk_size)
+        for r in [r for r in ROW_BUCKETS if r <= cb.cap] or [cb.cap]:
+            eng.step(r, 1)                       # captures the frame graph of every row count while all slots are idle
+        self._sync_current_stream()
+        if ready is not None:
+            ready.set()
+        backlog: list = [first] if first is not None else []
+        stop = False
+        while True:
+            self._lane_live[lane] = cb.live + len(backlog)
+            if not cb.cohorts and not backlog:
+                if stop or self._stopping:
+                    return
+                try:
+                    it = self._tts_q.get(timeout=0.05)
+                except queue.Empty:
+                    continue
+                if it is _STOP:
+                    return
+                backlog.append(it)
+                if self.batch_window_s > 0:
+                    time.sleep(self.batch_window_s)
+            others = [v for k, v in self._lane_live.items() if k != lane]
+            room = cb.free_slots - len(backlog)
+            if room > 0 and not stop and (not others or cb.live + len(backlog) <= min(others) + 8):
+                for it in self._drain(self._tts_q, room):
+                    if it is _STOP:
+                        stop = True
+                        break
+                    backlog.append(it)
+            try:
+                n0 = len(backlog)
+                t_a = time.perf_counter()
+                backlog = cb.admit(backlog)
+                t_r = time.perf_counter()
+                rows = cb.rows()
+                for job, chunk in cb.step():
+                    if chunk is None or not job.cancelled.is_set():
+                        job.chunks.put(chunk)
+                with self._stats_lock:
+                    if n0 > len(backlog):
+                        self.stats["tts_batches"] += 1
+                        self.stats["tts_requests"] += n0 - len(backlog)
+                        self.stats["tts_admit_s"] += t_r - t_a
+                    self.stats["tts_rounds"] += 1
+                    self.stats["tts_round_s"] += time.perf_counter() - t_r
+                    self.stats["tts_row_rounds"][rows] = self.stats["tts_row_rounds"].get(rows, 0) + 1
+            except BaseException as e:  # noqa: BLE001
+                logger.error("TTS lane %d failed: %s", lane, e, exc_info=True)
+                for job in cb.abort() + backlog:
+                    job.chunks.put(e)
+                backlog = []
+
     def _run_tts_lane(self, lane: int) -> None:
         eng, ctx = None, None
         while True:
@@ -329,6 +434,9 @@ class SessionPool:
                     return
                 if self._warm_requested and eng is None and "tts" in self._engines and not self._lane_ready[lane].is_set():
                     eng, ctx = self._lane_start(lane, warm=True)
+                    if eng is not None and self.continuous and hasattr(eng, "admit"):
+                        self._run_tts_lane_continuous(lane, eng, None, self._lane_ready[lane])
+                        return
                     self._lane_ready[lane].set()
                     if eng is None and lane > 0:
                         return                       # no replica possible: lane 0 serves everything
@@ -341,6 +449,9 @@ class SessionPool:
                 if eng is None:                      # hand the request back to the lanes that have an engine and retire
                     self._tts_q.put(first)
                     return
+            if self.continuous and hasattr(eng, "admit"):
+                self._run_tts_lane_continuous(lane, eng, first)
+                return
             if self.batch_window_s > 0:
                 time.sleep(self.batch_window_s)
             drained = self._drain(self._tts_q, min(self.max_batch, int(getattr(eng, "max_batch", self.max_batch))) - 1)
@@ -370,7 +481,7 @@ class SessionPool:
                 for r in batch:
                     r.chunks.put(e)
 
-    def _run_stt(self, reqs: list[_STTRequest], model: str) -> None:
+    def _run_stt(self, reqs: list[_STTRequest], model: str, engine: Any = None) -> None:
         if not reqs:
             return
         with self._stats_lock:
@@ -378,7 +489,10 @@ class SessionPool:
             self.stats["stt_requests"] += len(reqs)
             self.stats["max_stt_batch"] = max(self.stats["max_stt_batch"], len(reqs))
         try:
-            results = self._engines[model].transcribe_batch([r.audio for r in reqs], [r.options for r in reqs])
+            t_b = time.perf_counter()
+            results = (engine or self._engines[model]).transcribe_batch([r.audio for r in reqs], [r.options for r in reqs])
+            with self._stats_lock:
+                self.stats["stt_busy_s"] += time.perf_counter() - t_b
             for r, res in zip(reqs, results):
                 r.future.set_result(res)
         except BaseException as e:  # noqa: BLE001

@@ -1,0 +1,116 @@
+"""Smart-Turn end-of-turn check: the feature half on the GPU, batched over sessions.
+
+The reference runs, per turn and per session, ``WhisperFeatureExtractor(chunk_length=8)(audio, do_normalize=True, ...)`` on
+the host and feeds the [1, 80, 800] features to an ONNX classifier (VAD/smart_turn.py:130-153); that call sits between the
+end of speech and the start of STT, i.e. directly in time-to-first-audio.  Here the last 8 s of every session that just hit
+a speech-to-silence boundary are packed into one batch and go through the same log-mel kernel the Whisper encoder uses
+(csrc/logmel.hip, 800-frame window, waveform normalisation fused into the PCM staging).  The ONNX classifier and Silero
+itself stay on the host (north_star); no onnxruntime and no model file exist offline, so ``classifier`` is injected: any
+callable mapping float32 [B, 80, 800] features to B probabilities.  ``MI355XSmartTurnAnalyzer`` keeps the reference
+analyzer's ``predict()`` signature and result type so `VADHandler` can hold it in place of `SmartTurnAnalyzer`.
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+
+from .frontend import LogMelFrontend
+
+MODEL_SAMPLE_RATE = 16000        # VAD/smart_turn.py:22-23
+MAX_AUDIO_SECONDS = 8
+MAX_SAMPLES = MODEL_SAMPLE_RATE * MAX_AUDIO_SECONDS
+N_MELS = 80                      # WhisperFeatureExtractor's default feature_size
+
+
+@dataclass(frozen=True)
+class SmartTurnResult:
+    """Same fields as the reference's result record (VAD/smart_turn.py:27-33)."""
+
+    complete: bool
+    probability: float
+    inference_ms: float
+
+
+def prepare_audio(audio_array: np.ndarray, sample_rate: int = MODEL_SAMPLE_RATE) -> np.ndarray:
+    """Mono float32 at 16 kHz, exactly 8 s: the LAST 8 s of longer audio, zeros in FRONT of shorter audio (VAD/smart_turn.py:103-128)."""
+    audio = np.asarray(audio_array, dtype=np.float32)
+    if audio.ndim != 1:
+        raise ValueError(f"Smart Turn expects mono 1-D audio, got shape {audio.shape}")
+    if sample_rate <= 0:
+        raise ValueError(f"Smart Turn sample rate must be positive, got {sample_rate}")
+    if sample_rate != MODEL_SAMPLE_RATE:
+        from math import gcd
+
+        from scipy.signal import resample_poly
+
+        g = gcd(sample_rate, MODEL_SAMPLE_RATE)
+        audio = resample_poly(audio, MODEL_SAMPLE_RATE // g, sample_rate // g).astype(np.float32, copy=False)
+    if audio.size > MAX_SAMPLES:
+        audio = audio[-MAX_SAMPLES:]
+    elif audio.size < MAX_SAMPLES:
+        audio = np.pad(audio, (MAX_SAMPLES - audio.size, 0), mode="constant")
+    return audio
+
+
+class SmartTurnFeatures:
+    """Batched Smart-Turn input features on one GPU: list of utterances -> float32 [B, 80, 800] (device tensor)."""
+
+    def __init__(self, max_batch: int = 64, device: str | torch.device = "cuda:0"):
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self.frontend = LogMelFrontend("whisper", N_MELS, max_batch=self.max_batch, device=self.device)
+        self._host = torch.zeros((self.max_batch, MAX_SAMPLES), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        self._n = torch.full((self.max_batch,), MAX_SAMPLES, dtype=torch.int32, device=self.device)
+
+    def close(self) -> None:
+        self.frontend.close()
+
+    def __call__(self, audios: Sequence[np.ndarray], sample_rate: int = MODEL_SAMPLE_RATE) -> torch.Tensor:
+        B = len(audios)
+        if B == 0:
+            return torch.empty((0, N_MELS, MAX_SAMPLES // 160), dtype=torch.float32, device=self.device)
+        if B > self.max_batch:
+            return torch.cat([self(audios[i:i + self.max_batch], sample_rate) for i in range(0, B, self.max_batch)])
+        for i, a in enumerate(audios):
+            self._host[i] = torch.from_numpy(prepare_audio(a, sample_rate))
+        pcm = self._host[:B].to(self.device, non_blocking=True)
+        return self.frontend.whisper_window(pcm, self._n[:B], MAX_SAMPLES, normalize=True)
+
+
+class MI355XSmartTurnAnalyzer:
+    """`SmartTurnAnalyzer` with the feature extraction on the GPU.  `classifier(features[B, 80, 800] float32 numpy) -> B
+    probabilities` is the host-side ONNX session of the reference (`lambda f: session.run(None, {name: f})[0]`)."""
+
+    def __init__(self, classifier: Callable[[np.ndarray], np.ndarray], *, threshold: float = 0.5, max_batch: int = 64,
+                 device: str | torch.device = "cuda:0", warmup: bool = True) -> None:
+        if not 0.0 <= threshold <= 1.0:
+            raise ValueError(f"Smart Turn threshold must be between 0 and 1, got {threshold}")
+        self.threshold = threshold
+        self.classifier = classifier
+        self.features = SmartTurnFeatures(max_batch=max_batch, device=device)
+        if warmup:
+            self.predict(np.zeros(MODEL_SAMPLE_RATE, dtype=np.float32))
+
+    def predict_batch(self, audios: Sequence[np.ndarray], *, sample_rate: int = MODEL_SAMPLE_RATE) -> list[SmartTurnResult]:
+        """One classifier decision per utterance; the sessions that reached a speech-to-silence boundary in the same tick share one launch."""
+        started_at = time.perf_counter()
+        feats = self.features(audios, sample_rate).cpu().numpy()
+        probs = np.asarray(self.classifier(feats), dtype=np.float64).reshape(-1)
+        if probs.size != len(audios):
+            raise RuntimeError(f"Smart Turn classifier returned {probs.size} values for {len(audios)} utterances")
+        ms = (time.perf_counter() - started_at) * 1000
+        out = []
+        for p in probs:
+            if not np.isfinite(p):
+                raise RuntimeError(f"Smart Turn returned a non-finite probability: {p}")
+            out.append(SmartTurnResult(complete=bool(p > self.threshold), probability=float(p), inference_ms=ms))
+        return out
+
+    def predict(self, audio_array: np.ndarray, *, sample_rate: int = MODEL_SAMPLE_RATE) -> SmartTurnResult:
+        """Return whether ``audio_array`` sounds like a completed user turn (VAD/smart_turn.py:130-153)."""
+        return self.predict_batch([audio_array], sample_rate=sample_rate)[0]

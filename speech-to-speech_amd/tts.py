@@ -376,6 +376,73 @@ class TTSEngine:
                                                     native.ptr(nfr), C.byref(done) if check_done else None), "s2s_tts_generate")
         return codes, nfr, bool(done.value)
 
+    # ---- continuous batching: slots of the frame loop (csrc/tts.cpp s2s_tts_admit / _step / _read_codes / _release) -------------
+    def admit(self, prompts: Sequence[TTSPrompt], slot0: int, max_new_tokens: Sequence[int] | int, min_frames: Sequence[int] | int = 0,
+              utterance_id0: int = 0) -> None:
+        """Prefill `prompts` into the slots [slot0, slot0 + len(prompts)) while the other slots keep their state."""
+        n = len(prompts)
+        lens = [p.embeds.shape[0] for p in prompts]
+        Tp = max(lens)
+        # one pinned staging block per engine, allocated on first use (a pinned allocation synchronises the device: never while serving)
+        if getattr(self, "_admit_host", None) is None:
+            self._admit_host = torch.zeros((self.max_batch * self.max_prompt * self.dims.t_hidden,), dtype=torch.float32, pin_memory=True)
+            self._admit_ints = torch.zeros((3, self.max_batch), dtype=torch.int32, pin_memory=True)
+        torch.cuda.current_stream(self.device).synchronize()      # the previous admission's copies out of the staging block are done
+        host = self._admit_host[: n * Tp * self.dims.t_hidden].view(n, Tp, self.dims.t_hidden)
+        host.zero_()
+        for i, p in enumerate(prompts):
+            host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(p.embeds, dtype=np.float32))
+        emb = host.to(self.device, non_blocking=True)
+        ints = self._admit_ints
+        ints[0, :n] = torch.tensor(lens, dtype=torch.int32)
+        ln = ints[0, :n].to(self.device, non_blocking=True)
+
+        def per(row, v):
+            if isinstance(v, int):
+                return None
+            ints[row, :n] = torch.tensor([int(x) for x in v], dtype=torch.int32)
+            return ints[row, :n].to(self.device, non_blocking=True)
+
+        mn, bd = per(1, min_frames), per(2, max_new_tokens)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_admit(self._h, native.stream_handle(), native.ptr(emb), native.ptr(ln), n, Tp, int(slot0), native.ptr(mn), native.ptr(bd),
+                                                 int(min_frames) if mn is None else 0, int(max_new_tokens) if bd is None else self.max_frames,
+                                                 int(utterance_id0)), "s2s_tts_admit")
+        self._B = max(self._B, slot0 + n)
+        self._keep_admit = (emb, ln, mn, bd)
+
+    def step(self, rows: int, n_frames: int) -> None:
+        """n_frames frames for the slots [0, rows): every live slot advances by its own frame index."""
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_step(self._h, native.stream_handle(), int(rows), int(n_frames)), "s2s_tts_step")
+
+    def read_codes(self, slot0: int, n: int, frame0: int, n_frames: int):
+        """-> (codes int32 [n][n_frames][G], valid frames so far int32 [n], valid 24 kHz samples of this chunk int32 [n]) of the slots
+        [slot0, slot0 + n), all on the GPU."""
+        codes = torch.empty((n, n_frames, self.dims.n_groups), dtype=torch.int32, device=self.device)
+        nfr = torch.empty((n,), dtype=torch.int32, device=self.device)
+        nvalid = torch.empty((n,), dtype=torch.int32, device=self.device)
+        chunk_samples = self.codec_samples(n_frames) if frame0 == 0 else n_frames * self.dims.total_upsample
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_read_codes(self._h, native.stream_handle(), int(slot0), int(n), int(frame0), int(n_frames), native.ptr(codes),
+                                                      native.ptr(nfr), int(chunk_samples), native.ptr(nvalid)), "s2s_tts_read_codes")
+        return codes, nfr, nvalid
+
+    def release(self, slot0: int, n: int) -> None:
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_release(self._h, native.stream_handle(), int(slot0), int(n)), "s2s_tts_release")
+
+    def codec_decode_rows(self, codes: torch.Tensor, slot0: int, frames_done: int) -> torch.Tensor:
+        """Streaming codec continuation of the cohort in slots [slot0, slot0 + B): codes int32 [B][F][G], `frames_done` frames already decoded."""
+        B, F, _ = codes.shape
+        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        n = self.codec_samples(F) if frames_done == 0 else F * self.dims.total_upsample
+        wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_codec_decode_rows(self._h, native.stream_handle(), native.ptr(codes), int(slot0), B, F, int(frames_done), native.ptr(wav), n),
+                         "s2s_codec_decode_rows")
+        return wav
+
     def generate_forced(self, forced_codes: torch.Tensor, min_total_frames: int = 0, want_logits: bool = True):
         """Teacher-forced frames: forced_codes int32 [B][n][G] (entries < 0 keep the greedy pick).  -> (emitted codes int32
         [B][n][G], logits float32 [B][n][G][V] with V = max(codec_vocab, codebook); group 0 rows hold codec_vocab values)."""
@@ -465,7 +532,7 @@ class TTSEngine:
             nfr_h = nfr.cpu().numpy()
             if ctx_frames < 0:
                 raise ValueError("ctx_frames must be >= 0")
-            wav = self.codec_stream_decode(codes.clamp(min=0).contiguous())     # exact causal streaming: nothing is recomputed
+            wav = self.codec_stream_decode(codes)     # exact causal streaming: nothing is recomputed (codes < 0 after a session's end embed as code 0 in the kernel)
             pcm16 = self.resample_int16(wav).cpu().numpy()
             out: list[np.ndarray | None] = []
             for b in range(B):

@@ -156,6 +156,11 @@ class WhisperEngine:
         dev = torch.device(device)
         return cls(dims, None, dtype, max_batch, dev, engine_tensors=random_engine_tensors(dims, dtype, dev, seed))
 
+    def replica(self, max_batch: int | None = None) -> "WhisperEngine":
+        """A second engine instance on the same GPU sharing this one's weight tensors (no copy); it owns only its workspace (activations,
+        self / cross KV caches, decode graphs) and front-end - one per extra STT worker of the session pool."""
+        return WhisperEngine(self.dims, None, self.dtype, int(max_batch or self.max_batch), self.device, engine_tensors=self._weights)
+
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.s2s_whisper_workspace_bytes(self._h))

@@ -54,6 +54,31 @@ def make_logmel():
     print("logmel.npz written")
 
 
+def make_smart_turn():
+    """Smart-Turn input features exactly as reference VAD/smart_turn.py:130-143 builds them: last 8 s / left padding, then
+    WhisperFeatureExtractor(chunk_length=8)(..., padding="max_length", max_length=128000, truncation=True, do_normalize=True)."""
+    from transformers import WhisperFeatureExtractor
+
+    from oracle.logmel import smart_turn_prepare_audio
+
+    fe = WhisperFeatureExtractor(chunk_length=8)
+    out = {}
+    lens = [40000, 128000 + 7777, 16000]
+    for i, n in enumerate(lens):
+        x = synth_audio(n, session_idx=200 + i)
+        if i == 2:
+            x = x * 0.01 + 0.05          # quiet, with a DC offset: the normalisation matters
+        a = smart_turn_prepare_audio(x)
+        f = fe(a, sampling_rate=16000, return_tensors="np", padding="max_length", max_length=128000, truncation=True, do_normalize=True).input_features[0]
+        assert f.shape == (80, 800)
+        out[f"feat_{i}"] = f[:, ::4].astype(np.float32)              # every 4th frame (size) ...
+        out[f"tail_{i}"] = f[:, -64:].astype(np.float32)             # ... plus the dense tail, where the speech ends
+        out[f"sum_{i}"] = np.float64(f.astype(np.float64).sum())
+    out["lens"] = np.asarray(lens, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "smart_turn.npz"), **out)
+    print("smart_turn.npz written")
+
+
 WHISPER_TEST = dict(eos=319, sot=300, lang_ids=[301, 302, 303, 304], transcribe=305, notimestamps=306,
                     suppress=[1, 2, 7, 300, 301, 302, 303, 304, 305, 306], begin_suppress=[220, 319], max_new=12,
                     seed=3, gain=2.0, pos_std=2.0)
@@ -205,7 +230,7 @@ def make_qwen3_tts():
     print("qwen3_tts_tiny.npz written", {k: v.shape for k, v in out.items()}, float(np.abs(out["c2w_wav"]).mean()))
 
 
-SECTIONS = {"logmel": make_logmel, "whisper": make_whisper, "parakeet": make_parakeet, "qwen3_tts": make_qwen3_tts}
+SECTIONS = {"logmel": make_logmel, "smart_turn": make_smart_turn, "whisper": make_whisper, "parakeet": make_parakeet, "qwen3_tts": make_qwen3_tts}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)

@@ -60,3 +60,49 @@ def test_parakeet_logmel_matches_oracle():
         worst = max(worst, _report(f"parakeet[n={lens[i]}]", out[i], ref))
     assert worst < PARAKEET_ATOL
     fe.close()
+
+
+def test_smart_turn_features_match_oracle_and_golden(golden_dir):
+    """The Smart-Turn feature path (reference VAD/smart_turn.py:130-143) on the device: last 8 s / left padding on the host, waveform
+    normalisation + 800-frame Whisper log-mel in the kernels; vs the float64 oracle and vs the WhisperFeatureExtractor fixture."""
+    import os
+
+    from speech_to_speech_amd.smart_turn import MI355XSmartTurnAnalyzer, SmartTurnFeatures
+
+    gold = np.load(os.path.join(golden_dir, "smart_turn.npz"))
+    lens = [int(n) for n in gold["lens"]] + [0, 1, 127999, 300000]
+    audios = []
+    for i, n in enumerate(lens):
+        x = synth_audio(n, session_idx=200 + i)
+        audios.append(x * 0.01 + 0.05 if i == 2 else x)
+    st = SmartTurnFeatures(max_batch=4, device="cuda:0")              # 7 utterances through batches of 4
+    out = st(audios).cpu().numpy()
+    assert out.shape == (len(lens), 80, 800)
+    worst = 0.0
+    for i, a in enumerate(audios):
+        ref = O.whisper_logmel_window(O.smart_turn_prepare_audio(a), 80, 128000, normalize=True)
+        worst = max(worst, _report(f"smart_turn[n={lens[i]}]", out[i], ref))
+    assert worst < 3e-4
+    for i in range(3):
+        assert np.abs(out[i][:, ::4] - gold[f"feat_{i}"]).max() < 3e-4 and np.abs(out[i][:, -64:] - gold[f"tail_{i}"]).max() < 3e-4
+    st.close()
+    # the un-normalised short window agrees with the 30 s path on the frames both cover, when the clip's maximum is in the window
+    fe = LogMelFrontend("whisper", 128, max_batch=2, device="cuda:0")
+    a = synth_audio(100000, 3)
+    pcm, ns = pack_pcm([a], torch.device("cuda:0"))
+    short = fe.whisper_window(pcm, ns, 128000).cpu().numpy()[0]
+    np.testing.assert_allclose(short, O.whisper_logmel_window(a, 128, 128000), atol=WHISPER_ATOL)
+    fe.close()
+    # analyzer: the reference's predict() contract with an injected host classifier
+    seen = []
+
+    def classifier(f):
+        seen.append(f.shape)
+        return f.mean(axis=(1, 2)) * 0 + np.linspace(0.2, 0.9, f.shape[0])
+
+    an = MI355XSmartTurnAnalyzer(classifier, threshold=0.5, max_batch=4, warmup=True)
+    res = an.predict_batch(audios[:3])
+    assert [r.complete for r in res] == [False, True, True] and seen[-1] == (3, 80, 800) and seen[0] == (1, 80, 800)
+    one = an.predict(audios[0])
+    assert one.complete is False and abs(one.probability - 0.2) < 1e-9 and one.inference_ms > 0
+    an.features.close()

@@ -58,3 +58,42 @@ def test_product_filter_bank_equals_oracle():
         b = O.mel_filter_bank_slaney(nb, nm, fmax=fmax)
         assert a.dtype == np.float32 and a.shape == (nb, nm)
         np.testing.assert_allclose(a, b, atol=1e-9)
+
+
+def _smart_turn_input(i, n):
+    x = synth_audio(n, session_idx=200 + i)
+    return x * 0.01 + 0.05 if i == 2 else x
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_smart_turn_oracle_matches_whisper_feature_extractor(golden_dir, i):
+    """oracle.whisper_logmel_window(8 s, normalised) == WhisperFeatureExtractor(chunk_length=8)(do_normalize=True) on the audio
+    the reference's SmartTurnAnalyzer._prepare_audio hands it (fixture: tests/golden/make_golden.py smart_turn)."""
+    gold = np.load(os.path.join(golden_dir, "smart_turn.npz"))
+    n = int(gold["lens"][i])
+    a = O.smart_turn_prepare_audio(_smart_turn_input(i, n))
+    assert a.shape == (128000,)
+    got = O.whisper_logmel_window(a, 80, 128000, normalize=True)
+    assert got.shape == (80, 800)
+    np.testing.assert_allclose(got[:, ::4], gold[f"feat_{i}"], atol=3e-5, rtol=0)
+    np.testing.assert_allclose(got[:, -64:], gold[f"tail_{i}"], atol=3e-5, rtol=0)
+    assert abs(got.sum() - float(gold[f"sum_{i}"])) < 0.2
+
+
+def test_windowed_oracle_equals_the_30s_oracle_at_full_window():
+    x = synth_audio(30000, 5)
+    np.testing.assert_array_equal(O.whisper_logmel_window(x, 80), O.whisper_logmel(x, 80))
+
+
+def test_smart_turn_prepare_audio_keeps_the_last_eight_seconds():
+    from speech_to_speech_amd.smart_turn import prepare_audio
+
+    long = synth_audio(128000 + 999, 1)
+    short = synth_audio(5000, 2)
+    for a in (long, short):
+        np.testing.assert_array_equal(prepare_audio(a), O.smart_turn_prepare_audio(a))
+    assert np.array_equal(prepare_audio(long), long[-128000:]) and np.all(prepare_audio(short)[:-5000] == 0)
+    with pytest.raises(ValueError):
+        prepare_audio(np.zeros((2, 10), np.float32))
+    # other rates are resampled on the host exactly as the reference does (scipy.signal.resample_poly)
+    assert prepare_audio(np.zeros(48000, np.float32), 48000).shape == (128000,)

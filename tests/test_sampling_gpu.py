@@ -79,7 +79,18 @@ def test_engine_sampling_top_k_1_equals_greedy_and_is_reproducible():
     for which in ("talker", "predictor"):
         eng.set_sampling(which, temperature=1.0, top_k=50, top_p=0.8, repetition_penalty=1.05, seed=9)
     a, b = run(), run()
-    assert torch.equal(a, b) and not torch.equal(a, greedy)
+    # every utterance draws its own stream (keyed on seed, utterance id, frame, group): a second utterance does not replay the first one's draws
+    assert not torch.equal(a, b) and not torch.equal(a, greedy)
+
+    def run_slots(slot0, utt):
+        eng.release(0, 4)
+        eng.admit(prompts[:2], slot0, 8, 8, utterance_id0=utt)
+        eng.step(4, 8)
+        return eng.read_codes(slot0, 2, 0, 8)[0].cpu()
+
+    # ... and the stream belongs to the utterance, not to the slot it landed in or to its batch-mates: reproducible per (seed, utterance id)
+    u0, u0_other_slot, u1 = run_slots(0, 100), run_slots(2, 100), run_slots(0, 200)
+    assert torch.equal(u0, u0_other_slot) and not torch.equal(u0, u1)
     for which in ("talker", "predictor"):
         eng.set_sampling(which, temperature=0.0)
     assert torch.equal(run(), greedy)

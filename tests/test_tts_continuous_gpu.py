@@ -1,0 +1,113 @@
+"""Continuous batching of the TTS frame loop (speech-to-speech_amd/tts_continuous.py, s2s_tts_admit / _step / _read_codes / _release /
+s2s_codec_decode_rows): a session's output must not depend on WHEN it joined the frame loop, on its slot, or on its batch-mates.
+
+float32 engine, tiny dims: codes of every session BIT-EXACT vs the oracle run on that session alone (reference behaviour: every
+request is an independent stream, TTS/qwen3_tts_handler.py:695-749); int16 audio identical to the same engine streaming the session
+alone."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qwen3_tts as OT
+from speech_to_speech_amd.synth_weights import Qwen3TTSDims, qwen3_tts_state_dict
+from speech_to_speech_amd.tts import TTSEngine, TTSPrompt
+from speech_to_speech_amd.tts_continuous import ContinuousTTS, TTSJob
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 4
+
+
+@pytest.fixture(scope="module")
+def world():
+    dims = Qwen3TTSDims.test_tiny()
+    sd = qwen3_tts_state_dict(dims, seed=5)
+    g = torch.Generator().manual_seed(11)
+    lens = [6, 4, 9, 5, 7, 3, 8]
+    budgets = [12, 8, 12, 6, 12, 3, 10]          # frames per session (eos masked up to the budget: fixed-length replies); 6 and 10 end inside a
+                                                 # later chunk, 3 inside its FIRST chunk
+    prompts = [torch.randn(n, dims.t_hidden, generator=g) for n in lens]
+    pad = torch.randn(dims.t_hidden, generator=g) * 0.5
+    sup = [i for i in range(dims.codebook, dims.codec_vocab) if i != dims.codec_eos]
+    codes = []
+    with torch.no_grad():
+        for p, nf in zip(prompts, budgets):
+            c, _ = OT.talker_generate(sd, dims.talker_cfg(), dims.predictor_cfg(), p[None], dims.n_groups, nf, dims.codec_eos, suppress=sup, pad_embed=pad, min_frames=nf)
+            codes.append(c[0].numpy())
+    return dims, sd, prompts, budgets, pad, codes
+
+
+def _collect(events, audio, ended):
+    for job, chunk in events:
+        if chunk is None:
+            assert not ended.get(id(job)), "end marker delivered twice"
+            ended[id(job)] = True
+        else:
+            assert not ended.get(id(job)), "audio after the end marker"
+            audio.setdefault(id(job), []).append(chunk)
+
+
+def test_sessions_joining_mid_stream_match_the_oracle_and_a_solo_run(world):
+    dims, sd, prompts, budgets, pad, ref_codes = world
+    eng = TTSEngine(dims, sd, dtype=torch.float32, max_batch=6, max_prompt=16, max_frames=16, max_codec_frames=8, pad_embed=pad)
+    jobs = [TTSJob(TTSPrompt(p.numpy()), b, min_frames=b) for p, b in zip(prompts, budgets)]
+    cb = ContinuousTTS(eng, chunk_size=CHUNK)
+    cb.record_codes = True
+    audio, ended = {}, {}
+    # round 0: sessions 0, 1 start together
+    assert cb.admit(jobs[0:2]) == [] and cb.live == 2
+    _collect(cb.step(), audio, ended)
+    # session 2 and 3 join one chunk later; 4 two chunks later (1 has 8 frames: it ends after the second round and frees slot 1)
+    assert cb.admit(jobs[2:4]) == []
+    _collect(cb.step(), audio, ended)
+    assert ended.get(id(jobs[1])) and not ended.get(id(jobs[0]))
+    assert cb.admit([jobs[4]]) == []
+    _collect(cb.step(), audio, ended)
+    # 7 sessions never fit 6 slots at once: whatever does not fit is handed back and joins once slots are free
+    left = cb.admit(jobs[5:7])
+    while left or cb.cohorts:
+        _collect(cb.step(), audio, ended)
+        left = cb.admit(left)
+    assert all(ended.get(id(j)) for j in jobs) and cb.live == 0 and cb.free == [(0, 6)]
+    assert cb.stats["cohorts"] >= 4
+    for i, j in enumerate(jobs):
+        got = np.concatenate(j.codes)[: budgets[i]]
+        assert np.array_equal(got, ref_codes[i]), f"session {i}: codes differ from the oracle run of that session alone"
+        assert np.all(np.concatenate(j.codes)[budgets[i]:] == -1)
+    # the audio: identical samples to the same engine streaming each session alone (same chunking)
+    for i, j in enumerate(jobs):
+        solo = [c[0] for c in eng.stream([j.prompt], [budgets[i]], chunk_size=CHUNK, min_frames=budgets[i]) if c[0] is not None]
+        a, b = np.concatenate(audio[id(j)]), np.concatenate(solo)
+        assert a.dtype == np.int16 and a.shape == b.shape, (i, a.shape, b.shape)
+        # (same codes in, same kernels - a session that ends inside a chunk is cut at its last valid frame and resampled against silence, as
+        # when it streams alone; only the GEMM row counts differ between a 1-row and a 6-row launch: at most an int16 rounding step)
+        d = np.abs(a.astype(int) - b.astype(int))
+        print(f"session {i}: {a.size} samples, {int((d == 0).sum())} identical, max |diff| {int(d.max())}")
+        assert d.max() <= 2, f"session {i}: audio differs from its solo stream (max diff {d.max()})"
+    eng.close()
+
+
+def test_eos_budget_and_cancellation_free_the_slots(world):
+    dims, sd, prompts, budgets, pad, _ = world
+    eng = TTSEngine(dims, sd, dtype=torch.float32, max_batch=4, max_prompt=16, max_frames=16, max_codec_frames=8, pad_embed=pad)
+    cb = ContinuousTTS(eng, chunk_size=CHUNK)
+    # live eos (no min_frames): a session may end before its budget; the end marker comes exactly once and nothing follows it
+    jobs = [TTSJob(TTSPrompt(p.numpy()), 16) for p in prompts[:4]]
+    assert cb.admit(jobs) == []
+    audio, ended = {}, {}
+    _collect(cb.step(), audio, ended)
+    jobs[2].cancelled.set()                      # a client that went away: its session ends at the next chunk boundary
+    _collect(cb.step(), audio, ended)
+    assert ended.get(id(jobs[2]))
+    _collect(cb.drain(), audio, ended)
+    assert all(ended.get(id(j)) for j in jobs) and cb.free == [(0, 4)]
+    # a cancelled job is never admitted
+    gone = TTSJob(TTSPrompt(prompts[0].numpy()), 8)
+    gone.cancelled.set()
+    assert cb.admit([gone]) == [] and cb.live == 0
+    # the legacy entry points still work on the same engine afterwards (prefill resets every slot)
+    eng.prefill([TTSPrompt(prompts[0].numpy())])
+    c, nfr, _ = eng.generate(6, min_total_frames=6)
+    assert nfr.cpu().tolist() == [6] and int(c.min()) >= 0
+    eng.close()
