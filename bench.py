@@ -90,7 +90,8 @@ def parse(argv=None):
     ap.add_argument("--boundary-seconds", type=float, default=20.0, help="measurement window of one open-loop probe")
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
     ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
-    ap.add_argument("--stt-workers", type=int, default=2, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
+    ap.add_argument("--tts-lead-s", type=float, default=float("inf"), help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
+    ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--max-probes", type=int, default=6, help="open-loop probes of the sustained-sessions bisection")
     ap.add_argument("--turn-batches", action="store_true", help="open-loop probe with round-2 turn-batch TTS lanes instead of continuous batching (A/B)")
     ap.add_argument("--pool-lanes", type=int, default=3, help="TTS lanes of the SessionPool in the open-loop probe (measured: 6 lanes contend and are slower than 3)")
@@ -126,14 +127,14 @@ def spawn_ranks(args) -> int:
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (C1)
-def cpu_baseline_c1(talker_layers_sample: int = 7, reply_frames: int = 12):
+def cpu_baseline_c1(iterations: int = 3, first_chunk_frames: int = CHUNK_FRAMES):
     """BASELINE.md section 2 fallback: the CPU oracle (PyTorch fp32 restatements under oracle/, seeded-random weights at the true
-    dimensions - "CPU oracle, not ggml") on config C1: ONE 5 s utterance through Whisper tiny.en (full depth: log-mel, 4+4 layers,
-    greedy decode) and the Qwen3-TTS-1.7B reply.  Bounded sample for the TTS leg: `talker_layers_sample` of the 28 (identical-cost)
-    talker layers and `reply_frames` of the 63 codec frames are executed, the code predictor and the codec decoder at full depth;
-    per-layer / per-frame time is scaled to the whole 5.04 s reply.  cores = the node's count (torch.set_num_threads)."""
-    import copy
-
+    dimensions - "CPU oracle, not ggml / CTranslate2", neither is installable offline) on config C1: ONE 5 s utterance through Whisper
+    tiny.en and the Qwen3-TTS-1.7B reply, every stack at FULL depth (28 talker layers, 5 predictor layers x 15 groups, whole codec decoder).
+    Protocol of the reference's scripts/benchmark_stt.py:220-253 / benchmark_tts.py:183-210: 1 untimed warm-up + `iterations` timed
+    iterations of the time-to-first-audio path (STT leg -> talker prefill -> first `first_chunk_frames` codec frames -> codec decode of
+    that chunk), mean / min / std reported.  Bounded sample: the frames after the first chunk are not executed; the reply's remaining
+    frames are priced at the measured per-frame cost of the first chunk (identical work per frame).  cores = threads actually used."""
     import numpy as np
     import torch
 
@@ -164,41 +165,52 @@ def cpu_baseline_c1(talker_layers_sample: int = 7, reply_frames: int = 12):
     wsd = _rand_whisper_sd(wd, g)
     audio = synth_audio(80000, 0)
     frames_full = 63                                     # 5.04 s reply at 12.5 Hz
-    with torch.no_grad():
+    F = int(first_chunk_frames)
+    td = Qwen3TTSDims.tts_1_7b()
+    tsd = _rand_tts_sd(td, g)                            # full depth: 28 talker layers
+    prompt = torch.randn(1, 70, td.t_hidden, generator=g) * 0.5
+    pad = torch.randn(td.t_hidden, generator=g) * 0.5
+
+    def stt_leg():
         t0 = time.perf_counter()
         feats = torch.from_numpy(OL.whisper_logmel(audio, wd.n_mels).astype(np.float32))[None]
         enc = OW.encode(wsd, feats, wd.n_heads, wd.enc_layers)
         OW.greedy_decode(wsd, enc, wd.n_heads, wd.dec_layers, [[1, 2]], eos=-1, max_new_tokens=32)
-        t_stt = time.perf_counter() - t0
-        td = Qwen3TTSDims.tts_1_7b()
-        ts = copy.copy(td)
-        ts.t_layers = min(td.t_layers, talker_layers_sample)
-        tsd = _rand_tts_sd(ts, g)
-        prompt = torch.randn(1, 70, td.t_hidden, generator=g) * 0.5
-        pad = torch.randn(td.t_hidden, generator=g) * 0.5
+        return time.perf_counter() - t0
+
+    def tts_first_chunk(n):
         t1 = time.perf_counter()
-        codes, _ = OT.talker_generate(tsd, ts.talker_cfg(), ts.predictor_cfg(), prompt, td.n_groups, reply_frames, td.codec_eos, pad_embed=pad,
-                                      min_frames=reply_frames)
-        t_frames = time.perf_counter() - t1
+        codes, _ = OT.talker_generate(tsd, td.talker_cfg(), td.predictor_cfg(), prompt, td.n_groups, n, td.codec_eos, pad_embed=pad, min_frames=n)
+        t_gen = time.perf_counter() - t1
         t2 = time.perf_counter()
-        OT.code_predictor_greedy(tsd, ts.predictor_cfg(), torch.randn(1, td.t_hidden, generator=g), torch.randn(1, td.t_hidden, generator=g), td.n_groups)
-        t_pred = time.perf_counter() - t2
-        t3 = time.perf_counter()
-        OT.codec_decode(tsd, ts.codec_cfg(), codes.clamp(min=0).permute(0, 2, 1))
-        t_codec = time.perf_counter() - t3
-    # talker share of a frame scales with depth; predictor + heads do not
-    per_frame = t_frames / reply_frames
-    talker_frame = max(per_frame - t_pred, 0.0) * td.t_layers / ts.t_layers
-    t_tts = (talker_frame + t_pred) * frames_full + t_codec * frames_full / reply_frames
+        OT.codec_decode(tsd, td.codec_cfg(), codes.clamp(min=0).permute(0, 2, 1))
+        return t_gen, time.perf_counter() - t2
+
+    with torch.no_grad():
+        stt_leg()                                        # warm-up (untimed) ...
+        t_gen1, _ = tts_first_chunk(1)                   # ... which also gives prefill + ONE frame, to separate the prefill from the per-frame cost
+        stt, gen, cod = [], [], []
+        for _ in range(max(1, int(iterations))):
+            stt.append(stt_leg())
+            a, b = tts_first_chunk(F)
+            gen.append(a)
+            cod.append(b)
+    ttfa = np.array(stt) + np.array(gen) + np.array(cod)
+    t_stt, t_gen, t_codec = float(np.mean(stt)), float(np.mean(gen)), float(np.mean(cod))
+    per_frame = max(t_gen - t_gen1, 0.0) / max(F - 1, 1)
+    prefill = max(t_gen1 - per_frame, 0.0)
+    t_tts = prefill + per_frame * frames_full + t_codec * frames_full / F
     total = t_stt + t_tts
     turn_audio = 5.0 + frames_full * FRAME_S
     return {"value": round(turn_audio / total, 3), "unit": "concurrent real-time sessions (C1 turn: 5 s utterance in + 5.04 s reply out / CPU seconds of its STT + TTS legs)",
-            "cores": cores, "kind": "port", "ttfa_ms_estimate": round((t_stt + (talker_frame + t_pred) * CHUNK_FRAMES + t_codec * CHUNK_FRAMES / reply_frames) * 1e3, 1),
-            "node_cores": node_cores,
-            "sample": f"CPU oracle (PyTorch fp32), not ggml / CTranslate2 (neither is installed): config C1 = one 5 s utterance; STT leg Whisper tiny.en "
-                      f"dims at full depth ({t_stt:.2f} s: log-mel + encoder + 32 greedy tokens); TTS leg Qwen3-TTS-1.7B dims: {ts.t_layers}/{td.t_layers} talker "
-                      f"layers x {reply_frames}/{frames_full} frames executed ({t_frames:.1f} s), code predictor ({t_pred:.2f} s / frame) and codec decoder "
-                      f"({t_codec:.1f} s for {reply_frames} frames) at full depth, scaled to the whole reply -> {t_tts:.1f} s; {total:.1f} s per turn"}
+            "cores": cores, "kind": "port", "node_cores": node_cores, "iterations": len(stt), "warmup": 1,
+            "ttfa_ms": {"mean": round(float(ttfa.mean()) * 1e3, 1), "min": round(float(ttfa.min()) * 1e3, 1), "std": round(float(ttfa.std()) * 1e3, 1)},
+            "stt_ms": {"mean": round(t_stt * 1e3, 1), "min": round(float(np.min(stt)) * 1e3, 1)},
+            "sample": f"CPU oracle (PyTorch fp32), not ggml / CTranslate2 (neither is installed): config C1 = one 5 s utterance; 1 warm-up + {len(stt)} iterations of the "
+                      f"time-to-first-audio path at FULL depth - STT leg Whisper tiny.en dims ({t_stt:.2f} s: log-mel + encoder + 32 greedy tokens), Qwen3-TTS-1.7B dims: talker "
+                      f"prefill of 70 rows + first {F} frames with all {td.t_layers} talker layers and the 15-group code predictor ({t_gen:.2f} s; {per_frame:.3f} s per frame, "
+                      f"prefill {prefill:.2f} s), codec decoder of that chunk ({t_codec:.2f} s).  Throughput: the remaining {frames_full - F} frames of the 5.04 s reply are priced "
+                      f"at the measured per-frame cost (identical work per frame) -> {t_tts:.1f} s TTS, {total:.1f} s per turn"}
 
 
 def _rand_whisper_sd(dims, g):
@@ -319,7 +331,7 @@ def _rand_tts_sd(dims, g):
 
 
 # --------------------------------------------------------------------------------------------- boundary probe
-def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1):
+def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf")):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -338,7 +350,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     from speech_to_speech_amd.text import IdTextCodec, WhisperVocab
 
     B = tts_engine.max_batch
-    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers)
+    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
@@ -711,7 +723,7 @@ def main():
 
             def probe(n, window=args.boundary_seconds):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
-                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers)
+                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s)
 
             single = probe(1, window=12.0)
             best, tried = (None, [])

@@ -79,9 +79,14 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf")):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
+        # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
+        # playback by less than this (a round with a NEW cohort - time-to-first-audio - always runs at once).  Default inf = eager rounds:
+        # measured on C3 (profiles/r03_open_loop_ab.txt) pacing at 1-2 s raises the rows per round but does NOT raise the STT service rate,
+        # which is what bounds the sustained session count - p95 TTFA at 900 sessions 958 ms eager vs 3.3 s paced at 2 s.
+        self.tts_lead_s = float(tts_lead_s)
         self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
         self._lane_live: dict[int, int] = {}     # live sessions per continuous lane (load balancing between lanes)
         self.tts_lanes = max(1, int(tts_lanes))
@@ -406,6 +411,9 @@ class SessionPool:
                 t_a = time.perf_counter()
                 backlog = cb.admit(backlog)
                 t_r = time.perf_counter()
+                if n0 == len(backlog) and cb.cohorts and cb.min_lead_s(t_r) > self.tts_lead_s and not stop:
+                    time.sleep(0.004)            # everybody is far enough ahead of their playback: leave the device to STT / first chunks
+                    continue
                 rows = cb.rows()
                 for job, chunk in cb.step():
                     if chunk is None or not job.cancelled.is_set():

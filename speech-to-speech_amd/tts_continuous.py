@@ -42,6 +42,7 @@ class _Cohort:
     jobs: list
     frames: int = 0                 # frames generated (= decoded) so far
     ended: list = field(default_factory=list)     # per job: end marker delivered
+    t_first: float | None = None    # wall time its first chunk was handed out (playback starts then)
 
 
 class ContinuousTTS:
@@ -164,8 +165,12 @@ class ContinuousTTS:
             ev = self._events[ci]
             ev.record()
             pending.append((c, h_pcm, (h_nfr, h_nval), ev, (pcm, nfr, codes, wav, nvalid), h_codes))
+        import time as _time
+
         for c, h_pcm, h_nfr, ev, _keep, h_codes in pending:
             ev.synchronize()
+            if c.t_first is None:
+                c.t_first = _time.perf_counter()
             pcm_h, nfr_h, nval_h = h_pcm.numpy(), h_nfr[0].numpy(), h_nfr[1].numpy()       # (views of the pinned rows)
             for i, job in enumerate(c.jobs):
                 if c.ended[i]:
@@ -190,6 +195,16 @@ class ContinuousTTS:
             eng.release(c.slot0, len(c.jobs))
             self._give(c.slot0, len(c.jobs))
             self.cohorts.remove(c)
+
+    FRAME_S = 0.08                   # one codec frame = 80 ms of audio (12.5 Hz)
+
+    def min_lead_s(self, now: float) -> float:
+        """Smallest audio lead over the live cohorts: seconds of already delivered audio that playback has not reached yet
+        (first chunk handed out at t_first, frames * 80 ms delivered).  A cohort still waiting for its first chunk has lead -inf."""
+        lead = float("inf")
+        for c in self.cohorts:
+            lead = min(lead, float("-inf") if c.t_first is None else c.t_first + c.frames * self.FRAME_S - now)
+        return lead
 
     def drain(self) -> Iterator[tuple[Any, np.ndarray | None]]:
         while self.cohorts:
