@@ -171,6 +171,16 @@ int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W,
                         void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
                         int32_t nf, int32_t layout);
 int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t K, int32_t nf, int32_t layout);
+/* The same projection behind a LAYERNORM instead of an RMSNorm - the pre-LN blocks of the Whisper decoder (transformers
+ * whisper/modeling_whisper.py WhisperDecoderLayer: self_attn_layer_norm -> q/k/v, encoder_attn_layer_norm -> q, final_layer_norm -> fc1):
+ *   out = rstd * (A W'^T - mean * csum) + bias,  W' = W * gamma (columns), csum[n] = sum_k bf16(W'[n][k]),  bias = b + W beta.
+ * The row statistics come from PAIR partials (part 2 i = sum of squares, 2 i + 1 = plain sum of column slab i) written by the producing
+ * mode-2 call when layout bit 16 is set (s2s_op_gemm_dec_parts counts both) or by s2s_op_rows_prep_pairs.  mode 0 / 1 only. */
+int32_t s2s_op_gemm_dec_ln(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                           int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
+                           void* C, int64_t ldc, int32_t act, int32_t layout, const float* csum_dev);
+int32_t s2s_op_rows_prep_pairs(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
+                               int32_t frag, int64_t pair_stride);
 /* Tuning hook of the decode projections (microbenchmarks, parity sweeps): enable = 0 keeps every call on the 16-column kernel;
  * splitk / nt > 0 force the K-slices per column block / the 16-column tiles per wave of the column-block kernel (0 = chosen
  * from the shape).  Process-wide: not for use while engines are serving. */

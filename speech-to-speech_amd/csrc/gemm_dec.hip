@@ -63,6 +63,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     __shared__ float red[DEC_NW][GR * (GLU ? 2 : 1)][4][64];
     __shared__ float ssp[DEC_NW][MT * 16];
     __shared__ float rstd_s[MT * 16];
+    __shared__ float mean_s[MT * 16];
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: k-slice bounds live in SGPRs
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
     // RMS prologue: this wave's share of the input rows' partial sums of squares (parts p = wave, wave + 8, ...).  The
     // loads are issued BEFORE the weight stream and reduced right after stage 0 is in flight: loads return in order, so
     // waiting for these (oldest, L2-resident) values never waits for the HBM stream behind them.
-    constexpr int RH = (MT * 16 + 63) / 64, RP = MT > 4 ? 8 : 16;     // prefetched parts per wave (the rest: tail loop)
+    // prefetched parts per wave (the rest: tail loop); one weight stream leaves room for 20 x 8 waves = the 160 pair-partials of a
+    // 1280-wide LayerNorm input
+    constexpr int RH = (MT * 16 + 63) / 64, RP = MT > 4 ? 8 : (NS > 1 ? 16 : 20);
     float sv[RH][RP];
     const int ssrs = a.ss_rs > 0 ? a.ss_rs : 1;
     if (a.ss_in) {
@@ -260,10 +263,18 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
             __syncthreads();
             if (need_rstd) {                        // first pass only: finish the row scales
                 if (tid < MT * 16) {
-                    float v = 0.f;
+                    if (a.ln) {      // pairs: wave w reduced the parts w, w + 8, ... - all even (sums of squares) or all odd (sums)
+                        const float sq = (ssp[0][tid] + ssp[2][tid]) + (ssp[4][tid] + ssp[6][tid]);
+                        const float sm = (ssp[1][tid] + ssp[3][tid]) + (ssp[5][tid] + ssp[7][tid]);
+                        const float mean = sm * a.inv_dim;
+                        mean_s[tid] = mean;
+                        rstd_s[tid] = rsqrtf(fmaxf(sq * a.inv_dim - mean * mean, 0.f) + a.eps);
+                    } else {
+                        float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < DEC_NW; ++w) v += ssp[w][tid];
-                    rstd_s[tid] = rsqrtf(v * a.inv_dim + a.eps);
+                        for (int w = 0; w < DEC_NW; ++w) v += ssp[w][tid];
+                        rstd_s[tid] = rsqrtf(v * a.inv_dim + a.eps);
+                    }
                 }
                 need_rstd = false;
                 __syncthreads();
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
                     }
                 }
                 const float rs = (a.ss_in && m < MT * 16) ? rstd_s[m] : 1.0f;
+                if (a.ln && ok) v -= mean_s[m] * a.csum[nn];      // (x - mean) W'^T = x W'^T - mean * rowsum(W')
                 v *= rs;
                 if constexpr (GLU) {
                     u2 *= rs;
@@ -314,7 +326,18 @@ __global__ __launch_bounds__(DEC_NW * 64) void gemm_dec_kernel(DecGemm a) {
                         q += __shfl_xor(q, 2, 64);
                         q += __shfl_xor(q, 4, 64);
                         q += __shfl_xor(q, 8, 64);
-                        if (col == 0 && m < a.M && e < GR * 256) a.ss_out[(long)(blockIdx.x * NF + f) * a.ss_stride + m] = q;
+                        const long part = blockIdx.x * NF + f;
+                        if (a.ss_pairs) {
+                            float sx = xn;
+                            sx += __shfl_xor(sx, 1, 64);
+                            sx += __shfl_xor(sx, 2, 64);
+                            sx += __shfl_xor(sx, 4, 64);
+                            sx += __shfl_xor(sx, 8, 64);
+                            if (col == 0 && m < a.M && e < GR * 256) {
+                                a.ss_out[2 * part * a.ss_stride + m] = q;
+                                a.ss_out[(2 * part + 1) * a.ss_stride + m] = sx;
+                            }
+                        } else if (col == 0 && m < a.M && e < GR * 256) a.ss_out[part * a.ss_stride + m] = q;
                     }
                 }
             }
@@ -391,7 +414,7 @@ int dec_parts(int N, int NF) { return cdiv(N, 16 * NF) * NF; }
 
 int dec_out_parts(const DecGemm& a) {
     const int p2 = dec2_parts(a);
-    return p2 > 0 ? p2 : dec_parts(a.N, dec_nf(a));
+    return (p2 > 0 ? p2 : dec_parts(a.N, dec_nf(a))) * (a.ss_pairs ? 2 : 1);
 }
 
 int dec_nf(const DecGemm& a) {
@@ -410,6 +433,7 @@ int gemm_dec(hipStream_t st, const DecGemm& a) {
     S2S_REQUIRE(!a.glu || (a.mode == 0 && !a.bias && a.act == S2S_ACT_NONE && a.N % 16 == 0), "gemm_dec: SwiGLU output is bf16 without bias / activation, N a multiple of 16");
     S2S_REQUIRE(a.mode == 2 ? (a.X != nullptr) : (a.C != nullptr), "gemm_dec: null output");
     S2S_REQUIRE(!a.ss_in || (a.n_parts_in > 0 && a.ss_stride >= a.M && a.inv_dim > 0.f), "gemm_dec: bad RMS prologue arguments");
+    S2S_REQUIRE(!a.ln || (a.ss_in && a.csum && a.n_parts_in % 2 == 0 && !a.glu), "gemm_dec: the LayerNorm prologue needs pair partials, column sums and no SwiGLU");
     const int NF = dec_nf(a);
     ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * a.M * a.N * a.K * (a.glu ? 2 : 1),
                    (double)a.N * a.K * 2 * (a.glu ? 2 : 1) + (double)a.M * a.K * 2 + (double)a.M * a.N * (a.mode == 0 ? 2 : 4));
@@ -425,27 +449,32 @@ int gemm_dec(hipStream_t st, const DecGemm& a) {
 // rows of the f32 residual stream -> bf16 copy (row-major or fragment-major) + one partial sum of squares per row (entry of
 // a norm-free decode pass)
 __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, long x_rs, __hip_bfloat16* __restrict__ xb, long xb_rs,
-                                                        float* __restrict__ ss, int rows, int cols, int frag) {
+                                                        float* __restrict__ ss, int rows, int cols, int frag, long pair_stride) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long)row * x_rs;
-    float s = 0.f;
+    float s = 0.f, t = 0.f;
     for (int c = lane * 4; c < cols; c += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + c);
         s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        t += (v.x + v.y) + (v.z + v.w);
         ushort4 p;
         p.x = f32_to_bf16_bits(v.x); p.y = f32_to_bf16_bits(v.y); p.z = f32_to_bf16_bits(v.z); p.w = f32_to_bf16_bits(v.w);
         *reinterpret_cast<ushort4*>(xb + (frag ? frag_index(row, c, cols >> 5) : (long)row * xb_rs + c)) = p;
     }
     s = wave_sum(s);
     if (lane == 0) ss[row] = s;
+    if (pair_stride > 0) {
+        t = wave_sum(t);
+        if (lane == 0) ss[pair_stride + row] = t;
+    }
 }
 
-int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag) {
+int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag, long pair_stride) {
     S2S_REQUIRE(cols % 4 == 0 && x_rs % 4 == 0 && xb_rs % 4 == 0 && (!frag || cols % 32 == 0), "rows_prep: cols=%d unsupported", cols);
     if (rows == 0) return S2S_OK;
-    rows_prep_kernel<<<cdiv(rows, 4), 256, 0, st>>>(x, x_rs, (__hip_bfloat16*)xb, xb_rs, ss, rows, cols, frag ? 1 : 0);
+    rows_prep_kernel<<<cdiv(rows, 4), 256, 0, st>>>(x, x_rs, (__hip_bfloat16*)xb, xb_rs, ss, rows, cols, frag ? 1 : 0, pair_stride);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -490,12 +519,13 @@ int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* ou
 }  // namespace s2s
 
 /* Public op (parity tests / microbenchmarks): one decode-step projection.  See include/s2s_mi355x.h. */
-extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
-                                   int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
-                                   void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
-                                   int32_t nf, int32_t layout) {
+static int32_t op_gemm_dec_impl(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                                int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
+                                void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
+                                int32_t nf, int32_t layout, const float* csum) {
     S2S_REQUIRE(mode >= 0 && mode <= 2 && nf >= 0 && nf <= 2, "op_gemm_dec: bad mode / nf");
     s2s::DecGemm a{};
+    a.ln = csum != nullptr; a.csum = csum; a.ss_pairs = (layout & 16) != 0;
     a.A = (const __hip_bfloat16*)A; a.lda = (long)lda; a.W = (const __hip_bfloat16*)W; a.ldw = (long)ldw; a.bias = bias;
     a.M = M; a.N = N; a.K = K;
     a.ss_in = ss_in; a.n_parts_in = n_parts_in; a.ss_stride = ss_stride; a.inv_dim = inv_dim; a.eps = eps;
@@ -511,17 +541,43 @@ extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, con
     return s2s::gemm_dec((hipStream_t)stream, a);
 }
 
+extern "C" int32_t s2s_op_gemm_dec(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                                   int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
+                                   void* C, int64_t ldc, int32_t act, float* X, int64_t ldx, void* XB, int64_t ldxb, float* ss_out, int32_t glu,
+                                   int32_t nf, int32_t layout) {
+    return op_gemm_dec_impl(stream, A, lda, W, ldw, bias, M, N, K, ss_in, n_parts_in, ss_stride, inv_dim, eps, mode, C, ldc, act, X, ldx, XB, ldxb, ss_out, glu,
+                            nf, layout, nullptr);
+}
+
+/* The same projection behind a LAYERNORM (Whisper's pre-LN decoder blocks): ss_in holds pair partials (layout bit 16 on the producing
+ * mode-2 call / s2s_op_rows_prep_pairs), W has gamma folded into its columns, csum_dev f32 [N] = column sums of those folded bf16
+ * weights, bias = b + W beta.  out = rstd * (A W'^T - mean * csum) + bias. */
+extern "C" int32_t s2s_op_gemm_dec_ln(void* stream, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                                      int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
+                                      void* C, int64_t ldc, int32_t act, int32_t layout, const float* csum_dev) {
+    S2S_REQUIRE(csum_dev && ss_in && mode != 2, "op_gemm_dec_ln: needs csum, pair partials and an output mode 0 / 1");
+    return op_gemm_dec_impl(stream, A, lda, W, ldw, bias, M, N, K, ss_in, n_parts_in, ss_stride, inv_dim, eps, mode, C, ldc, act, nullptr, 0, nullptr, 0, nullptr, 0,
+                            1, layout, csum_dev);
+}
+
 /* number of partial sums of squares per row s2s_op_gemm_dec (mode 2) writes for this shape (nf 0 -> the library's choice); layout as
- * in s2s_op_gemm_dec (only bit 1, fragment-major A, matters) */
+ * in s2s_op_gemm_dec (bit 1, fragment-major A, and bit 16, pair partials, matter) */
 extern "C" int32_t s2s_op_gemm_dec_parts(int32_t M, int32_t N, int32_t K, int32_t nf, int32_t layout) {
     s2s::DecGemm a{};
-    a.M = M; a.N = N; a.K = K; a.nf = nf; a.mode = 2; a.a_frag = (layout & 1) != 0;
+    a.M = M; a.N = N; a.K = K; a.nf = nf; a.mode = 2; a.a_frag = (layout & 1) != 0; a.ss_pairs = (layout & 16) != 0;
     return s2s::dec_out_parts(a);
 }
 
 extern "C" int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
                                     int32_t frag) {
     return s2s::rows_prep((hipStream_t)stream, x, (long)x_rs, xb, (long)xb_rs, ss, rows, cols, frag != 0);
+}
+
+/* ... and ss[pair_stride + r] = sum_c x[r][c]: the pair partials (parts 0 and 1) a LayerNorm consumer reads */
+extern "C" int32_t s2s_op_rows_prep_pairs(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
+                                          int32_t frag, int64_t pair_stride) {
+    S2S_REQUIRE(pair_stride >= rows, "op_rows_prep_pairs: pair_stride %ld < rows %d", (long)pair_stride, rows);
+    return s2s::rows_prep((hipStream_t)stream, x, (long)x_rs, xb, (long)xb_rs, ss, rows, cols, frag != 0, (long)pair_stride);
 }
 
 /* row-major bf16 [rows][K] -> the fragment-major layout s2s_op_gemm_dec reads (rows padded to a multiple of 16 with zeros;

@@ -370,9 +370,9 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     }
 
     // ---- epilogue on the accumulator layout: lane = (row m = 16 i + l15, columns n .. n + 3 with n = tile * 16 + 4 lg) ----
-    float ssq[MT];
+    float ssq[MT], ssm[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ssq[i] = 0.f;
+    for (int i = 0; i < MT; ++i) ssq[i] = ssm[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + l15;
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
                         }
                 }
                 ssq[i] += (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+                ssm[i] += (xn[0] + xn[1]) + (xn[2] + xn[3]);
             }
         }
     }
@@ -475,7 +476,24 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
             float q = 0.f;
 #pragma unroll
             for (int w = 0; w < D2_NW; ++w) q += ssw[w * MT * 16 + tid];
-            a.ss_out[(long)cb * a.ss_stride + tid] = q;
+            a.ss_out[(long)(a.ss_pairs ? 2 * cb : cb) * a.ss_stride + tid] = q;
+        }
+        if (a.ss_pairs) {        // plain sums for a LayerNorm consumer: the same fixed-order reduction through the same LDS rows
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float q = ssm[i];
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lg == 0) ssw[wave * MT * 16 + i * 16 + l15] = q;
+            }
+            __syncthreads();
+            if (tid < MT * 16 && tid < a.M) {
+                float q = 0.f;
+#pragma unroll
+                for (int w = 0; w < D2_NW; ++w) q += ssw[w * MT * 16 + tid];
+                a.ss_out[(long)(2 * cb + 1) * a.ss_stride + tid] = q;
+            }
         }
     }
     if (p.dbg) {
@@ -551,7 +569,7 @@ struct Dec2Choice { int MT, NT, KC, ncb, splitk, nch, rslabs; };
 static Dec2Choice dec2_choose(const DecGemm& a) {
     Dec2Choice c{};
     const Tune& t = tune();
-    if (!t.enable || a.nf > 0 || a.M < t.min_m || !a.a_frag || (a.M > 128 && a.M % 128 != 0)) return c;
+    if (!t.enable || a.nf > 0 || a.M < t.min_m || !a.a_frag || (a.M > 128 && a.M % 128 != 0) || a.ln) return c;     // (LayerNorm prologue: 16-column kernel)
     if (a.glu && a.N % 16 != 0) return c;
     if (a.ss_in && a.n_parts_in > 64) return c;        // (the RMS prologue prefetches at most 64 partial sums per row)
     if (a.K % 32 != 0 || a.K < 256) return c;

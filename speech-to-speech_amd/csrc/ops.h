@@ -47,6 +47,11 @@ struct DecGemm {
     // RMS prologue: out = rsqrt(sum_p ss_in[p][m] * inv_dim + eps) * acc  (gamma folded into W's columns)
     const float* ss_in; int n_parts_in; int ss_stride; float inv_dim; float eps;
     int ss_rs;                              // GEMM row m reads ss_in[p * ss_stride + m * ss_rs] (0 -> 1)
+    // LayerNorm prologue (Whisper's pre-LN decoder blocks): ss_in holds PAIRS of partials - even parts sums of squares, odd parts plain
+    // sums - and out = rstd * (acc - mean * csum[n]) + bias with gamma folded into W's columns, csum[n] = sum_k W'[n][k] (the folded,
+    // bf16-rounded weights) and beta folded into the bias (b' = b + W beta).  16-column kernel only.
+    bool ln; const float* csum;
+    bool ss_pairs;                          // mode 2: write pairs (part 2 i = sum of squares, 2 i + 1 = sum) for a LayerNorm consumer
     int mode;                               // 0: C bf16, 1: C f32, 2: X += out (f32, in place) + XB (bf16 copy) + ss_out
     void* C; long ldc; int act;
     float* X; long ldx; __hip_bfloat16* XB; long ldxb;
@@ -68,7 +73,7 @@ int gemm_dec2(hipStream_t st, const DecGemm& a);
 int dec2_parts(const DecGemm& a);           // column blocks (= partial sums per row) when gemm_dec2 takes the shape, else 0
 int dec2_ensure_default_ws();
 constexpr size_t DEC_WS_BYTES = (size_t)48 << 20;   // K-slice workspace an engine allocates per stream of decode launches
-int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag);
+int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag, long pair_stride = 0);   // pair_stride > 0: also ss[pair_stride + row] = plain sum
 int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K);
 
 int layernorm(hipStream_t st, const float* x, const float* gamma, const float* beta, void* y, int rows,

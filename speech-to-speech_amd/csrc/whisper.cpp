@@ -33,6 +33,9 @@ struct Tensor {
     long numel;
 };
 
+constexpr int WH_SS_PARTS = 512;      // pair partials per row of a residual projection (2 x d / 16; 160 at d = 1280)
+constexpr int WH_SS_STRIDE = 128;     // row stride of the partial arrays (= the most sessions of a decode batch)
+
 struct Whisper {
     s2s_whisper_config cfg;
     int max_batch;
@@ -57,6 +60,11 @@ struct Whisper {
     // bf16 decode path on the fragment-major weight-streaming kernel (gemm_dec.hip): own pre-swizzled copies of the decoder matrices
     std::map<std::string, void*> fragw;
     void* dec_ws = nullptr;       // K-slice workspace of the decode projections (gemm_dec2.hip)
+    // LayerNorm-free decoder blocks (gemm_dec.hip LayerNorm prologue): the projections behind ln1 / ln2 / ln3 with gamma folded into
+    // their columns ("<name>.lf"), beta into their bias ("<name>.lb") and their column sums ("<name>.cs"); pair partials of the residual
+    // rows ping-pong between ssA / ssB [WH_SS_PARTS][WH_SS_STRIDE]
+    bool ln_fold = false;
+    float *ssA = nullptr, *ssB = nullptr;
     std::vector<void*> owned;
 };
 
@@ -198,6 +206,26 @@ static int finalize(Whisper* m) {
             S2S_HIP_CHECK(hipMalloc(&m->dec_ws, DEC_WS_BYTES));
             S2S_HIP_CHECK(hipMemset(m->dec_ws, 0, DEC_WS_BYTES));
             m->owned.push_back(m->dec_ws);
+            // LayerNorm folded into the projections that follow it (made by the host side next to the ".f" copies)
+            bool ln = getenv("S2S_NO_LN_FOLD") == nullptr && 2 * cdiv(d, 16) <= WH_SS_PARTS && B <= WH_SS_STRIDE;
+            auto lnw = [&](const std::string& name, long rows) -> bool {
+                const Tensor* w = find(m, name + ".w.lf");
+                const Tensor* b = find(m, name + ".lb");
+                const Tensor* s = find(m, name + ".cs");
+                if (!w || !b || !s || w->numel != (rows + 15) / 16 * 16 * (long)d || b->numel != rows || s->numel != rows) return false;
+                m->fragw[name + ".w.lf"] = const_cast<void*>(w->ptr);
+                return true;
+            };
+            for (int l = 0; ln && l < c.dec_layers; ++l) ln = lnw(lname("dec", l, "qkv"), 3 * d) && lnw(lname("dec", l, "cq"), d) && lnw(lname("dec", l, "fc1"), c.ffn);
+            if (ln) {
+                S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * WH_SS_PARTS * WH_SS_STRIDE));
+                S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * WH_SS_PARTS * WH_SS_STRIDE));
+                S2S_HIP_CHECK(hipMemset(m->ssA, 0, sizeof(float) * WH_SS_PARTS * WH_SS_STRIDE));
+                S2S_HIP_CHECK(hipMemset(m->ssB, 0, sizeof(float) * WH_SS_PARTS * WH_SS_STRIDE));
+                m->owned.push_back(m->ssA);
+                m->owned.push_back(m->ssB);
+                m->ln_fold = true;
+            }
         }
     }
     m->finalized = true;
@@ -267,12 +295,71 @@ static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
 
 // decode-step projection on the fragment-major weight-streaming kernel: C = act(A W^T + b) (bf16 / f32) or X += A W^T + b
 static int dec_proj(Whisper* m, hipStream_t st, const void* A, const std::string& w, const float* bias, int B, int N, int K, int mode, void* C,
-                    bool c_frag, int act, float* X) {
+                    bool c_frag, int act, float* X, void* XB = nullptr, float* ss_out = nullptr, int* parts_out = nullptr) {
     DecGemm a{};
     a.A = (const __hip_bfloat16*)A; a.a_frag = true; a.W = (const __hip_bfloat16*)m->fragw.at(w); a.bias = bias;
     a.M = B; a.N = N; a.K = K; a.mode = mode; a.C = C; a.ldc = N; a.c_frag = c_frag; a.act = act; a.X = X; a.ldx = N;
     a.ws = m->dec_ws; a.ws_bytes = DEC_WS_BYTES;
+    if (XB) {      // LayerNorm-free path: the residual projection also emits the bf16 copy of the new rows and their pair partials
+        a.XB = (__hip_bfloat16*)XB; a.ldxb = N; a.xb_frag = true; a.ss_out = ss_out; a.ss_stride = WH_SS_STRIDE; a.ss_pairs = true;
+        if (parts_out) *parts_out = dec_out_parts(a);
+    }
     return gemm_dec(st, a);
+}
+
+// projection behind a LayerNorm folded into it: out = rstd * (xb W'^T - mean * csum) + b'   (gemm_dec.hip LayerNorm prologue)
+static int dec_proj_ln(Whisper* m, hipStream_t st, const void* xb, const std::string& name, int B, int N, int K, void* C, bool c_frag, int act, const float* ss,
+                       int parts) {
+    DecGemm a{};
+    a.A = (const __hip_bfloat16*)xb; a.a_frag = true; a.W = (const __hip_bfloat16*)m->fragw.at(name + ".w.lf"); a.bias = PF(m, name + ".lb");
+    a.M = B; a.N = N; a.K = K; a.mode = 0; a.C = C; a.ldc = N; a.c_frag = c_frag; a.act = act;
+    a.ln = true; a.csum = PF(m, name + ".cs"); a.ss_in = ss; a.n_parts_in = parts; a.ss_stride = WH_SS_STRIDE; a.inv_dim = 1.0f / (float)K; a.eps = 1e-5f;
+    a.ws = m->dec_ws; a.ws_bytes = DEC_WS_BYTES;
+    return gemm_dec(st, a);
+}
+
+// one decoder step without LayerNorm launches: 9 launches per block (qkv, cache append, self attention, out-proj, cross-q, cross
+// attention, out-proj, fc1, fc2) instead of 12; the f32 residual rows xd keep a bf16 fragment-major copy (hd) and pair partials
+static int decode_step_dec_ln(Whisper* m, hipStream_t st, int B) {
+    const auto& c = m->cfg;
+    const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
+    const float scale = 1.0f / sqrtf((float)D);
+    int rc;
+    if ((rc = embed(st, m->cur_ids, m->pos, P(m, "dec.tok"), P(m, "dec.pos"), m->xd, B, d, 1.0f, dt))) return rc;
+    if ((rc = rows_prep(st, m->xd, d, m->hd, d, m->ssA, B, d, true, WH_SS_STRIDE))) return rc;
+    float *cur = m->ssA, *nxt = m->ssB;
+    int parts = 2;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        void* sk = at(m->self_k, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* sv = at(m->self_v, (size_t)l * m->max_batch * m->tmax * d * e);
+        void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
+        if ((rc = dec_proj_ln(m, st, m->hd, lname("dec", l, "qkv"), B, 3 * d, d, m->qkvd, false, S2S_ACT_NONE, cur, parts))) return rc;
+        if ((rc = kv_append(st, m->qkvd, 3 * d, d, 2 * d, sk, sv, (long)m->tmax * d, m->pos, B, d, dt))) return rc;
+        AttnRowsParams p{};
+        p.Q = m->qkvd; p.q_bs = 3 * d; p.q_rs = 3 * d;
+        p.K = sk; p.V = sv; p.kv_bs = (long)m->tmax * d; p.kv_rs = d;
+        p.O = m->attd; p.o_bs = d; p.o_rs = d; p.o_frag = true;
+        p.kv_len_const = m->tmax; p.causal = 1; p.causal_off_arr = m->pos;
+        p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
+        if ((rc = attn_rows(st, p, dt))) return rc;
+        if ((rc = dec_proj(m, st, m->attd, lname("dec", l, "o.w"), PF(m, lname("dec", l, "o.b")), B, d, d, 2, nullptr, false, S2S_ACT_NONE, m->xd, m->hd, nxt, &parts))) return rc;
+        std::swap(cur, nxt);
+        if ((rc = dec_proj_ln(m, st, m->hd, lname("dec", l, "cq"), B, d, d, m->qd, false, S2S_ACT_NONE, cur, parts))) return rc;
+        AttnRowsParams pc{};
+        pc.Q = m->qd; pc.q_bs = d; pc.q_rs = d;
+        pc.K = ckv; pc.V = at(ckv, (size_t)d * e); pc.kv_bs = (long)ENC_T * 2 * d; pc.kv_rs = 2 * d;
+        pc.O = m->attd; pc.o_bs = d; pc.o_rs = d; pc.o_frag = true;
+        pc.kv_len_const = ENC_T; pc.B = B; pc.H = H; pc.Hkv = H; pc.Tq = 1; pc.D = D; pc.scale = scale;
+        if ((rc = attn_rows(st, pc, dt))) return rc;
+        if ((rc = dec_proj(m, st, m->attd, lname("dec", l, "co.w"), PF(m, lname("dec", l, "co.b")), B, d, d, 2, nullptr, false, S2S_ACT_NONE, m->xd, m->hd, nxt, &parts))) return rc;
+        std::swap(cur, nxt);
+        if ((rc = dec_proj_ln(m, st, m->hd, lname("dec", l, "fc1"), B, c.ffn, d, m->ffnd, true, S2S_ACT_GELU, cur, parts))) return rc;
+        if ((rc = dec_proj(m, st, m->ffnd, lname("dec", l, "fc2.w"), PF(m, lname("dec", l, "fc2.b")), B, d, c.ffn, 2, nullptr, false, S2S_ACT_NONE, m->xd, m->hd, nxt, &parts))) return rc;
+        std::swap(cur, nxt);
+    }
+    // the final LayerNorm stays a launch: its consumer, the 51 866-column logits projection, runs the column-block kernel
+    if ((rc = layernorm(st, m->xd, PF(m, "dec.ln.g"), PF(m, "dec.ln.b"), m->hd, B, d, 1e-5f, dt, true))) return rc;
+    return dec_proj(m, st, m->hd, "dec.tok", nullptr, B, c.vocab, d, 1, m->logits, false, S2S_ACT_NONE, nullptr);
 }
 
 // one decoder step for B sessions on the bf16 serving path: LayerNorm rows, attention outputs and the GELU activations are
@@ -318,7 +405,7 @@ static int decode_step_dec(Whisper* m, hipStream_t st, int B) {
 
 // one decoder step for B sessions: input ids in m->cur_ids, positions in m->pos
 static int decode_step(Whisper* m, hipStream_t st, int B, bool split_ok) {
-    if (!m->fragw.empty() && B <= 128 && m->tmax >= 64) return decode_step_dec(m, st, B);
+    if (!m->fragw.empty() && B <= 128 && m->tmax >= 64) return m->ln_fold ? decode_step_dec_ln(m, st, B) : decode_step_dec(m, st, B);
     const auto& c = m->cfg;
     const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
     const float scale = 1.0f / sqrtf((float)D);

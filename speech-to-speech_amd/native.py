@@ -74,6 +74,8 @@ _SIGNATURES = {
     "s2s_op_gemm_dec": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _vp, _i64,
                         _vp, _i64, _vp, _i32, _i32, _i32],
     "s2s_op_gemm_dec_parts": [_i32, _i32, _i32, _i32, _i32],
+    "s2s_op_gemm_dec_ln": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _i32, _vp],
+    "s2s_op_rows_prep_pairs": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i64],
     "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
     "s2s_op_gemm_dec_debug": [_vp],
     "s2s_op_rows_prep": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32],

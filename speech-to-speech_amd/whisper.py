@@ -143,6 +143,17 @@ class WhisperEngine:
                     for nm in ("qkv.w", "o.w", "cq.w", "co.w", "fc1.w", "fc2.w"):
                         tensors[f"dec.{l}.{nm}.f"] = native.to_frag(tensors[f"dec.{l}.{nm}"].view(-1, dims.ffn if nm == "fc2.w" else dims.d_model))
                 tensors["dec.tok.f"] = native.to_frag(tensors["dec.tok"].view(dims.vocab, dims.d_model))
+                # LayerNorm-free decoder blocks (csrc/gemm_dec.hip LayerNorm prologue): the projection behind each LayerNorm with gamma folded
+                # into its columns (".w.lf", one bf16 rounding of W * gamma), beta into its bias (".lb" = b + W beta) and the column sums of
+                # the folded weights (".cs", what the mean term multiplies)
+                d = dims.d_model
+                for l in range(dims.dec_layers):
+                    for nm, lnn in (("qkv", "ln1"), ("cq", "ln2"), ("fc1", "ln3")):
+                        W = tensors[f"dec.{l}.{nm}.w"].view(-1, d)
+                        gam, bet = tensors[f"dec.{l}.{lnn}.g"].float(), tensors[f"dec.{l}.{lnn}.b"].float()
+                        tensors[f"dec.{l}.{nm}.w.lf"] = native.to_frag(W, gam)
+                        tensors[f"dec.{l}.{nm}.lb"] = (tensors[f"dec.{l}.{nm}.b"].float() + W.float() @ bet).contiguous()
+                        tensors[f"dec.{l}.{nm}.cs"] = (W.float() * gam).to(torch.bfloat16).float().sum(1).contiguous()
                 torch.cuda.current_stream().synchronize()      # (a stream, not the device: never collide with another thread's capture)
             for name, dt in tensors.items():
                 self._weights[name] = dt   # keep alive: the engine holds raw pointers

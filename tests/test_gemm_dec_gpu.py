@@ -486,3 +486,77 @@ def test_gemm_dec2_ticket_handoff_stress(dec2_default):
                 first[ci] = out.clone()
             else:
                 assert torch.equal(out, first[ci]), f"run {it} of case {ci} differs from the first run"
+
+
+@pytest.mark.parametrize("M,d,ffn", [(64, 1280, 5120), (5, 1280, 5120), (128, 384, 1536)])
+def test_layernorm_free_whisper_block_matches_layernorm_linear_reference(M, d, ffn):
+    """The Whisper decoder's pre-LN block without LayerNorm launches (transformers whisper/modeling_whisper.py WhisperDecoderLayer):
+    rows_prep(pairs) -> qkv behind LN1 (gamma folded into W, beta into the bias, mean term through the column sums) -> [identity
+    attention] -> out-proj (residual, pair partials) -> cross-q behind LN2 -> out-proj (residual) -> fc1 behind LN3 + GELU -> fc2
+    (residual; at K = 5120 the column-block kernel writes the pair partials) vs the float64 LayerNorm -> Linear chain on the same
+    weights.  The row statistics use the f32 residual rows, the projections their bf16 copy - the engine's rounding points."""
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(d + M)
+    x0 = torch.randn(M, d, generator=g) * 1.5 + 0.7 * torch.randn(M, 1, generator=g)        # rows with a mean: the mean term matters
+    eps = 1e-5
+
+    def lin(o, i):
+        return _bf(torch.randn(o, i, generator=g) * i ** -0.5), torch.randn(o, generator=g) * 0.1
+
+    gam = [1.0 + 0.1 * torch.randn(d, generator=g) for _ in range(3)]
+    bet = [0.1 * torch.randn(d, generator=g) for _ in range(3)]
+    (Wq, bq), (Wo, bo), (Wc, bc), (Wco, bco), (W1, b1), (W2, b2) = lin(d, d), lin(d, d), lin(d, d), lin(d, d), lin(ffn, d), lin(d, ffn)
+
+    def ln(v, i):
+        return torch.nn.functional.layer_norm(v, (d,), gam[i].double(), bet[i].double(), eps)
+
+    # textbook chain in float64 (bf16 only where the engine stores bf16: projection inputs and mode-0 outputs)
+    x = x0.double()
+    q = _bf((_bf(ln(x, 0).float()).double() @ _f64(Wq).T + bq.double()).float()).double()
+    x = x + q @ _f64(Wo).T + bo.double()
+    c = _bf((_bf(ln(x, 1).float()).double() @ _f64(Wc).T + bc.double()).float()).double()
+    x = x + c @ _f64(Wco).T + bco.double()
+    h = _bf(torch.nn.functional.gelu(_bf(ln(x, 2).float()).double() @ _f64(W1).T + b1.double()).float()).double()
+    x_ref = x + h @ _f64(W2).T + b2.double()
+
+    def folded(W, b, i):
+        Wf = _bf(W.float() * gam[i])                                  # one rounding of W * gamma, like the library's converter
+        return to_frag(W.to(DEV), gam[i].to(DEV)), (b + W.float() @ bet[i]).to(DEV), Wf.float().sum(1).to(DEV)
+
+    (Wq_f, bq_f, sq), (Wc_f, bc_f, sc), (W1_f, b1_f, s1) = folded(Wq, bq, 0), folded(Wc, bc, 1), folded(W1, b1, 2)
+    Wo_f, Wco_f, W2_f = to_frag(Wo.to(DEV)), to_frag(Wco.to(DEV)), to_frag(W2.to(DEV))
+    Mp, S = (M + 15) // 16 * 16, max(128, M)
+    X = x0.clone().to(DEV)
+    XB = torch.zeros(Mp * d, dtype=torch.bfloat16, device=DEV)
+    ssA, ssB = torch.zeros(512, S, device=DEV), torch.zeros(512, S, device=DEV)
+    st = native.stream_handle()
+    native.check(lib.s2s_op_rows_prep_pairs(st, native.ptr(X), d, native.ptr(XB), d, native.ptr(ssA), M, d, 1, S), "rows_prep_pairs")
+
+    def ln_proj(Wf, bias, csum, N, ss, parts, out, act=0, c_frag=True):
+        native.check(lib.s2s_op_gemm_dec_ln(st, native.ptr(XB), d, native.ptr(Wf), d, native.ptr(bias), M, N, d, native.ptr(ss), parts, S, 1.0 / d, eps, 0,
+                                            native.ptr(out), N, act, 1 | (2 if c_frag else 0), native.ptr(csum)), "gemm_dec_ln")
+
+    def resid(Af, Wf, bias, K, ss_out):
+        native.check(lib.s2s_op_gemm_dec(st, native.ptr(Af), K, native.ptr(Wf), K, native.ptr(bias.to(DEV)), M, d, K, None, 0, S, 0.0, 0.0, 2, None, 0, 0,
+                                         native.ptr(X), d, native.ptr(XB), d, native.ptr(ss_out), 0, 0, 1 | 4 | 16), "gemm_dec resid")
+        return lib.s2s_op_gemm_dec_parts(min(M, 128), d, K, 0, 1 | 16)
+
+    t = torch.zeros(Mp * d, dtype=torch.bfloat16, device=DEV)
+    ln_proj(Wq_f, bq_f, sq, d, ssA, 2, t)
+    p = resid(t, Wo_f, bo, d, ssB)
+    ln_proj(Wc_f, bc_f, sc, d, ssB, p, t)
+    p = resid(t, Wco_f, bco, d, ssA)
+    hh = torch.zeros(Mp * ffn, dtype=torch.bfloat16, device=DEV)
+    ln_proj(W1_f, b1_f, s1, ffn, ssA, p, hh, act=native.ACT_GELU)
+    p2 = resid(hh, W2_f, b2, ffn, ssB)
+    assert p % 2 == 0 and p2 % 2 == 0
+    # the statistics the last projection left behind are those of the final rows (what the next block's LN1 would read)
+    torch.cuda.synchronize()
+    sums = ssB[:p2].double().cpu()
+    xf = _f64(X)
+    assert (sums[0::2, :M].sum(0) - (xf ** 2).sum(1)).abs().max().item() <= 1e-3 * (xf ** 2).sum(1).max().item()
+    assert (sums[1::2, :M].sum(0) - xf.sum(1)).abs().max().item() <= 1e-3 * xf.abs().sum(1).max().item()
+    err = (xf - x_ref).abs().max().item()
+    scale = x_ref.abs().max().item()
+    print(f"LayerNorm-free Whisper block M={M} d={d}: max|err| vs the float64 LayerNorm -> Linear chain {err:.3e} (|x| max {scale:.2f}, fc2 partials {p2})")
+    assert err <= 3e-2 * scale
