@@ -736,9 +736,9 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     }
 }
 
-// ---- 256x256 tile GEMM: 4 waves of 128x128, 4-stage ring of 32-wide K slabs (bf16) -------------------------------------------
-// EXPERIMENTAL (S2S_TILE4=1; off by default: written at the end of round 2 without GPU time left to validate it - the
-// addressing is checked by tools/proto/tile4_addressing_check.py, parity and timing by tools/proto/tile4_check.py).
+// ---- 256x256 tile GEMM: 8 waves of 128x64 (or 4 of 128x128), 4-stage ring of 32-wide K slabs (bf16) ----------------------------
+// Validated in round 3 (tools/proto/tile4_check.py, profiles/r03_tile4_check.txt; tests/test_ops_gpu.py runs the encoder shapes through
+// it): the 8-wave variant is the default for the encoder-sized projections.
 // Why: gemm_tile3's 64x64 wave tiles need 32 flop per LDS byte - exactly what the LDS delivers (128 B/clk/CU against
 // 4069 flop/clk/CU) - so its main loop can not pass ~50 % of the MFMA peak.  Here every wave owns a 128x128 output block
 // (8x8 fragments, 256 accumulator registers, one wave per SIMD): 16 fragment reads feed 64 MFMAs per 32-wide K slab, i.e.
@@ -1139,10 +1139,19 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
     }
 }
 
-// the experimental 256x256 kernel serves the encoder-sized bf16 projections when S2S_TILE4 is set
+// the 256x256 kernel serves the encoder-sized bf16 projections (S2S_TILE4=0 keeps them on gemm_tile3; measured round 3,
+// profiles/r03_tile4_check.txt: parity OK on every shape, 8-wave variant +2 .. +19 % over gemm_tile3 on the Whisper encoder GEMMs,
+// the 4-wave variant slower than gemm_tile3 - it stays selectable with S2S_TILE4=1 for A/B runs only)
+static int tile4_mode() {
+    static const int mode = [] {
+        const char* e = getenv("S2S_TILE4");
+        return e ? atoi(e) : 2;
+    }();
+    return mode;
+}
 template <typename T>
 static bool tile4_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
-    static const bool on = getenv("S2S_TILE4") != nullptr;
+    const bool on = tile4_mode() > 0;
     return on && sizeof(T) == 2 && !ext && g.tap_len == 0 && K % T4_BK == 0 && K >= 4 * T4_BK && M >= 2048 && N >= 512 &&
            (long)cdiv(M, T4_M) * cdiv(N, T4_N) * nz >= 192;
 }
@@ -1235,7 +1244,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                            ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-            static const bool eight_waves = atoi(getenv("S2S_TILE4")) >= 2;      // (tile4_ok: the variable is set)
+            const bool eight_waves = tile4_mode() >= 2;
             if (eight_waves)
                 launch_k(gemm_tile4_kernel<CT, 4>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
                          (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);

@@ -318,7 +318,7 @@ static int dec_proj_ln(Whisper* m, hipStream_t st, const void* xb, const std::st
     return gemm_dec(st, a);
 }
 
-// one decoder step without LayerNorm launches: 9 launches per block (qkv, cache append, self attention, out-proj, cross-q, cross
+// one decoder step without LayerNorm launches: 8 launches per block (qkv, cache append + self attention, out-proj, cross-q, cross
 // attention, out-proj, fc1, fc2) instead of 12; the f32 residual rows xd keep a bf16 fragment-major copy (hd) and pair partials
 static int decode_step_dec_ln(Whisper* m, hipStream_t st, int B) {
     const auto& c = m->cfg;
@@ -334,14 +334,14 @@ static int decode_step_dec_ln(Whisper* m, hipStream_t st, int B) {
         void* sv = at(m->self_v, (size_t)l * m->max_batch * m->tmax * d * e);
         void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
         if ((rc = dec_proj_ln(m, st, m->hd, lname("dec", l, "qkv"), B, 3 * d, d, m->qkvd, false, S2S_ACT_NONE, cur, parts))) return rc;
-        if ((rc = kv_append(st, m->qkvd, 3 * d, d, 2 * d, sk, sv, (long)m->tmax * d, m->pos, B, d, dt))) return rc;
-        AttnRowsParams p{};
-        p.Q = m->qkvd; p.q_bs = 3 * d; p.q_rs = 3 * d;
-        p.K = sk; p.V = sv; p.kv_bs = (long)m->tmax * d; p.kv_rs = d;
-        p.O = m->attd; p.o_bs = d; p.o_rs = d; p.o_frag = true;
-        p.kv_len_const = m->tmax; p.causal = 1; p.causal_off_arr = m->pos;
-        p.B = B; p.H = H; p.Hkv = H; p.Tq = 1; p.D = D; p.scale = scale;
-        if ((rc = attn_rows(st, p, dt))) return rc;
+        {   // self attention: cache append + attention over keys 0 .. pos[b] in ONE launch (no head norms, no rotary: Whisper)
+            AttnStepParams a{};
+            a.qkv = m->qkvd; a.qkv_rs = 3 * d;
+            a.K = sk; a.V = sv; a.kv_bs = (long)m->tmax * d; a.kv_rs = d;
+            a.O = m->attd; a.o_bs = d; a.o_frag = true;
+            a.pos = m->pos; a.B = B; a.H = H; a.Hkv = H; a.D = D; a.kv_cap = m->tmax; a.window = 0; a.scale = scale; a.eps = 0.f;
+            if ((rc = attn_step(st, a, dt))) return rc;
+        }
         if ((rc = dec_proj(m, st, m->attd, lname("dec", l, "o.w"), PF(m, lname("dec", l, "o.b")), B, d, d, 2, nullptr, false, S2S_ACT_NONE, m->xd, m->hd, nxt, &parts))) return rc;
         std::swap(cur, nxt);
         if ((rc = dec_proj_ln(m, st, m->hd, lname("dec", l, "cq"), B, d, d, m->qd, false, S2S_ACT_NONE, cur, parts))) return rc;

@@ -38,7 +38,10 @@ def _ref(A, W, bias, resid, act):
 SHAPES = [(128, 128, 64), (300, 200, 136), (1500, 384, 384), (64, 1280, 1280), (1, 51864, 384), (17, 100, 72),
           (65, 130, 264),
           # large-M shapes that take the 256x128 / 3-stage ring kernel (ragged M and N edges; 3, 5 and 6 K-slabs)
-          (9000, 650, 192), (8192, 1024, 320)]
+          (9000, 650, 192), (8192, 1024, 320),
+          # encoder-sized bf16 projections: the 256x256 tile kernel (8 waves of 128x64, 4-stage ring of 32-wide K slabs) - ragged M / N
+          # edges, 40 and 5 K-slabs
+          (12700, 1300, 1280), (16000, 3840, 160)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)

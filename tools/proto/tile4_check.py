@@ -11,8 +11,10 @@ import ctypes as C
 import os
 import sys
 
-if not os.environ.get("S2S_TILE4_OFF"):
-    os.environ.setdefault("S2S_TILE4", "1")      # 1: 4 waves of 128 x 128;  2: 8 waves of 128 x 64
+if os.environ.get("S2S_TILE4_OFF"):
+    os.environ["S2S_TILE4"] = "0"                # gemm_tile3 (the A/B reference)
+else:
+    os.environ.setdefault("S2S_TILE4", "2")      # 1: 4 waves of 128 x 128;  2: 8 waves of 128 x 64 (the library default)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
