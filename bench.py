@@ -777,6 +777,16 @@ def main():
                    "launches_per_step": r["launches"] // n_prof, "kernel_ms_per_step": round(r["ms"] / n_prof, 2),
                    "avg_kernel_us": round(r["ms"] * 1e3 / r["launches"], 2),
                    "algorithmic_gb_per_step": round(r["bytes"] / n_prof / 1e9, 2), "algorithmic_tflop_per_step": round(r["flops"] / n_prof / 1e12, 3)}
+    if "gemm_dec" in fams and tts is not None and n_prof:
+        # SURVEY 8d classes the code predictor (5 layers, re-read by each of its 15 steps per frame) as cache-resident / latency-bound: the
+        # same family with those weights counted ONCE per frame instead of 15 times
+        P, pf, nq = tdims.p_hidden, tdims.p_ffn, (tdims.p_heads + 2 * tdims.p_kv_heads) * tdims.p_head_dim
+        layer_b = 2.0 * (nq * P + P * tdims.p_heads * tdims.p_head_dim + 2 * pf * P + P * pf)
+        reread_gb = tdims.p_layers * layer_b * (tdims.n_groups - 2) * n_frames / 1e9          # 15 reads per frame, 14 of them re-reads
+        f = fams["gemm_dec"]
+        once_gb = max(f["algorithmic_gb_per_step"] - reread_gb, 0.0)
+        f["frac_predictor_weights_once_per_frame"] = round(f["frac"] * once_gb / max(f["algorithmic_gb_per_step"], 1e-9), 4)
+        f["predictor_weight_rereads_gb_per_step"] = round(reread_gb, 2)
     if args.breakdown:
         for k, f in fams.items():
             print(f"[breakdown] {k}: {f['kernel_ms_per_step']} ms/step, {f['launches_per_step']} launches, avg {f['avg_kernel_us']} us, {f['achieved']} {f['unit']} ({f['frac']:.3f})", file=sys.stderr)
@@ -788,10 +798,10 @@ def main():
         roof = dict(fams[dom])
         roof["traffic"] = None
         # HBM traffic of the dominant family from the PMC counters: FETCH_SIZE (x2 on gfx950 for 16 B/lane streaming reads) + WRITE_SIZE,
-        # separate rocprofv3 --pmc passes over a REDUCED step of this same bench (tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json);
+        # separate rocprofv3 --pmc passes over a REDUCED step of this same bench (tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json);
         # the measured / algorithmic ratio of that run is applied to this run's algorithmic bytes per launch
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), "")
+        if pmc_path:
             pm = json.load(open(pmc_path)).get(dom)
             if pm:
                 per_launch = fams[dom]["algorithmic_gb_per_step"] * 1e9 / max(fams[dom]["launches_per_step"], 1)
@@ -799,7 +809,8 @@ def main():
                 roof["traffic_note"] = (f"bytes per launch = {pm['hbm_over_algorithmic']:.3f} x this run's algorithmic bytes per launch; ratio measured with rocprofv3 --pmc "
                                         f"FETCH_SIZE / WRITE_SIZE (separate passes) over a reduced step of this bench ({pm.get('command', '')})")
         roof["families"] = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "kernel_ms_per_step", "avg_kernel_us",
-                                                     "algorithmic_gb_per_step", "algorithmic_tflop_per_step")}
+                                                     "algorithmic_gb_per_step", "algorithmic_tflop_per_step", "frac_predictor_weights_once_per_frame",
+                                                     "predictor_weight_rereads_gb_per_step") if kk in v}
                             for k, v in fams.items()}
         roof["sampled_over"] = (f"{n_prof} extra step(s) of the same workload right after the timed region, plain stream launches on one stream; durations = "
                                 "the kernels' own begin/end timestamps (hipExtLaunchKernelGGL events, the quantity rocprofv3 --kernel-trace reports) - nothing subtracted")

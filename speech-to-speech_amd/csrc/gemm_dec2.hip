@@ -30,6 +30,7 @@
 // bf16 copy and ONE partial sum of squares per column block (n_parts = N / BN instead of N / 16).
 #include "ops.h"
 
+#include <cmath>
 #include <type_traits>
 
 namespace s2s {
@@ -111,13 +112,14 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     const int t0 = (cb * D2_NW + wave) * NT;            // this wave's first column tile
 
     // reciprocal RMS of the input rows (gamma is folded into W): 4 threads per row, <= 64 partial sums per row.  The loads are issued
-    // HERE, ahead of the weight stream, and reduced once the stream is in flight (they are the oldest loads: waiting for them never
-    // waits for HBM).  Branch-free on purpose - without ss_in the same loads read row 0 of A and the result is ignored: a branch
-    // around loads makes hipcc's wait counts conservative (vmcnt(0)) for everything issued after it.
+    // BEHIND the first weight / activation loads (the HBM latency of the weights is the long pole of the launch - phase timestamps,
+    // profiles/r03_decode_gemm_phases.txt - so they go first; everything is waited for together before the first MFMA anyway).
+    // Branch-free on purpose - without ss_in the same loads read row 0 of A and the result is ignored: a branch around loads makes
+    // hipcc's wait counts conservative (vmcnt(0)) for everything issued after it.
     constexpr int RH = (MT * 16 * 4 + D2_NW * 64 - 1) / (D2_NW * 64);
     constexpr int RP = 16;
     float sv[RH][RP];
-    {
+    auto sv_load = [&]() {
         const bool has = a.ss_in != nullptr;
         const float* base = has ? a.ss_in : reinterpret_cast<const float*>(a.A);
         const long ssrs = has ? (a.ss_rs > 0 ? a.ss_rs : 1) : 0, sst = has ? a.ss_stride : 0;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
             for (int j = 0; j < RP; ++j) sv[h][j] = src[(long)min((e & 3) + 4 * j, np1) * sst];
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
     auto rstd_reduce = [&]() {
 #pragma unroll
         for (int h = 0; h < RH; ++h) {
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     };
 
     if constexpr (NCH == 1) {
-        load_a(0, 0);
         load_w(0, 0);
+        load_a(0, 0);
+        sv_load();
         rstd_reduce();
         stamp(7);
         store_a(0, 0);
@@ -247,10 +250,11 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         compute(0);
     } else if constexpr (NCH == 2) {
         // the whole slice in flight at once: activations (L2) first, then the weight stream; ONE barrier
-        load_a(0, 0);
-        load_a(1, 1);
         load_w(0, 0);
         load_w(1, 1);
+        load_a(0, 0);
+        load_a(1, 1);
+        sv_load();
         rstd_reduce();
         stamp(7);
         store_a(0, 0);
@@ -259,8 +263,9 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
         stamp(1);
         compute_seq(I0{}, I2{});
     } else if (nch == 1) {
-        load_a(0, 0);
         load_w(0, 0);
+        load_a(0, 0);
+        sv_load();
         rstd_reduce();
         stamp(7);
         store_a(0, 0);
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(D2_NW * 64) void gemm_dec2_kernel(DecGemm a, Dec2Pl
     } else {
         // two chunks in flight from the start; in the steady state the activations run two chunks ahead of the MFMAs (registers
         // -> LDS one chunk ahead) and the weights one to two chunks ahead
-        load_a(0, 0);
         load_w(0, 0);
-        load_a(1, 1);
+        load_a(0, 0);
         load_w(1, 1);
+        load_a(1, 1);
+        sv_load();
         rstd_reduce();
         stamp(7);
         store_a(0, 0);
@@ -584,37 +590,42 @@ static Dec2Choice dec2_choose(const DecGemm& a) {
     const int Mslab = a.M > 128 ? 128 : a.M;
     c.rslabs = a.M > 128 ? a.M / 128 : 1;
     c.MT = Mslab <= 64 ? 4 : 8;
-    c.KC = c.MT == 4 ? 8 : 4;
-    const int steps = a.K / 32;
-    if (steps % c.KC != 0) return c;
-    const int chunks = steps / c.KC;
     const int ntiles = (a.N + 15) / 16;
     int nt = t.nt > 0 ? t.nt : 1;
-    if (t.nt == 0 && !a.glu && c.MT == 8 && ntiles >= 2 * D2_NW * 48) nt = 2;       // 128-column blocks when there are enough of them
     if (a.glu) nt = 1;
+    // chunk length: 8 k-steps for 64-row slabs, 4 for 128-row slabs.  (With two weight streams per wave - SwiGLU, 128-column blocks -
+    // the 8-step chunk loop needs 272 VGPRs and spills 32; 4-step chunks removed the spill and measured 12 % SLOWER on the talker's
+    // gate/up projection - twice the barriers - so the spill stays.)
+    c.KC = c.MT == 4 ? 8 : 4;
+    const int steps = a.K / 32;
+    const int KS = c.MT == 4 ? 8 : 4;              // granularity of the K-slice choice (k-steps): the sweep's units
+    if (steps % KS != 0) return c;
+    const int chunks = steps / KS;
+    if (t.nt == 0 && !a.glu && c.MT == 8 && ntiles >= 2 * D2_NW * 48) nt = 2;       // 128-column blocks when there are enough of them
     c.NT = nt;
     c.ncb = (ntiles + D2_NW * nt - 1) / (D2_NW * nt);
-    // K-slices: slices of one or two chunks run the straight-line schedule (every load of the slice in flight at once); among those
-    // the fewest slices that still give about one workgroup per CU.  Shapes that cannot be cut that way (few chunks that do not
-    // divide, or so many column blocks that one slice per block fills the chip) run the chunk loop.
+    // K-slices: the slice count that brings the launch closest to one workgroup per CU (256), measured over the sweep of
+    // profiles/r03_microbench_decode_gemm.txt: gate/up 96 column blocks -> 2 slices (192 workgroups; 4 slices = 384 is 20 % slower),
+    // down 32 blocks -> 8 slices, Whisper fc1 80 blocks -> 5 slices (400), the 811-block logits -> 1.  Slices of one or two chunks
+    // additionally run the straight-line schedule (every load of the slice in flight at once).
     int sk = 1;
     if (t.splitk > 0) sk = t.splitk;
     else {
         const int items = c.ncb * c.rslabs;
-        int best = 0;
-        for (int f = 1; f <= 12; ++f) {
-            if (chunks % f != 0 || chunks / f > 2) continue;
-            best = f;
-            if (items * f >= 192) break;
-        }
-        if (best > 0 && items < 512) sk = best;
-        else {
-            while (sk < 8 && items * sk < 192 && chunks % (sk * 2) == 0) sk *= 2;
+        double best_d = 1e30;
+        for (int f = 1; f <= 16 && f <= chunks; ++f) {
+            if (chunks % f != 0) continue;
+            const double r = (double)items * f / 256.0;
+            const double dd = r >= 1.0 ? r : 1.0 / r;
+            if (dd < best_d - 1e-9 || (fabs(dd - best_d) <= 1e-9 && f > sk)) {
+                best_d = dd;
+                sk = f;
+            }
         }
     }
     if (sk < 1 || chunks % sk != 0) sk = 1;
     c.splitk = sk;
-    c.nch = chunks / sk;
+    c.nch = (steps / sk) / c.KC;
     return c;
 }
 

@@ -185,8 +185,21 @@ class WhisperEngine:
     # ---- stages ---------------------------------------------------------------------------
     def features(self, audios: Sequence[np.ndarray]) -> torch.Tensor:
         """float32 utterances -> encoder-layout log-mel [B][3002][n_mels] in the model dtype."""
-        pcm, ns = pack_pcm(audios, self.device, max_len=480000)
         B = len(audios)
+        # engine-owned pinned staging block (a pinned allocation per batch would synchronise the device under the TTS lanes); the previous
+        # batch's copy out of it completed before its results were read back
+        lens = [min(len(a), 480000) for a in audios]
+        stride = max(8, (max(lens) + 7) // 8 * 8) if lens else 8
+        if getattr(self, "_pcm_host", None) is None or self._pcm_host.numel() < B * stride:
+            self._pcm_host = torch.empty((max(B, self.max_batch) * max(stride, 160000),), dtype=torch.float32, pin_memory=True)
+            self._ns_host = torch.empty((max(B, self.max_batch),), dtype=torch.int32, pin_memory=True)
+        host = self._pcm_host[: B * stride].view(B, stride)
+        for i, (a, n) in enumerate(zip(audios, lens)):
+            host[i, :n] = torch.from_numpy(np.ascontiguousarray(a[:n], dtype=np.float32))
+            host[i, n:] = 0.0
+        self._ns_host[:B] = torch.tensor(lens, dtype=torch.int32)
+        pcm = host.to(self.device, non_blocking=True)
+        ns = self._ns_host[:B].to(self.device, non_blocking=True)
         out = torch.empty((B, 3002, self.dims.n_mels), dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             native.check(self._lib.s2s_logmel_whisper_tm(self.frontend._handle, native.stream_handle(), native.ptr(pcm),
@@ -210,9 +223,13 @@ class WhisperEngine:
     def _mask(self, ids: Sequence[int] | None, invert: bool = False):
         if ids is None or len(ids) == 0:
             return None
-        m = torch.ones(self.dims.vocab, dtype=torch.uint8) if invert else torch.zeros(self.dims.vocab, dtype=torch.uint8)
-        m[list(ids)] = 0 if invert else 1
-        return m.to(self.device)
+        key = (tuple(int(i) for i in ids), bool(invert))
+        cache = self.__dict__.setdefault("_mask_cache", {})
+        if key not in cache:          # the masks of a vocabulary never change: built and uploaded once
+            m = torch.ones(self.dims.vocab, dtype=torch.uint8) if invert else torch.zeros(self.dims.vocab, dtype=torch.uint8)
+            m[list(key[0])] = 0 if invert else 1
+            cache[key] = m.to(self.device)
+        return cache[key]
 
     def decode(self, prompts: Sequence[Sequence[int]], eos: int, max_new_tokens: int, suppress: Sequence[int] | None = None,
                begin_suppress: Sequence[int] | None = None, lang_ids: Sequence[int] | None = None, min_steps: int = 0,
