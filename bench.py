@@ -91,7 +91,9 @@ def parse(argv=None):
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
     ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
     ap.add_argument("--tts-lead-s", type=float, default=float("inf"), help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
+    ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
+    ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
     ap.add_argument("--max-probes", type=int, default=6, help="open-loop probes of the sustained-sessions bisection")
     ap.add_argument("--turn-batches", action="store_true", help="open-loop probe with round-2 turn-batch TTS lanes instead of continuous batching (A/B)")
     ap.add_argument("--pool-lanes", type=int, default=3, help="TTS lanes of the SessionPool in the open-loop probe (measured: 6 lanes contend and are slower than 3)")
@@ -331,7 +333,7 @@ def _rand_tts_sd(dims, g):
 
 
 # --------------------------------------------------------------------------------------------- boundary probe
-def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf")):
+def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -350,7 +352,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     from speech_to_speech_amd.text import IdTextCodec, WhisperVocab
 
     B = tts_engine.max_batch
-    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s)
+    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
@@ -404,6 +406,8 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
                             "blocks": n_blocks, "late": late})
 
     rng = np.random.default_rng(seed)
+    cpu0 = os.times()
+    t_wall0 = time.perf_counter()
     t0 = time.perf_counter() + 0.2
     arrivals = []
     if n_sessions == 1:       # an idle system: a few turns of one session, spaced far enough apart to never overlap
@@ -427,6 +431,8 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
             pass
     ex.shutdown(wait=False, cancel_futures=True)
     stats = dict(pool.stats)
+    cpu1 = os.times()
+    stats["host_cores_busy"] = round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(time.perf_counter() - t_wall0, 1e-9), 2)
     pool.shutdown(close_engines=False)      # fails whatever is still queued, stops the lanes, closes the lane replicas; the bench's engines stay open
     torch.cuda.synchronize(dev)
     win = [r for r in results if r["in_window"]]
@@ -441,7 +447,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     res = {"sessions": n_sessions, "turns_arrived": n_arr, "turns_completed": full, "blocks_expected_per_turn": want_blocks,
            "min_blocks_per_turn": blocks[0] if blocks else None, "median_blocks_per_turn": blocks[len(blocks) // 2] if blocks else None,
            "pool": {k: (round(stats[k], 2) if isinstance(stats[k], float) else stats[k]) for k in ("stt_batches", "max_stt_batch", "tts_batches", "tts_requests", "stt_busy_s",
-                                                                                                    "tts_rounds", "tts_round_s", "tts_admit_s", "tts_row_rounds") if k in stats},
+                                                                                                    "tts_rounds", "tts_round_s", "tts_admit_s", "tts_row_rounds", "host_cores_busy") if k in stats},
            "p50_ttfa_ms": None, "p95_ttfa_ms": None, "max_playback_lag_ms": None}
     if win:
         stt_l = np.array([r["stt"] for r in win]) * 1e3
@@ -720,10 +726,11 @@ def main():
     if not args.no_boundary and tts is not None and wl in ("c3", "c1", "c2", "tiny"):
         try:
             lanes = max(1, args.pool_lanes)
+            sys.setswitchinterval(max(1e-4, args.gil_switch_ms * 1e-3))
 
             def probe(n, window=args.boundary_seconds):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
-                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s)
+                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first)
 
             single = probe(1, window=12.0)
             best, tried = (None, [])

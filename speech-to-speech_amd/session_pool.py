@@ -79,7 +79,7 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf")):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -87,6 +87,9 @@ class SessionPool:
         # measured on C3 (profiles/r03_open_loop_ab.txt) pacing at 1-2 s raises the rows per round but does NOT raise the STT service rate,
         # which is what bounds the sustained session count - p95 TTFA at 900 sessions 958 ms eager vs 3.3 s paced at 2 s.
         self.tts_lead_s = float(tts_lead_s)
+        # lane admission policy: 0 = the least loaded lanes take new sessions (spreads them over all lanes); T > 0 = fill first: lane k only
+        # takes new sessions once every lane below it holds at least T live sessions (fewer frame loops running, fuller rows)
+        self.tts_fill_first = int(tts_fill_first)
         self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
         self._lane_live: dict[int, int] = {}     # live sessions per continuous lane (load balancing between lanes)
         self.tts_lanes = max(1, int(tts_lanes))
@@ -386,9 +389,14 @@ class SessionPool:
         stop = False
         while True:
             self._lane_live[lane] = cb.live + len(backlog)
+            T = self.tts_fill_first
+            lower_full = T <= 0 or all(self._lane_live.get(j, 0) >= T for j in range(lane))
             if not cb.cohorts and not backlog:
                 if stop or self._stopping:
                     return
+                if not lower_full:               # fill first: an idle upper lane leaves the queue to the lanes below it
+                    time.sleep(0.002)
+                    continue
                 try:
                     it = self._tts_q.get(timeout=0.05)
                 except queue.Empty:
@@ -400,7 +408,7 @@ class SessionPool:
                     time.sleep(self.batch_window_s)
             others = [v for k, v in self._lane_live.items() if k != lane]
             room = cb.free_slots - len(backlog)
-            if room > 0 and not stop and (not others or cb.live + len(backlog) <= min(others) + 8):
+            if room > 0 and not stop and ((T > 0 and lower_full) or (T <= 0 and (not others or cb.live + len(backlog) <= min(others) + 8))):
                 for it in self._drain(self._tts_q, room):
                     if it is _STOP:
                         stop = True
