@@ -14,6 +14,7 @@
 
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -104,6 +105,8 @@ struct Tts {
     int next_utt = 1;                  // utterance ids handed out by the legacy prefill
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
+    std::mutex graphs_mu;                       // frame_graphs is read by the lane thread and replaced by s2s_tts_set_sampling
+    std::vector<hipGraphExec_t> retired_graphs; // executables replaced while a stream may still be replaying them: destroyed with the engine
     std::vector<void*> head_n;         // code-predictor heads, fragment-major with pred.norm folded in (bf16 decode path)
     void* in_proj_f = nullptr;         // fragment-major pred.in_proj.w
     // norm-free decode path (gemm_dec.hip): bf16 copy of the residual rows + two partial-sum-of-squares buffers
@@ -594,10 +597,13 @@ static int frame_body(Tts* m, hipStream_t st, int B) {
 
 // captured frame body for batch size B (built on first use; the arena and the weights never move after finalize)
 static int frame_graph(Tts* m, int B, hipGraphExec_t* out) {
-    auto it = m->frame_graphs.find(B);
-    if (it != m->frame_graphs.end()) {
-        *out = it->second;
-        return S2S_OK;
+    {
+        std::lock_guard<std::mutex> g(m->graphs_mu);
+        auto it = m->frame_graphs.find(B);
+        if (it != m->frame_graphs.end()) {
+            *out = it->second;
+            return S2S_OK;
+        }
     }
     std::lock_guard<std::mutex> capture_lock(capture_mutex());
     if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
@@ -614,7 +620,10 @@ static int frame_graph(Tts* m, int B, hipGraphExec_t* out) {
     const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     S2S_HIP_CHECK(ie);
-    m->frame_graphs[B] = exec;
+    {
+        std::lock_guard<std::mutex> g(m->graphs_mu);
+        m->frame_graphs[B] = exec;
+    }
     *out = exec;
     return S2S_OK;
 }
@@ -647,6 +656,7 @@ extern "C" int32_t s2s_tts_destroy(void* model) {
     for (void* p : m->owned) (void)hipFree(p);
     for (void* p : m->cstate) (void)hipFree(p);
     for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (hipGraphExec_t e : m->retired_graphs) (void)hipGraphExecDestroy(e);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return S2S_OK;
@@ -830,8 +840,11 @@ extern "C" int32_t s2s_tts_set_sampling(void* model, int32_t which, float temper
     S2S_REQUIRE(top_k >= 0 && top_p > 0.f && repetition_penalty > 0.f, "tts_set_sampling: top_k >= 0, top_p > 0, repetition_penalty > 0");
     SampleParams sp{temperature, top_k, top_p, repetition_penalty, (unsigned long long)seed};
     (which == 0 ? m->sp_talker : m->sp_pred) = sp;
+    // the captured graphs hold the old parameters by value: they are RETIRED, not destroyed - a lane's stream may still be replaying
+    // one (destroying it there would be a use-after-free); the next generate / step call captures again
     std::lock_guard<std::mutex> capture_lock(capture_mutex());
-    for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
+    std::lock_guard<std::mutex> g(m->graphs_mu);
+    for (auto& kv : m->frame_graphs) m->retired_graphs.push_back(kv.second);
     m->frame_graphs.clear();
     return S2S_OK;
 }

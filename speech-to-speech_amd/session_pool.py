@@ -408,7 +408,16 @@ class SessionPool:
                     time.sleep(self.batch_window_s)
             others = [v for k, v in self._lane_live.items() if k != lane]
             room = cb.free_slots - len(backlog)
-            if room > 0 and not stop and ((T > 0 and lower_full) or (T <= 0 and (not others or cb.live + len(backlog) <= min(others) + 8))):
+            mine = cb.live + len(backlog)
+            least = not others or mine <= min(others) + 8
+            if T > 0:        # fill first: up to T sessions per lane in lane order; once every lane holds T, the least loaded ones take the rest
+                n_lanes = max(self.tts_lanes, lane + 1)
+                all_full = mine >= T and all(self._lane_live.get(j, 0) >= T for j in range(n_lanes))
+                take = lower_full and (mine < T or (all_full and least))
+                room = min(room, T - mine) if mine < T else room
+            else:
+                take = least
+            if room > 0 and not stop and take:
                 for it in self._drain(self._tts_q, room):
                     if it is _STOP:
                         stop = True

@@ -287,3 +287,94 @@ def test_continuous_tts_slot_allocator_prefers_contiguous_runs():
     cb._give(0, 3)
     cb._give(3, 5)
     assert cb.free == [(0, 8)]
+
+
+class _StubTTSEngine:
+    """Records what the continuous-batching scheduler asks of an engine and answers with deterministic 'audio' (no GPU): slot s of a
+    cohort that has produced f frames yields chunks whose samples encode (utterance id, frame)."""
+
+    class _Dims:
+        total_upsample, n_groups, t_hidden = 12, 2, 4
+
+    max_batch, max_frames = 8, 32
+    dims = _Dims()
+
+    def __init__(self):
+        self.log, self.slots = [], {}
+
+    def release(self, s0, n):
+        self.log.append(("release", s0, n))
+        for s in range(s0, s0 + n):
+            self.slots.pop(s, None)
+
+    def admit(self, prompts, s0, budgets, mins, utterance_id0=0):
+        self.log.append(("admit", s0, len(prompts)))
+        for i in range(len(prompts)):
+            assert s0 + i not in self.slots, "slot admitted twice"
+            self.slots[s0 + i] = {"utt": utterance_id0 + i, "frames": 0, "budget": budgets[i], "eos": getattr(prompts[i], "eos_at", None)}
+
+    def step(self, rows, n):
+        self.log.append(("step", rows, n))
+        for s, st in self.slots.items():
+            assert s < rows, "a live slot lies outside the stepped rows"
+            lim = st["budget"] if st["eos"] is None else min(st["budget"], st["eos"])
+            st["frames"] = min(st["frames"] + n, lim)
+
+
+def test_continuous_tts_scheduler_admits_retires_and_orders_cohorts(monkeypatch):
+    """ContinuousTTS on a stub engine (pure host logic): contiguous slot ranges, row buckets, youngest cohort first, one end marker per
+    job, budgets and eos inside a chunk, cancellation, slots returned and reused."""
+    import types
+
+    import numpy as np
+    import torch
+
+    from speech_to_speech_amd import tts_continuous as TC
+
+    eng = _StubTTSEngine()
+    up, chunk = eng.dims.total_upsample, 4
+    order = []
+
+    def read_codes(s0, n, f0, F):
+        order.append(("decode", s0, f0))
+        nfr = torch.tensor([eng.slots[s0 + i]["frames"] for i in range(n)], dtype=torch.int32)
+        nval = torch.tensor([max(0, min(int(v) - f0, F)) * up for v in nfr], dtype=torch.int32)
+        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
+
+    eng.read_codes = read_codes
+    eng.codec_decode_rows = lambda codes, s0, fd: torch.zeros((codes.shape[0], codes.shape[1] * up))
+    eng.resample_int16 = lambda wav, nvalid=None: torch.full((wav.shape[0], (2 * wav.shape[1] + 2) // 3), 7, dtype=torch.int16)
+
+    class _Ev:
+        def record(self):
+            pass
+
+        def synchronize(self):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(TC.ContinuousTTS, "_host", lambda self, key, shape, dtype: torch.empty(tuple(shape), dtype=dtype))
+    cb = TC.ContinuousTTS(eng, chunk_size=chunk)
+    mk = lambda budget, eos=None: TC.TTSJob(types.SimpleNamespace(eos_at=eos), budget)      # noqa: E731
+    a, b, c = mk(8), mk(6), mk(12, eos=5)
+    assert cb.admit([a, b]) == [] and cb.live == 2 and cb.free == [(2, 6)] and cb.rows() == 8
+    ev = list(cb.step())
+    assert [(j is a, j is b) for j, ch in ev if ch is not None] == [(True, False), (False, True)] and all(ch is None or len(ch) == (2 * chunk * up + 2) // 3 for _, ch in ev)
+    assert cb.admit([c]) == []                       # joins one chunk later, in the next free slots
+    order.clear()
+    ev = list(cb.step())
+    assert order[0] == ("decode", 2, 0) and order[1] == ("decode", 0, 4)            # the youngest cohort (first chunk) is decoded first
+    got = {id(j): [ch for jj, ch in ev if jj is j] for j in (a, b, c)}
+    assert got[id(a)][-1] is None and len(got[id(a)]) == 2                          # budget 8 = two full chunks, then the end marker
+    assert got[id(b)][-1] is None and len(got[id(b)][0]) == (2 * 2 * up + 2) // 3   # budget 6: two frames of the second chunk
+    assert len(got[id(c)]) == 1 and got[id(c)][0] is not None                       # c goes on
+    assert ("release", 0, 2) in eng.log and cb.free == [(0, 2), (3, 5)]
+    d = mk(16)
+    left = cb.admit([d] + [mk(4) for _ in range(7)])          # 7 free slots in two ranges: two more cohorts, one job does not fit and is handed back
+    assert len(left) == 1 and cb.free == [] and cb.stats["cohorts"] == 4
+    ev = list(cb.step())                              # c: eos at frame 5 -> one frame of its second chunk, end marker, slot freed
+    assert [ch is None for jj, ch in ev if jj is c] == [False, True]
+    d.cancelled.set()
+    ev = list(cb.drain())
+    assert sum(1 for jj, ch in ev if jj is d and ch is None) == 1 and not any(jj is d and ch is not None for jj, ch in ev)
+    assert cb.live == 0 and cb.free == [(0, 8)] and all(k[0] != "step" or k[1] == 8 for k in eng.log)

@@ -5,7 +5,7 @@ O=$R/gpurun_out/r3o
 mkdir -p $O
 cd $R
 for f in 0 48; do
-timeout 500 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --probe-sessions 600,800,950 --tts-fill-first $f --prof-steps 0 > $O/bench_f$f.json 2> $O/bench_f$f.err; tail -2 $O/bench_f$f.err
+timeout 500 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --probe-sessions 800,950,1050 --tts-fill-first $f --prof-steps 0 > $O/bench_f$f.json 2> $O/bench_f$f.err; tail -2 $O/bench_f$f.err
 done
 python - <<'PY'
 import json, glob
