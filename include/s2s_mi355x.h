@@ -70,6 +70,10 @@ double s2s_prof_event_overhead_us(void);
  * the same results); graphs are also bypassed while kernel timing is enabled.  Default on; the environment
  * variable S2S_NO_GRAPHS=1 starts with it off. */
 int32_t s2s_graphs_enable(int32_t on);
+/* A HIP stream restricted to cus_per_8 of every 8 consecutive compute units (hipExtStreamCreateWithCUMask; 8 = all CUs).  For hosts
+ * that run the latency-bound TTS lanes next to the STT encoder on one GPU (speech-to-speech_amd/session_pool.py `tts_lane_cus`). */
+int32_t s2s_stream_create_masked(int32_t cus_per_8, void** out_stream);
+int32_t s2s_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Log-mel front-ends.

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "s2s_device_count": [],
     "s2s_prof_enable": [C.c_uint32],
     "s2s_graphs_enable": [_i32],
+    "s2s_stream_create_masked": [_i32, C.POINTER(_vp)],
+    "s2s_stream_destroy": [_vp],
     "s2s_prof_event_overhead_us": [],
     "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],

@@ -79,7 +79,7 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -90,6 +90,8 @@ class SessionPool:
         # lane admission policy: 0 = the least loaded lanes take new sessions (spreads them over all lanes); T > 0 = fill first: lane k only
         # takes new sessions once every lane below it holds at least T live sessions (fewer frame loops running, fuller rows)
         self.tts_fill_first = int(tts_fill_first)
+        # CU mask of the TTS lanes' streams: lanes run on `tts_lane_cus` of every 8 compute units (8 = all, no mask)
+        self.tts_lane_cus = int(tts_lane_cus)
         self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
         self._lane_live: dict[int, int] = {}     # live sessions per continuous lane (load balancing between lanes)
         self.tts_lanes = max(1, int(tts_lanes))
@@ -326,7 +328,7 @@ class SessionPool:
         self._lane_replicas.append(rep)
         return rep
 
-    def _lane_stream_ctx(self, priority: int = 0):
+    def _lane_stream_ctx(self, priority: int = 0, cus_per_8: int = 8):
         """Every lane issues its GPU work on its own HIP stream (no-op for devices torch does not know, e.g. test doubles)."""
         import contextlib
 
@@ -336,6 +338,14 @@ class SessionPool:
             dev = torch.device(self.device)
             if dev.type == "cuda" and torch.cuda.is_available():
                 torch.cuda.set_device(dev)
+                if 1 <= cus_per_8 < 8:           # a stream confined to a subset of the CUs (created by the library, wrapped for torch)
+                    import ctypes as C
+
+                    from . import native
+
+                    h = C.c_void_p()
+                    native.check(native.load().s2s_stream_create_masked(int(cus_per_8), C.byref(h)), "s2s_stream_create_masked")
+                    return torch.cuda.stream(torch.cuda.ExternalStream(h.value, device=dev))
                 # (no device-wide synchronise here: it would collide with another lane's stream capture; the worker that builds an
                 # engine synchronises ITS stream before the build is reported done)
                 return torch.cuda.stream(torch.cuda.Stream(device=dev, priority=priority))
@@ -362,7 +372,7 @@ class SessionPool:
             eng = None
         if eng is None:
             return None, None
-        ctx = self._lane_stream_ctx()
+        ctx = self._lane_stream_ctx(0, self.tts_lane_cus)
         ctx.__enter__()
         with self._stats_lock:
             self.stats["tts_lanes_used"] += 1
