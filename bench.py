@@ -479,7 +479,9 @@ def sustained_search(probe, n_hint, bound_ms, max_probes=6, start=0.7):
             n = int(n * 1.25) if hi is None else (n + hi) // 2
         else:
             hi = n
-            n = (lo + n) // 2 if lo else max(1, n // 2)
+            # nothing sustained yet: a near miss (everything completed, p95 within 1.5 x the bound) steps down by 20 %, a clear miss halves
+            near = r["turns_completed"] >= r["turns_arrived"] and r["p95_ttfa_ms"] is not None and r["p95_ttfa_ms"] <= 1.5 * bound_ms
+            n = (lo + n) // 2 if lo else max(1, int(n * 0.8) if near else n // 2)
         if n <= lo or (hi is not None and hi - lo <= max(4, lo // 20)):
             break
     return best, tried
