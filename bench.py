@@ -69,6 +69,19 @@ def reduce_step_time(dt: float) -> float:
     return float(t.item())
 
 
+def sum_over_ranks(count: int) -> int:
+    """Whole-job sustained session count: every rank probes its own GPU's pool (sessions are pinned to a pool, nothing is exchanged on the
+    data path); the per-rank counts are summed over gloo.  A rank whose probe failed contributes 0 - and still takes part in the reduce."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(count)
+    t = torch.tensor([int(count)], dtype=torch.int64)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -519,8 +532,10 @@ def main():
         if world > 1:
             dist.barrier()
         mx = reduce_step_time(0.1 * (rank + 1))
+        sustained = sum_over_ranks(100 * (rank + 1))        # (stands in for the per-rank open-loop figures)
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "dry_run": True, "max_step_s": mx, "sessions": [shard_sessions(args.sessions or 4, r) for r in range(world)]}))
+            print(json.dumps({"n_gpus": world, "dry_run": True, "max_step_s": mx, "sustained_sum": sustained,
+                              "sessions": [shard_sessions(args.sessions or 4, r) for r in range(world)]}))
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -742,13 +757,7 @@ def main():
             elif B > 1:
                 best, tried = sustained_search(probe, xrt / world, args.ttfa_bound_ms, max_probes=args.max_probes)
             mine = 0 if best is None else int(best["sessions"])
-            total = mine
-            if world > 1:
-                import torch.distributed as dist
-
-                tsum = torch.tensor([mine], dtype=torch.int64)
-                dist.all_reduce(tsum)            # gloo, host scalar: the sum of the ranks' sustained session counts
-                total = int(tsum.item())
+            total = sum_over_ranks(mine)         # gloo, host scalar: the sum of the ranks' sustained session counts
             boundary = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, STT batches of up to "
                                 f"{MB} sessions, {lanes} TTS lanes x {MB} slots, " + ("turn-batches" if args.turn_batches else "continuous batching at chunk boundaries")
                                 + f") -> C ABI; uniform-phase staggered turn arrivals, {args.boundary_seconds:g} s window per probe",
@@ -760,10 +769,7 @@ def main():
                                     "p95 TTFA <= bound; bisected to about +-5 %"}
         except Exception as ex:  # pragma: no cover
             boundary = {"error": repr(ex)}
-            if world > 1:
-                import torch.distributed as dist
-
-                dist.all_reduce(torch.tensor([0], dtype=torch.int64))
+            sum_over_ranks(0)
     if rank != 0:
         return
     sustained = (boundary or {}).get("sustained_sessions")

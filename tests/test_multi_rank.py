@@ -15,15 +15,16 @@ def test_two_rank_gloo_aggregation(tmp_path):
         import os, sys, json
         sys.path.insert(0, {ROOT!r})
         import torch, torch.distributed as dist
-        from bench import shard_sessions, reduce_step_time
+        from bench import shard_sessions, reduce_step_time, sum_over_ranks
         dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
         rank, world = dist.get_rank(), dist.get_world_size()
         ids = shard_sessions(per_gpu=5, rank=rank)
         t = reduce_step_time(0.1 * (rank + 1))
+        total = sum_over_ranks(7 + rank)
         gathered = [None] * world
         dist.all_gather_object(gathered, ids)
         if rank == 0:
-            print(json.dumps({{"t": t, "ids": gathered}}))
+            print(json.dumps({{"t": t, "ids": gathered, "total": total}}))
         dist.destroy_process_group()
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -35,6 +36,7 @@ def test_two_rank_gloo_aggregation(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert abs(r["t"] - 0.2) < 1e-9                       # MAX over ranks
+    assert r["total"] == 15                               # per-rank sustained counts are summed
     flat = [i for ids in r["ids"] for i in ids]
     assert sorted(flat) == list(range(10)) and len(set(flat)) == 10   # disjoint session shards, weak scaling
 
@@ -53,3 +55,4 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and abs(r["max_step_s"] - 0.2) < 1e-9 and r["sessions"] == [[0, 1, 2], [3, 4, 5]]
+    assert r["sustained_sum"] == 300                      # the whole-job sustained figure is the SUM of the ranks' open-loop figures
