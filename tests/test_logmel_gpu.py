@@ -106,3 +106,20 @@ def test_smart_turn_features_match_oracle_and_golden(golden_dir):
     one = an.predict(audios[0])
     assert one.complete is False and abs(one.probability - 0.2) < 1e-9 and one.inference_ms > 0
     an.features.close()
+
+    # the reference's own predict() test (tests/test_smart_turn.py:208-236) with its fake ONNX session behind the adapter
+    class FakeSession:
+        def __init__(self):
+            self.feeds = []
+
+        def run(self, _outputs, feeds):
+            self.feeds.append(feeds)
+            return [np.array([[0.75]], dtype=np.float32)]
+
+    sess = FakeSession()
+    an2 = MI355XSmartTurnAnalyzer(lambda f: sess.run(None, {"input_features": f})[0], threshold=0.5, max_batch=2, warmup=False)
+    result = an2.predict(np.ones(100, dtype=np.float32))
+    assert result.complete is True and result.probability == 0.75
+    feats = sess.feeds[0]["input_features"]
+    assert feats.shape == (1, 80, 800) and feats.dtype == np.float32
+    an2.features.close()

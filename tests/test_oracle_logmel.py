@@ -97,3 +97,21 @@ def test_smart_turn_prepare_audio_keeps_the_last_eight_seconds():
         prepare_audio(np.zeros((2, 10), np.float32))
     # other rates are resampled on the host exactly as the reference does (scipy.signal.resample_poly)
     assert prepare_audio(np.zeros(48000, np.float32), 48000).shape == (128000,)
+
+
+def test_smart_turn_prepare_audio_known_answers_of_the_reference_tests():
+    """The reference's own cases (tests/test_smart_turn.py:131-148) on the adapter's `prepare_audio`."""
+    from speech_to_speech_amd.smart_turn import MAX_AUDIO_SECONDS, MODEL_SAMPLE_RATE, prepare_audio
+
+    max_samples = MAX_AUDIO_SECONDS * MODEL_SAMPLE_RATE
+    short_audio = np.arange(100, dtype=np.float32)
+    prepared_short = prepare_audio(short_audio, MODEL_SAMPLE_RATE)
+    assert prepared_short.shape == (max_samples,)
+    np.testing.assert_array_equal(prepared_short[-100:], short_audio)
+    assert np.count_nonzero(prepared_short[:-100]) == 0
+    long_audio = np.arange(max_samples + 10, dtype=np.float32)
+    np.testing.assert_array_equal(prepare_audio(long_audio, MODEL_SAMPLE_RATE), long_audio[-max_samples:])
+    prepared = prepare_audio(np.ones(8000, dtype=np.float32), sample_rate=8000)
+    assert prepared.shape == (max_samples,) and np.count_nonzero(prepared[-MODEL_SAMPLE_RATE:]) > 0
+    with pytest.raises(ValueError):
+        prepare_audio(np.ones(10, np.float32), 0)
