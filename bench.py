@@ -751,6 +751,8 @@ def main():
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus)
 
             single = probe(1, window=12.0)
+            if B > 1 and not args.probe_sessions:
+                probe(max(8, int(0.3 * xrt / world)), window=5.0)      # untimed warm-up at a moderate load: allocator pools and batch shapes of a loaded pool
             best, tried = (None, [])
             if args.probe_sessions:      # fixed probes (A/B runs), no search
                 tried = [probe(int(n)) for n in args.probe_sessions.split(",")]

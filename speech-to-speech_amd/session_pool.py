@@ -390,6 +390,9 @@ class SessionPool:
         from .tts_continuous import ROW_BUCKETS, ContinuousTTS
 
         cb = ContinuousTTS(eng, chunk_size=self.tts_chunk_size)
+        if hasattr(eng, "prepare_admission"):
+            eng.prepare_admission()              # pinned staging of the prompt rows: allocated now, never while serving
+            cb.prepare()
         for r in [r for r in ROW_BUCKETS if r <= cb.cap] or [cb.cap]:
             eng.step(r, 1)                       # captures the frame graph of every row count while all slots are idle
         self._sync_current_stream()

@@ -383,17 +383,23 @@ class TTSEngine:
         n = len(prompts)
         lens = [p.embeds.shape[0] for p in prompts]
         Tp = max(lens)
-        # one pinned staging block per engine, allocated on first use (a pinned allocation synchronises the device: never while serving)
-        if getattr(self, "_admit_host", None) is None:
-            self._admit_host = torch.zeros((self.max_batch * self.max_prompt * self.dims.t_hidden,), dtype=torch.float32, pin_memory=True)
-            self._admit_ints = torch.zeros((3, self.max_batch), dtype=torch.int32, pin_memory=True)
-        torch.cuda.current_stream(self.device).synchronize()      # the previous admission's copies out of the staging block are done
-        host = self._admit_host[: n * Tp * self.dims.t_hidden].view(n, Tp, self.dims.t_hidden)
+        # one pinned staging block per engine, allocated on first use (a pinned allocation synchronises the device: never while serving),
+        # used as a ring: consecutive admissions - several cohorts at one chunk boundary when the free slots are fragmented - take
+        # disjoint regions and do NOT wait for each other's prefill; the stream is synchronised only when the ring wraps
+        E = self.dims.t_hidden
+        self.prepare_admission()
+        need = n * Tp * E
+        if self._admit_off + need > self._admit_host.numel() or self._admit_row >= self._admit_ints.shape[0]:
+            torch.cuda.current_stream(self.device).synchronize()      # every copy out of the ring has completed
+            self._admit_off, self._admit_row = 0, 0
+        host = self._admit_host[self._admit_off: self._admit_off + need].view(n, Tp, E)
+        self._admit_off += need
         host.zero_()
         for i, p in enumerate(prompts):
             host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(p.embeds, dtype=np.float32))
         emb = host.to(self.device, non_blocking=True)
-        ints = self._admit_ints
+        ints = self._admit_ints[self._admit_row]
+        self._admit_row += 1
         ints[0, :n] = torch.tensor(lens, dtype=torch.int32)
         ln = ints[0, :n].to(self.device, non_blocking=True)
 
@@ -410,6 +416,13 @@ class TTSEngine:
                                                  int(utterance_id0)), "s2s_tts_admit")
         self._B = max(self._B, slot0 + n)
         self._keep_admit = (emb, ln, mn, bd)
+
+    def prepare_admission(self) -> None:
+        """Allocate the pinned staging ring of `admit` (once; the session pool calls it while the lane warms up, not on the first request)."""
+        if getattr(self, "_admit_host", None) is None:
+            self._admit_host = torch.empty((2 * self.max_batch * self.max_prompt * self.dims.t_hidden,), dtype=torch.float32, pin_memory=True)
+            self._admit_ints = torch.zeros((64, 3, self.max_batch), dtype=torch.int32, pin_memory=True)
+            self._admit_off, self._admit_row = 0, 0
 
     def step(self, rows: int, n_frames: int) -> None:
         """n_frames frames for the slots [0, rows): every live slot advances by its own frame index."""

@@ -60,6 +60,15 @@ class ContinuousTTS:
         self.stats = {"admitted": 0, "cohorts": 0, "rounds": 0, "max_live": 0, "row_rounds": {}}
         self.eng.release(0, self.cap)                           # every slot idle
 
+    def prepare(self) -> None:
+        """Allocate every pinned staging row and event the scheduler can ever need (the session pool calls this while the lane warms
+        up: a pinned allocation in the middle of serving stalls the device for every stream)."""
+        for ci in range(self.max_cohorts):
+            self._host(("pcm", ci), (1, 1), torch.int16)
+            self._host(("nfr", ci), (1,), torch.int32)
+            self._host(("nval", ci), (1,), torch.int32)
+            self._events.append(torch.cuda.Event())
+
     # ---- slots ------------------------------------------------------------------------------------
     @property
     def live(self) -> int:
