@@ -359,7 +359,9 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     import numpy as np
     import torch
 
-    from speech_to_speech_amd.boundary import TTSInput, VADAudio
+    from types import SimpleNamespace
+
+    from speech_to_speech_amd.boundary import GenerateResponseRequest, TTSInput, VADAudio
     from speech_to_speech_amd.handlers.qwen3_tts import MI355XQwen3TTSHandler
     from speech_to_speech_amd.handlers.whisper import MI355XWhisperSTTHandler
     from speech_to_speech_amd.session_pool import SessionPool
@@ -391,7 +393,11 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
         t.should_listen, t.cancel_scope, t.speculative_turns = None, None, None
         t.streaming_chunk_size, t.max_new_tokens, t.blocksize, t.pool = CHUNK_FRAMES, n_frames, 512, pool
         t.min_new_tokens = n_frames          # replies of the full length (eos masked), so that every counted turn did the whole work
-        return s, t
+        from speech_to_speech_amd.handlers.echo_llm import EchoLLMHandler
+
+        llm = object.__new__(EchoLLMHandler)          # the registered `--llm echo` backend (BASELINE config C1's stub LLM)
+        llm.prefix, llm.cancel_scope, llm.speculative_turns = "", None, None
+        return s, t, llm
 
     local = threading.local()
     results, lock = [], threading.Lock()
@@ -399,14 +405,19 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     def turn(session, t_arr, in_window):
         if not hasattr(local, "h"):
             local.h = make_handlers()
-        stt, tts = local.h
+        stt, tts, llm = local.h
         now = time.perf_counter()
         if t_arr > now:
             time.sleep(t_arr - now)
         va = VADAudio(audio=audios[session % len(audios)], mode="final", turn_id=f"s{session}", turn_revision=0, created_at_s=t_arr)
         out = list(stt.process(va))
         t_stt = time.perf_counter() - t_arr
-        text = (out[0].text if out else "")[:100]      # echo "LLM": the (capped) transcript is the reply, as in the timed region
+        # echo LLM: Transcription -> GenerateResponseRequest (last user message = the transcript, capped like the timed region's prompts)
+        # -> EchoLLMHandler.process() -> LLMResponseChunk.text -> TTSInput
+        said = (out[0].text if out else "")[:100]
+        req = GenerateResponseRequest(response_key=va.turn_id, runtime_config=SimpleNamespace(chat=[{"role": "user", "content": said}]), turn_id=va.turn_id,
+                                      turn_revision=0, language_code="en", speech_stopped_at_s=t_arr)
+        text = next((m.text for m in llm.process(req) if hasattr(m, "text")), "")
         t_first, n_blocks, late = None, 0, 0.0
         for block in tts.process(TTSInput(text=text or "t1", turn_id=va.turn_id, turn_revision=0, speech_stopped_at_s=t_arr)):
             tn = time.perf_counter()
