@@ -106,6 +106,8 @@ def parse(argv=None):
     ap.add_argument("--tts-lead-s", type=float, default=float("inf"), help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
     ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
+    ap.add_argument("--stt-max-batch", type=int, default=16, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
+                    "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
     ap.add_argument("--max-probes", type=int, default=6, help="open-loop probes of the sustained-sessions bisection")
@@ -347,7 +349,7 @@ def _rand_tts_sd(dims, g):
 
 
 # --------------------------------------------------------------------------------------------- boundary probe
-def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8):
+def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -368,7 +370,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     from speech_to_speech_amd.text import IdTextCodec, WhisperVocab
 
     B = tts_engine.max_batch
-    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus)
+    pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus, stt_max_batch=stt_max_batch)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
@@ -759,7 +761,7 @@ def main():
 
             def probe(n, window=args.boundary_seconds):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
-                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus)
+                                      stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch)
 
             single = probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
@@ -772,7 +774,7 @@ def main():
             mine = 0 if best is None else int(best["sessions"])
             total = sum_over_ranks(mine)         # gloo, host scalar: the sum of the ranks' sustained session counts
             boundary = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, STT batches of up to "
-                                f"{MB} sessions, {lanes} TTS lanes x {MB} slots, " + ("turn-batches" if args.turn_batches else "continuous batching at chunk boundaries")
+                                f"{args.stt_max_batch or MB} sessions, {lanes} TTS lanes x {MB} slots, " + ("turn-batches" if args.turn_batches else "continuous batching at chunk boundaries")
                                 + f") -> C ABI; uniform-phase staggered turn arrivals, {args.boundary_seconds:g} s window per probe",
                         "ttfa_bound_ms": args.ttfa_bound_ms,
                         "sustained_sessions": None if best is None else total,

@@ -79,7 +79,7 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -90,6 +90,9 @@ class SessionPool:
         # lane admission policy: 0 = the least loaded lanes take new sessions (spreads them over all lanes); T > 0 = fill first: lane k only
         # takes new sessions once every lane below it holds at least T live sessions (fewer frame loops running, fuller rows)
         self.tts_fill_first = int(tts_fill_first)
+        # largest final-STT batch (0: the engine's max_batch).  A cap keeps a backlog from locking the pool into long STT batches whose
+        # sessions then all start their TTS at the same instant (bursty prefills against the next batch's encoder)
+        self.stt_max_batch = int(stt_max_batch)
         # CU mask of the TTS lanes' streams: lanes run on `tts_lane_cus` of every 8 compute units (8 = all, no mask)
         self.tts_lane_cus = int(tts_lane_cus)
         self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
@@ -260,6 +263,8 @@ class SessionPool:
             cap = self.max_batch
             if isinstance(first, _STTRequest):
                 cap = min(cap, int(getattr(self._engines.get(first.model), "max_batch", cap)))     # never hand an engine more rows than it was built for
+                if self.stt_max_batch > 0:
+                    cap = min(cap, self.stt_max_batch)
             items = [first] + self._drain(self._stt_q, cap - 1)
             reqs: list[_STTRequest] = []
             for it in items:
