@@ -378,3 +378,83 @@ def test_continuous_tts_scheduler_admits_retires_and_orders_cohorts(monkeypatch)
     ev = list(cb.drain())
     assert sum(1 for jj, ch in ev if jj is d and ch is None) == 1 and not any(jj is d and ch is not None for jj, ch in ev)
     assert cb.live == 0 and cb.free == [(0, 8)] and all(k[0] != "step" or k[1] == 8 for k in eng.log)
+
+
+def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch):
+    """SessionPool.synthesize() through a continuously batched lane (stub engine, no GPU): requests that arrive while others are
+    streaming join at the next chunk boundary instead of waiting for a free lane; every request gets its chunks and exactly one end;
+    a cancelled request stops early and its slot is reused."""
+    import threading
+    import time
+    import types
+
+    import torch
+
+    from speech_to_speech_amd import tts_continuous as TC
+    from speech_to_speech_amd.session_pool import SessionPool
+
+    eng = _StubTTSEngine()
+    up = eng.dims.total_upsample
+    step_gate = threading.Semaphore(0)           # the test releases one frame-loop round at a time
+    real_step = eng.step
+
+    def gated_step(rows, n):
+        if any(k[0] == "admit" for k in eng.log):
+            step_gate.acquire(timeout=5)
+        real_step(rows, n)
+
+    eng.step = gated_step
+
+    def read_codes(s0, n, f0, F):
+        nfr = torch.tensor([eng.slots[s0 + i]["frames"] for i in range(n)], dtype=torch.int32)
+        nval = torch.tensor([max(0, min(int(v) - f0, F)) * up for v in nfr], dtype=torch.int32)
+        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
+
+    eng.read_codes = read_codes
+    eng.codec_decode_rows = lambda codes, s0, fd: torch.zeros((codes.shape[0], codes.shape[1] * up))
+    eng.resample_int16 = lambda wav, nvalid=None: torch.full((wav.shape[0], (2 * wav.shape[1] + 2) // 3), 5, dtype=torch.int16)
+
+    class _Ev:
+        def record(self):
+            pass
+
+        def synchronize(self):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(TC.ContinuousTTS, "_host", lambda self, key, shape, dtype: torch.empty(tuple(shape), dtype=dtype))
+    pool = SessionPool("cpu-test-continuous", max_batch=8, batch_window_ms=0.0, tts_chunk_size=4, tts_lanes=1)
+    pool._engines["tts"] = eng
+    try:
+        prompt = types.SimpleNamespace(eos_at=None)
+        it_a, _ = pool.synthesize(prompt, 12)
+        deadline = time.time() + 5
+        while not any(k[0] == "admit" for k in eng.log) and time.time() < deadline:
+            time.sleep(0.01)
+        step_gate.release()                               # round 1: a's first chunk
+        first = next(it_a)
+        assert len(first) == (2 * 4 * up + 2) // 3
+        it_b, cancel_b = pool.synthesize(prompt, 8)       # arrives while a is streaming ...
+        it_c, _ = pool.synthesize(prompt, 4)
+        deadline = time.time() + 5
+        while sum(1 for k in eng.log if k[0] == "admit") < 2 and time.time() < deadline:
+            time.sleep(0.01)
+        assert sum(k[2] for k in eng.log if k[0] == "admit") == 3                    # ... and joins at the next boundary: no second lane, no waiting for a to end
+        got = {"a": [first], "b": [], "c": []}
+        threads = [threading.Thread(target=lambda k=k, it=it: got[k].extend(list(it))) for k, it in (("a", it_a), ("b", it_b), ("c", it_c))]
+        [t.start() for t in threads]
+        step_gate.release()                               # round 2: a second chunk, b and c first chunks (c: budget 4 -> done)
+        time.sleep(0.2)
+        cancel_b.set()                                    # b goes away after its first chunk
+        for _ in range(6):
+            step_gate.release()
+        [t.join(timeout=10) for t in threads]
+        assert not any(t.is_alive() for t in threads)
+        assert len(got["a"]) == 3 and len(got["c"]) == 1 and 1 <= len(got["b"]) <= 2
+        assert pool.stats["tts_requests"] == 3 and pool.stats["tts_rounds"] >= 3
+        releases = [k for k in eng.log if k[0] == "release" and k[2] < 8]
+        assert sum(k[2] for k in releases) == 3                                       # every admitted slot was given back
+    finally:
+        for _ in range(20):
+            step_gate.release()
+        pool.shutdown(close_engines=False)
