@@ -381,9 +381,9 @@ def test_continuous_tts_scheduler_admits_retires_and_orders_cohorts(monkeypatch)
 
 
 def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch):
-    """SessionPool.synthesize() through a continuously batched lane (stub engine, no GPU): requests that arrive while others are
+    """SessionPool.synthesize() through a continuously batched lane (stub engine, no GPU): requests that arrive while another one is
     streaming join at the next chunk boundary instead of waiting for a free lane; every request gets its chunks and exactly one end;
-    a cancelled request stops early and its slot is reused."""
+    a cancelled request stops early; every slot is given back."""
     import threading
     import time
     import types
@@ -395,15 +395,13 @@ def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch)
 
     eng = _StubTTSEngine()
     up = eng.dims.total_upsample
-    step_gate = threading.Semaphore(0)           # the test releases one frame-loop round at a time
     real_step = eng.step
 
-    def gated_step(rows, n):
-        if any(k[0] == "admit" for k in eng.log):
-            step_gate.acquire(timeout=5)
+    def slow_step(rows, n):
+        time.sleep(0.03)                          # a round takes a while: later requests arrive while the first one is streaming
         real_step(rows, n)
 
-    eng.step = gated_step
+    eng.step = slow_step
 
     def read_codes(s0, n, f0, F):
         nfr = torch.tensor([eng.slots[s0 + i]["frames"] for i in range(n)], dtype=torch.int32)
@@ -427,34 +425,35 @@ def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch)
     pool._engines["tts"] = eng
     try:
         prompt = types.SimpleNamespace(eos_at=None)
-        it_a, _ = pool.synthesize(prompt, 12)
-        deadline = time.time() + 5
-        while not any(k[0] == "admit" for k in eng.log) and time.time() < deadline:
-            time.sleep(0.01)
-        step_gate.release()                               # round 1: a's first chunk
+        it_a, _ = pool.synthesize(prompt, 32)             # 8 rounds of 4 frames
         first = next(it_a)
         assert len(first) == (2 * 4 * up + 2) // 3
-        it_b, cancel_b = pool.synthesize(prompt, 8)       # arrives while a is streaming ...
+        it_b, cancel_b = pool.synthesize(prompt, 16)      # arrive while a is streaming
         it_c, _ = pool.synthesize(prompt, 4)
-        deadline = time.time() + 5
-        while sum(1 for k in eng.log if k[0] == "admit") < 2 and time.time() < deadline:
-            time.sleep(0.01)
-        assert sum(k[2] for k in eng.log if k[0] == "admit") == 3                    # ... and joins at the next boundary: no second lane, no waiting for a to end
         got = {"a": [first], "b": [], "c": []}
-        threads = [threading.Thread(target=lambda k=k, it=it: got[k].extend(list(it))) for k, it in (("a", it_a), ("b", it_b), ("c", it_c))]
+
+        def drain_b():
+            for ch in it_b:
+                got["b"].append(ch)
+                cancel_b.set()                            # the client goes away after its first chunk
+
+        threads = [threading.Thread(target=lambda: got["a"].extend(list(it_a))), threading.Thread(target=drain_b),
+                   threading.Thread(target=lambda: got["c"].extend(list(it_c)))]
         [t.start() for t in threads]
-        step_gate.release()                               # round 2: a second chunk, b and c first chunks (c: budget 4 -> done)
-        time.sleep(0.2)
-        cancel_b.set()                                    # b goes away after its first chunk
-        for _ in range(6):
-            step_gate.release()
-        [t.join(timeout=10) for t in threads]
+        [t.join(timeout=20) for t in threads]
         assert not any(t.is_alive() for t in threads)
-        assert len(got["a"]) == 3 and len(got["c"]) == 1 and 1 <= len(got["b"]) <= 2
-        assert pool.stats["tts_requests"] == 3 and pool.stats["tts_rounds"] >= 3
-        releases = [k for k in eng.log if k[0] == "release" and k[2] < 8]
-        assert sum(k[2] for k in releases) == 3                                       # every admitted slot was given back
+        assert len(got["a"]) == 8 and len(got["c"]) == 1 and 1 <= len(got["b"]) <= 2          # b: budget 16 = 4 chunks, cut short by the cancel
+        log = list(eng.log)
+        admits = [i for i, k in enumerate(log) if k[0] == "admit"]
+        a_release = next(i for i, k in enumerate(log) if k[0] == "release" and k[1] == 0 and k[2] == 1)
+        assert len(admits) >= 2 and max(admits) < a_release       # b and c joined the ONE lane while a's slot was still live
+        deadline = time.time() + 5
+        while pool.stats["tts_requests"] < 3 and time.time() < deadline:
+            time.sleep(0.01)
+        assert pool.stats["tts_requests"] == 3
+        deadline = time.time() + 5
+        while sum(k[2] for k in eng.log if k[0] == "release" and k[2] < 8) < 3 and time.time() < deadline:
+            time.sleep(0.01)
+        assert sum(k[2] for k in eng.log if k[0] == "release" and k[2] < 8) == 3          # every admitted slot was given back
     finally:
-        for _ in range(20):
-            step_gate.release()
         pool.shutdown(close_engines=False)
