@@ -32,7 +32,7 @@ extern "C" {
 #define S2S_ERR_STATE (-3)
 #define S2S_ERR_UNSUPPORTED (-4)
 
-#define S2S_ABI_VERSION 1
+#define S2S_ABI_VERSION 2 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions */
 
 /* element types of device buffers */
 #define S2S_F32 0
@@ -189,6 +189,9 @@ int32_t s2s_op_rows_prep_pairs(void* stream, const float* x, int64_t x_rs, void*
  * splitk / nt > 0 force the K-slices per column block / the 16-column tiles per wave of the column-block kernel (0 = chosen
  * from the shape).  Process-wide: not for use while engines are serving. */
 int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt);
+/* The same for the row-block kernel of wide frame loops (129 .. 1024 rows, csrc/gemm_decw.hip): enable = 0 sends such calls down the
+ * 128-row slab path, splitk > 0 forces the K-slices per tile, min_m > 0 moves the smallest row count the kernel takes (default 129). */
+int32_t s2s_op_gemm_decw_tune(int32_t enable, int32_t splitk, int32_t min_m);
 /* development: per-workgroup phase timestamps of the column-block decode kernel (8 x u64 per workgroup, 100 MHz), null = off */
 int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
 /* xb = bf16(x) (frag != 0: fragment-major [rows][cols]) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
@@ -396,6 +399,10 @@ int32_t s2s_tts_step(void* model, void* stream, int32_t rows, int32_t n_frames);
 int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, int32_t n, int32_t frame0, int32_t n_frames, int32_t* codes_dev,
                            int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev);
 int32_t s2s_tts_release(void* model, void* stream, int32_t slot0, int32_t n);
+/* s2s_tts_read_codes for rows of DIFFERENT ages in one call: frame0_rows_dev int32[n] (device) = first frame to read per slot; chunk_samples
+ * = n_frames * total_upsample (continuation chunks only - a stream's first chunk goes through s2s_tts_read_codes). */
+int32_t s2s_tts_read_codes_rows(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* frame0_rows_dev, int32_t n_frames,
+                                int32_t* codes_dev, int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev);
 /* Sampling of the frame loop (the reference's backend samples; greedy is the parity policy and the default).  which: 0 = talker
  * (codebook 0; the repetition penalty covers the utterance's earlier codebook-0 picks), 1 = code predictor (residual groups).
  * Processor order = transformers generate(): repetition penalty -> temperature -> top-k -> top-p -> seeded multinomial
@@ -432,6 +439,13 @@ int32_t s2s_codec_stream_decode(void* model, void* stream, const int32_t* codes_
  * disjoint row ranges stream independently of each other (sessions admitted at different chunk boundaries). */
 int32_t s2s_codec_decode_rows(void* model, void* stream, const int32_t* codes_dev, int32_t slot0, int32_t n, int32_t F, int32_t frames_done,
                               float* wav_dev, int32_t n_samples);
+/* Continuation of rows of DIFFERENT ages in ONE pass (all continuation cohorts of a round; the launch count of a round no longer grows
+ * with the number of cohorts): frames_done_rows_dev int32[n] (device) = frames already decoded per row (> 0 for every live stream: the
+ * first chunk of a stream has its own geometry and goes through s2s_codec_decode_rows with frames_done = 0), max_frames_done = the
+ * largest entry.  Rows of [slot0, slot0 + n) that carry no live stream are computed and ignored; their state is rewritten by the
+ * first chunk of the next stream in that slot.  wav_dev f32 [n][n_samples], n_samples = F * total_upsample. */
+int32_t s2s_codec_decode_rows_at(void* model, void* stream, const int32_t* codes_dev, int32_t slot0, int32_t n, int32_t F,
+                                 const int32_t* frames_done_rows_dev, int32_t max_frames_done, float* wav_dev, int32_t n_samples);
 /* Post-processing of Qwen3TTSHandler._stream (TTS/qwen3_tts_handler.py:612-613,674-680): per-chunk
  * scipy.signal.resample_poly(x, up=2, down=3) then clip(x*32768).astype(int16).
  *   pcm24_dev f32 [B][in_stride], n_in_dev optional int32 [B] (else in_stride samples), fir_dev f32 [taps] the

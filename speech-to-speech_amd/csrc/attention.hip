@@ -123,10 +123,16 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
             if (d < D) acc[u] = fmaf(pj, Elem<T>::ld(Vb + (long)(jlo + j) * p.kv_rs + d), acc[u]);
         }
     }
+    // fragment-major output rows (operand layout of the decode projections, gemm_dec.hip): row b * Tq + t, column h * D + d
+    const long orow = (long)b * p.Tq + t;
+    const int oksteps = (p.H * D) >> 5;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int d = lane + u * 64;
-        if (d < D) Elem<T>::st(o + d, acc[u] * inv);
+        if (d < D && p.o_frag) {
+            const int k = h * D + d;
+            Elem<T>::st((T*)p.O + ((((orow >> 4) * oksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (orow & 15)) * 8 + (k & 7), acc[u] * inv);
+        } else if (d < D) Elem<T>::st(o + d, acc[u] * inv);
     }
 }
 
@@ -543,7 +549,8 @@ int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype) {
     if (p.kv_len_const <= 0) return fail(S2S_ERR_ARG, "attention: kv_len_const must be > 0");
     if (p.Tq == 1 && !p.bias && p.kv_len_const >= 64)
         return dtype == S2S_BF16 ? launch_attn_decode<__hip_bfloat16>(st, p) : launch_attn_decode<float>(st, p);
-    S2S_REQUIRE(!p.o_frag, "attention: fragment-major output is a decode-kernel (Tq = 1, >= 64 keys) feature");
+    S2S_REQUIRE(!p.o_frag || ((p.H * p.D) % 32 == 0 && p.o_bs == (long)p.Tq * p.H * p.D && p.o_rs == (long)p.H * p.D),
+                "attention: fragment-major output needs contiguous [B * Tq][H * D] rows, H * D a multiple of 32");
     return dtype == S2S_BF16 ? launch_attn_rows<__hip_bfloat16>(st, p) : launch_attn_rows<float>(st, p);
 }
 

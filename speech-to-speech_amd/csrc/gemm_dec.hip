@@ -413,7 +413,8 @@ int launch_dec_mt(hipStream_t st, const DecGemm& a, int NF) {
 int dec_parts(int N, int NF) { return cdiv(N, 16 * NF) * NF; }
 
 int dec_out_parts(const DecGemm& a) {
-    const int p2 = dec2_parts(a);
+    const int pw = decw_parts(a);
+    const int p2 = pw > 0 ? pw : dec2_parts(a);
     return (p2 > 0 ? p2 : dec_parts(a.N, dec_nf(a))) * (a.ss_pairs ? 2 : 1);
 }
 
@@ -426,7 +427,8 @@ int dec_nf(const DecGemm& a) {
 }
 
 int gemm_dec(hipStream_t st, const DecGemm& a) {
-    S2S_REQUIRE(a.M >= 1 && (a.M <= 128 || a.M % 128 == 0) && a.N > 0 && a.K > 0, "gemm_dec: bad shape M=%d N=%d K=%d (M <= 128 or a multiple of 128)", a.M, a.N, a.K);
+    S2S_REQUIRE(a.M >= 1 && (a.M <= 128 || a.M % 128 == 0 || decw_parts(a) > 0) && a.N > 0 && a.K > 0,
+                "gemm_dec: bad shape M=%d N=%d K=%d (M <= 128, a multiple of 128, or fragment-major rows for the wide kernel)", a.M, a.N, a.K);
     S2S_REQUIRE(a.K >= 256 && a.K % 32 == 0 && (a.a_frag || a.lda % 8 == 0), "gemm_dec: K=%d must be >= 256 and a multiple of 32, lda a multiple of 8", a.K);
     S2S_REQUIRE((!a.c_frag || (a.mode == 0 && a.ldc % 32 == 0)) && (!a.xb_frag || a.ldxb % 32 == 0), "gemm_dec: fragment-major outputs need a row width that is a multiple of 32");
     S2S_REQUIRE(a.A && a.W && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_dec: operands must be 16-byte aligned");
@@ -437,6 +439,12 @@ int gemm_dec(hipStream_t st, const DecGemm& a) {
     const int NF = dec_nf(a);
     ProfScope prof(st, S2S_PROF_GEMM_SKINNY, 2.0 * a.M * a.N * a.K * (a.glu ? 2 : 1),
                    (double)a.N * a.K * 2 * (a.glu ? 2 : 1) + (double)a.M * a.K * 2 + (double)a.M * a.N * (a.mode == 0 ? 2 : 4));
+    // wide frame loops (129 .. 1024 rows, fragment-major activations): the row-block x column-block kernel (gemm_decw.hip)
+    if (a.M > 64) {
+        DecGemm w = a;
+        if (!w.ws) w.ws = dec2_default_ws(&w.ws_bytes);
+        if (const int rw = gemm_decw(st, w)) return rw < 0 ? rw : S2S_OK;
+    }
     // 33 .. 128-row slabs with fragment-major activations: the column-block / K-slice kernel (gemm_dec2.hip)
     if (const int r2 = gemm_dec2(st, a)) return r2 < 0 ? r2 : S2S_OK;
     const int MT = cdiv(a.M, 16);

@@ -561,6 +561,11 @@ int dec2_ensure_default_ws() {
     return S2S_OK;
 }
 
+void* dec2_default_ws(size_t* bytes) {
+    if (bytes) *bytes = default_ws().bytes;
+    return default_ws().p;
+}
+
 void dec2_set_debug(unsigned long long* dbg) { tune().dbg = dbg; }
 
 void dec2_set_tune(int enable, int splitk, int nt) {

@@ -72,6 +72,10 @@ int dec_out_parts(const DecGemm& a);        // partial sums per row gemm_dec(a) 
 int gemm_dec2(hipStream_t st, const DecGemm& a);
 int dec2_parts(const DecGemm& a);           // column blocks (= partial sums per row) when gemm_dec2 takes the shape, else 0
 int dec2_ensure_default_ws();
+void* dec2_default_ws(size_t* bytes);       // the process-wide default K-slice workspace (null before dec2_ensure_default_ws)
+// row-block x column-block kernel for 129 .. 1024 rows (gemm_decw.hip): 1 launched, 0 not eligible, < 0 error
+int gemm_decw(hipStream_t st, const DecGemm& a);
+int decw_parts(const DecGemm& a);           // column blocks (= partial sums per row) when gemm_decw takes the shape, else 0
 constexpr size_t DEC_WS_BYTES = (size_t)48 << 20;   // K-slice workspace an engine allocates per stream of decode launches
 int rows_prep(hipStream_t st, const float* x, long x_rs, void* xb, long xb_rs, float* ss, int rows, int cols, bool frag, long pair_stride = 0);   // pair_stride > 0: also ss[pair_stride + row] = plain sum
 int to_frag(hipStream_t st, const void* W, long ld, const float* gamma, void* out, int rows, int K);

@@ -37,8 +37,8 @@ int tts_frame_end(hipStream_t st, int* pos_t, int* frame_b, int* finished, const
 int tts_slots_set(hipStream_t st, int* pos_t, int* frame_b, int* min_b, int* budget_b, int* utt_b, int* finished, int* n_frames, int* code0,
                   const int* prompt_len, const int* min_frames, const int* budget, int min_all, int budget_all, int utt0, int max_frames, int slot0,
                   int n, bool live);
-int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, int F, int* out);
-int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* out);
+int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, const int* frame0_rows, int F, int* out);
+int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, const int* frame0_rows, int F, int up, int chunk_samples, int* out);
 int fold_norm_weight(hipStream_t st, const void* W, const float* gamma, void* out, long rows, int K, int dtype);
 int gather_embed(hipStream_t st, const void* table, const int* ids, int id_stride, int id_offset, float* dst, long dst_rs, int B,
                  int dim, int accumulate, const void* addvec, int dtype);
@@ -47,7 +47,8 @@ int dwconv7_ln(hipStream_t st, const void* x, const float* w, const float* bias,
                int Tn, int C, int lpad, float eps, int dtype);
 int wav_out(hipStream_t st, const void* x, float* wav, int B, int Tn, int lpad, int skip, int n, int dtype);
 
-constexpr int DEC_ROWS = 1024;   // most rows (sessions x new tokens) of a norm-free decode pass: <= 128, or a multiple of 128 (gemm_dec row slabs)
+constexpr int DEC_ROWS = 1024;   // most rows (sessions x new tokens) of a norm-free decode pass (gemm_dec.hip up to 128 rows, gemm_decw.hip above)
+constexpr int MAX_SLOTS = 512;   // most rows of the frame loop (the code predictor's two-row pass runs 2 x slots rows)
 constexpr int SS_PARTS = 256;   // most column slabs of a residual projection (hidden / 16)
 constexpr int LPAD = 56;   // >= (7-1)*9 = 54 taps of history for the widest dilated conv, multiple of 8
 
@@ -379,7 +380,9 @@ static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
 static inline const void* at(const void* p, size_t bytes) { return (const char*)p + bytes; }
 
 static bool dec_fusion_ok(const Tts* m, const Stack& s, int M) {
-    return m->cfg.dtype == S2S_BF16 && (M <= 128 || (M % 128 == 0 && M <= DEC_ROWS)) && !s.qkv_n.empty() && m->xb && s.c.hidden <= m->xb_width;
+    // (every operand of the decode projections is fragment-major on this path, so any row count up to DEC_ROWS is served: the 16-column
+    // / column-block kernels up to 128 rows, the row-block kernel of gemm_decw.hip above)
+    return m->cfg.dtype == S2S_BF16 && M <= DEC_ROWS && !s.qkv_n.empty() && m->xb && s.c.hidden <= m->xb_width;
 }
 
 // attention of one stack pass (q/k head norms, RoPE, cache append, softmax(QK^T)V) from m->qkv into m->att
@@ -407,7 +410,8 @@ static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T
         if (o_frag) *o_frag = a.o_frag;
         return attn_step(st, a, dt);
     }
-    if (o_frag) *o_frag = false;
+    const bool rows_frag = o_frag != nullptr && (H * D) % 32 == 0;     // several new tokens per session: the row kernel writes the same layout
+    if (o_frag) *o_frag = rows_frag;
     if ((rc = rope_qknorm(st, m->qkv, M, T_len, H, Hk, D, c.qk_norm ? TPF(m, p + "qnorm") : nullptr, c.qk_norm ? TPF(m, p + "knorm") : nullptr,
                           c.eps, s.cosT, s.sinT, pos0, kc, vc, (long)c.max_pos * Hk * D, dt))) return rc;
     AttnRowsParams a{};
@@ -416,6 +420,7 @@ static int stack_attention(Tts* m, hipStream_t st, Stack& s, int l, int B, int T
     a.O = m->att; a.o_bs = (long)T_len * H * D; a.o_rs = (long)H * D;
     a.kv_len = kv_len_dev; a.kv_len_const = kv_cap; a.B = B; a.H = H; a.Hkv = Hk; a.Tq = T_len; a.D = D;
     a.causal = 1; a.causal_off = 0; a.causal_off_arr = pos0; a.window = c.window; a.scale = 1.0f / sqrtf((float)D);
+    a.o_frag = rows_frag;
     return attn_rows(st, a, dt);
 }
 
@@ -633,7 +638,7 @@ static int frame_graph(Tts* m, int B, hipGraphExec_t* out) {
 using namespace s2s;
 
 extern "C" int32_t s2s_tts_create(const s2s_tts_config* cfg, int32_t max_batch, void** out) {
-    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= 128, "tts_create: bad arguments (max_batch 1..128)");
+    S2S_REQUIRE(cfg && out && max_batch > 0 && max_batch <= MAX_SLOTS, "tts_create: bad arguments (max_batch 1..%d)", MAX_SLOTS);
     S2S_REQUIRE(cfg->dtype == S2S_F32 || cfg->dtype == S2S_BF16, "tts_create: bad dtype");
     S2S_REQUIRE(cfg->t_hidden % 8 == 0 && cfg->p_hidden % 8 == 0 && cfg->c_hidden % 8 == 0 && cfg->t_ffn % 8 == 0 && cfg->p_ffn % 8 == 0 &&
                     cfg->c_ffn % 8 == 0 && cfg->n_dec_blocks >= 1 && cfg->n_dec_blocks <= 4 && (cfg->c_decoder_dim >> cfg->n_dec_blocks) % 8 == 0,
@@ -794,9 +799,23 @@ extern "C" int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, 
     S2S_REQUIRE(m && m->finalized && slot0 >= 0 && n >= 1 && slot0 + n <= m->max_batch && frame0 >= 0 && n_frames >= 1 && codes_dev, "tts_read_codes: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = tts_read_codes(st, m->codes_out, m->cfg.max_frames, m->cfg.n_groups, slot0, n, frame0, n_frames, codes_dev))) return rc;
+    if ((rc = tts_read_codes(st, m->codes_out, m->cfg.max_frames, m->cfg.n_groups, slot0, n, frame0, nullptr, n_frames, codes_dev))) return rc;
     if (n_frames_dev) S2S_HIP_CHECK(hipMemcpyAsync(n_frames_dev, m->n_frames + slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
-    if (valid_samples_dev && (rc = tts_valid_samples(st, m->n_frames, slot0, n, frame0, n_frames, m->cfg.total_upsample, chunk_samples, valid_samples_dev))) return rc;
+    if (valid_samples_dev && (rc = tts_valid_samples(st, m->n_frames, slot0, n, frame0, nullptr, n_frames, m->cfg.total_upsample, chunk_samples, valid_samples_dev))) return rc;
+    return S2S_OK;
+}
+
+/* The same for rows of DIFFERENT ages in one call: frame0_rows_dev int32[n] = first frame to read per slot (sessions admitted at different
+ * chunk boundaries share one codec pass, s2s_codec_decode_rows_at).  chunk_samples = n_frames * total_upsample (continuation chunks). */
+extern "C" int32_t s2s_tts_read_codes_rows(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* frame0_rows_dev, int32_t n_frames,
+                                           int32_t* codes_dev, int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && slot0 >= 0 && n >= 1 && slot0 + n <= m->max_batch && frame0_rows_dev && n_frames >= 1 && codes_dev, "tts_read_codes_rows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = tts_read_codes(st, m->codes_out, m->cfg.max_frames, m->cfg.n_groups, slot0, n, 0, frame0_rows_dev, n_frames, codes_dev))) return rc;
+    if (n_frames_dev) S2S_HIP_CHECK(hipMemcpyAsync(n_frames_dev, m->n_frames + slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    if (valid_samples_dev && (rc = tts_valid_samples(st, m->n_frames, slot0, n, 0, frame0_rows_dev, n_frames, m->cfg.total_upsample, chunk_samples, valid_samples_dev))) return rc;
     return S2S_OK;
 }
 
@@ -912,12 +931,15 @@ namespace s2s {
 // row0 / frames_done_io: the streaming state (history rows, pre-transformer cache) of the batch rows lives in rows [row0, row0 + B) of the
 // engine's codec state and the stream has *frames_done_io frames behind it (updated) - cohorts of sessions admitted at different
 // times stream independently from disjoint row ranges (continuous batching); null: the engine-wide stream of the legacy entry points.
+// pos_rows_dev (optional, int32[B] on the device; streaming continuation only): frames already decoded PER ROW - rows of different ages
+// share the pass (every stage's history rows and the pre-transformer cache are per row anyway; only the positions differ), and
+// *frames_done_io is then the largest of them (the host's bound for the cache length).
 static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F, int ctx, bool streaming, float* wav_dev, int n_samples, int row0 = 0,
-                     int* frames_done_io = nullptr) {
+                     int* frames_done_io = nullptr, const int* pos_rows_dev = nullptr) {
     const auto& c = m->cfg;
     const int dt = c.dtype, e = m->esz, H = c.c_hidden, G = c.n_groups;
     int& frames_done = frames_done_io ? *frames_done_io : m->codec_frames_done;
-    const bool first = !streaming || frames_done == 0;
+    const bool first = !streaming || (frames_done == 0 && !pos_rows_dev);
     const int saveB = m->cur_B;
     m->cur_B = B;
     int rc;
@@ -949,7 +971,9 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
     // code embeddings -> sliding-window transformer (KV cache continues across streamed chunks)
     if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
     const int f0 = streaming ? frames_done : 0;
-    if (streaming) {
+    if (streaming && pos_rows_dev) {
+        S2S_HIP_CHECK(hipMemcpyAsync(m->pos_c, pos_rows_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    } else if (streaming) {
         fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->pos_c, f0, B);
         S2S_LAUNCH_CHECK();
     }
@@ -1132,6 +1156,22 @@ extern "C" int32_t s2s_codec_decode_rows(void* model, void* stream, const int32_
     S2S_REQUIRE(frames_done + F <= m->codec.c.max_pos, "codec_decode_rows: %d frames exceed the stream capacity %d", frames_done + F, m->codec.c.max_pos);
     int fd = frames_done;
     return codec_run(m, (hipStream_t)stream, codes_dev, n, F, 0, true, wav_dev, n_samples, slot0, &fd);
+}
+
+/* Streaming continuation of rows of DIFFERENT ages in one pass: frames_done_rows_dev int32[n] (device) = frames already decoded per row
+ * (every row continues a stream: the first chunk of a stream has its own geometry and goes through s2s_codec_decode_rows with
+ * frames_done = 0), max_frames_done = the largest entry.  Rows of the range that carry no live stream may be passed with any
+ * position; their output is meaningless and their state is rewritten by the first chunk of the next stream that uses the slot.
+ * wav_dev f32 [n][F * total_upsample]. */
+extern "C" int32_t s2s_codec_decode_rows_at(void* model, void* stream, const int32_t* codes_dev, int32_t slot0, int32_t n, int32_t F,
+                                            const int32_t* frames_done_rows_dev, int32_t max_frames_done, float* wav_dev, int32_t n_samples) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "codec_decode_rows_at: model not finalized");
+    S2S_REQUIRE(slot0 >= 0 && n > 0 && slot0 + n <= m->max_batch && F >= 1 && F <= m->cfg.max_codec_frames && max_frames_done >= 0 && codes_dev && wav_dev &&
+                    frames_done_rows_dev, "codec_decode_rows_at: bad arguments");
+    S2S_REQUIRE(max_frames_done + F <= m->codec.c.max_pos, "codec_decode_rows_at: %d frames exceed the stream capacity %d", max_frames_done + F, m->codec.c.max_pos);
+    int fd = max_frames_done;
+    return codec_run(m, (hipStream_t)stream, codes_dev, n, F, 0, true, wav_dev, n_samples, slot0, &fd, frames_done_rows_dev);
 }
 
 extern "C" int64_t s2s_codec_samples(void* model, int32_t F) {

@@ -449,13 +449,15 @@ __global__ void tts_slots_set_kernel(int* pos_t, int* frame_b, int* min_b, int* 
 }
 
 // codes of frames [frame0, frame0 + F) of slots [slot0, slot0 + n): out [n][F][G]
-__global__ void tts_read_codes_kernel(const int* __restrict__ codes_out, int max_frames, int G, int slot0, int frame0, int F, int* __restrict__ out, long total) {
+// frame0_rows (optional, int32[n]): per-row first frame instead of frame0 (rows of different ages in one call)
+__global__ void tts_read_codes_kernel(const int* __restrict__ codes_out, int max_frames, int G, int slot0, int frame0, const int* __restrict__ frame0_rows, int F,
+                                      int* __restrict__ out, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int g = (int)(i % G);
     const long r = i / G;
     const int f = (int)(r % F), b = (int)(r / F);
-    const int fr = frame0 + f;
+    const int fr = (frame0_rows ? frame0_rows[b] : frame0) + f;
     out[i] = fr < max_frames ? codes_out[((long)(slot0 + b) * max_frames + fr) * G + g] : -1;
 }
 
@@ -501,23 +503,24 @@ int tts_slots_set(hipStream_t st, int* pos_t, int* frame_b, int* min_b, int* bud
 
 // 24 kHz samples of this chunk that belong to VALID frames of each slot: chunk_samples when all F frames are valid, else what the
 // valid frames contribute (a first chunk is shorter than F * up by the codec's left trim)
-__global__ void tts_valid_samples_kernel(const int* __restrict__ n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* __restrict__ out) {
+__global__ void tts_valid_samples_kernel(const int* __restrict__ n_frames, int slot0, int n, int frame0, const int* __restrict__ frame0_rows, int F, int up,
+                                         int chunk_samples, int* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int valid = min(max(n_frames[slot0 + i] - frame0, 0), F);
+    const int valid = min(max(n_frames[slot0 + i] - (frame0_rows ? frame0_rows[i] : frame0), 0), F);
     out[i] = valid >= F ? chunk_samples : max(0, valid * up - (F * up - chunk_samples));
 }
 
-int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, int F, int up, int chunk_samples, int* out) {
-    tts_valid_samples_kernel<<<cdiv(n, 64), 64, 0, st>>>(n_frames, slot0, n, frame0, F, up, chunk_samples, out);
+int tts_valid_samples(hipStream_t st, const int* n_frames, int slot0, int n, int frame0, const int* frame0_rows, int F, int up, int chunk_samples, int* out) {
+    tts_valid_samples_kernel<<<cdiv(n, 64), 64, 0, st>>>(n_frames, slot0, n, frame0, frame0_rows, F, up, chunk_samples, out);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
-int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, int F, int* out) {
+int tts_read_codes(hipStream_t st, const int* codes_out, int max_frames, int G, int slot0, int n, int frame0, const int* frame0_rows, int F, int* out) {
     const long total = (long)n * F * G;
     if (total <= 0) return S2S_OK;
-    tts_read_codes_kernel<<<(unsigned)cdiv(total, 256), 256, 0, st>>>(codes_out, max_frames, G, slot0, frame0, F, out, total);
+    tts_read_codes_kernel<<<(unsigned)cdiv(total, 256), 256, 0, st>>>(codes_out, max_frames, G, slot0, frame0, frame0_rows, F, out, total);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

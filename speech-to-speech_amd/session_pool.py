@@ -79,7 +79,8 @@ class SessionPool:
             p.shutdown()
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
-                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0):
+                 tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
+                 tts_admit_wait_s: float = 0.0):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -87,6 +88,9 @@ class SessionPool:
         # measured on C3 (profiles/r03_open_loop_ab.txt) pacing at 1-2 s raises the rows per round but does NOT raise the STT service rate,
         # which is what bounds the sustained session count - p95 TTFA at 900 sessions 958 ms eager vs 3.3 s paced at 2 s.
         self.tts_lead_s = float(tts_lead_s)
+        # ... and a queued request joins the loop once it has waited this long (at once when the lane is idle or a round is due anyway):
+        # bounds what pacing adds to a session's time-to-first-audio
+        self.tts_admit_wait_s = float(tts_admit_wait_s)
         # lane admission policy: 0 = the least loaded lanes take new sessions (spreads them over all lanes); T > 0 = fill first: lane k only
         # takes new sessions once every lane below it holds at least T live sessions (fewer frame loops running, fuller rows)
         self.tts_fill_first = int(tts_fill_first)
@@ -130,6 +134,7 @@ class SessionPool:
         while len(self._lanes) < max(1, n):
             i = len(self._lanes)
             t = threading.Thread(target=self._run_tts_lane, args=(i,), name=f"s2s-pool-{self.device}-tts{i}", daemon=True)
+            self._lane_live.setdefault(i, 0)         # (every lane's key exists before any lane iterates the dict)
             self._lane_ready.append(threading.Event())
             self._lanes.append(t)
             t.start()
@@ -315,7 +320,10 @@ class SessionPool:
                 return
             eng = replicas[model]
             reqs, back = [first], []
-            for it in self._drain(self._stt_q, int(getattr(eng, "max_batch", self.max_batch)) - 1):
+            cap = min(self.max_batch, int(getattr(eng, "max_batch", self.max_batch)))
+            if self.stt_max_batch > 0:
+                cap = min(cap, self.stt_max_batch)
+            for it in self._drain(self._stt_q, cap - 1):
                 (reqs if isinstance(it, _STTRequest) and it.model == model else back).append(it)
             for it in back:
                 self._stt_q.put(it)
@@ -391,64 +399,89 @@ class SessionPool:
     def _run_tts_lane_continuous(self, lane: int, eng: Any, first: Any, ready: threading.Event | None = None) -> None:
         """One lane as a continuously batched engine: at every chunk boundary finished sessions leave, queued requests are prefilled into
         free slots, and the frame loop goes on for everybody (speech-to-speech_amd/tts_continuous.py).  Several lanes share the request
-        queue; a busy lane only takes new requests while it is among the least loaded ones, idle lanes block on the queue."""
+        queue; a busy lane only takes new requests while it is among the least loaded ones, idle lanes block on the queue.
+
+        Pacing (round 4): the frame loop's cost per round grows far slower than its row count (csrc/gemm_decw.hip), so rounds should be
+        FULL rather than frequent.  A round runs when (a) some session's delivered audio leads its playback by less than ``tts_lead_s``,
+        or (b) a queued request has waited ``tts_admit_wait_s`` (or the lane is idle: a lone session starts at once).  With both at their
+        defaults (inf / 0) every round runs as soon as the previous one has been handed out (eager)."""
         from .tts_continuous import ROW_BUCKETS, ContinuousTTS
 
-        cb = ContinuousTTS(eng, chunk_size=self.tts_chunk_size)
-        if hasattr(eng, "prepare_admission"):
-            eng.prepare_admission()              # pinned staging of the prompt rows: allocated now, never while serving
-            cb.prepare()
-        for r in [r for r in ROW_BUCKETS if r <= cb.cap] or [cb.cap]:
-            eng.step(r, 1)                       # captures the frame graph of every row count while all slots are idle
-        self._sync_current_stream()
-        if ready is not None:
-            ready.set()
         backlog: list = [first] if first is not None else []
+        cb = None
+        try:
+            cb = ContinuousTTS(eng, chunk_size=self.tts_chunk_size)
+            if hasattr(eng, "prepare_admission"):
+                eng.prepare_admission()              # pinned staging of the prompt rows: allocated now, never while serving
+                cb.prepare()
+            for r in [r for r in ROW_BUCKETS if r <= cb.cap] or [cb.cap]:
+                eng.step(r, 1)                       # captures the frame graph of every row count while all slots are idle
+            self._sync_current_stream()
+        except BaseException as e:  # noqa: BLE001  (a lane that cannot start must not leave its requests - or warm_tts_lanes - hanging)
+            logger.error("TTS lane %d could not start: %s", lane, e, exc_info=True)
+            for job in backlog:
+                job.chunks.put(e)
+            self._lane_live[lane] = 1 << 30          # never the least loaded lane again
+            return
+        finally:
+            if ready is not None:
+                ready.set()
         stop = False
         while True:
-            self._lane_live[lane] = cb.live + len(backlog)
-            T = self.tts_fill_first
-            lower_full = T <= 0 or all(self._lane_live.get(j, 0) >= T for j in range(lane))
-            if not cb.cohorts and not backlog:
-                if stop or self._stopping:
-                    return
-                if not lower_full:               # fill first: an idle upper lane leaves the queue to the lanes below it
-                    time.sleep(0.002)
-                    continue
-                try:
-                    it = self._tts_q.get(timeout=0.05)
-                except queue.Empty:
-                    continue
-                if it is _STOP:
-                    return
-                backlog.append(it)
-                if self.batch_window_s > 0:
-                    time.sleep(self.batch_window_s)
-            others = [v for k, v in self._lane_live.items() if k != lane]
-            room = cb.free_slots - len(backlog)
-            mine = cb.live + len(backlog)
-            least = not others or mine <= min(others) + 8
-            if T > 0:        # fill first: up to T sessions per lane in lane order; once every lane holds T, the least loaded ones take the rest
-                n_lanes = max(self.tts_lanes, lane + 1)
-                all_full = mine >= T and all(self._lane_live.get(j, 0) >= T for j in range(n_lanes))
-                take = lower_full and (mine < T or (all_full and least))
-                room = min(room, T - mine) if mine < T else room
-            else:
-                take = least
-            if room > 0 and not stop and take:
-                for it in self._drain(self._tts_q, room):
-                    if it is _STOP:
-                        stop = True
-                        break
-                    backlog.append(it)
             try:
+                self._lane_live[lane] = cb.live + len(backlog)
+                T = self.tts_fill_first
+                lower_full = T <= 0 or all(self._lane_live.get(j, 0) >= T for j in range(lane))
+                if not cb.live and not backlog:
+                    if stop or self._stopping:
+                        return
+                    if not lower_full:               # fill first: an idle upper lane leaves the queue to the lanes below it
+                        time.sleep(0.002)
+                        continue
+                    try:
+                        it = self._tts_q.get(timeout=0.05)
+                    except queue.Empty:
+                        continue
+                    if it is _STOP:
+                        return
+                    backlog.append(it)
+                    if self.batch_window_s > 0:
+                        time.sleep(self.batch_window_s)
+                others = [v for k, v in list(self._lane_live.items()) if k != lane]
+                room = cb.free_slots - len(backlog)
+                mine = cb.live + len(backlog)
+                least = not others or mine <= min(others) + 8
+                if T > 0:        # fill first: up to T sessions per lane in lane order; once every lane holds T, the least loaded ones take the rest
+                    n_lanes = max(self.tts_lanes, lane + 1)
+                    all_full = mine >= T and all(self._lane_live.get(j, 0) >= T for j in range(n_lanes))
+                    take = lower_full and (mine < T or (all_full and least))
+                    room = min(room, T - mine) if mine < T else room
+                else:
+                    take = least
+                if room > 0 and not stop and take:
+                    for it in self._drain(self._tts_q, room):
+                        if it is _STOP:
+                            stop = True
+                            break
+                        backlog.append(it)
+                backlog = [r for r in backlog if not r.cancelled.is_set()]
+                now = time.perf_counter()
+                can_admit = bool(backlog) and cb.free_slots > 0
+                waited = now - min(r.t_submit for r in backlog) if backlog else 0.0
+                due = cb.live > 0 and (stop or cb.min_lead_s(now) <= self.tts_lead_s)
+                admit_now = can_admit and (cb.live == 0 or due or stop or waited >= self.tts_admit_wait_s)
+                if not admit_now and not due:
+                    time.sleep(0.002)                # everybody is far enough ahead of their playback: leave the device to STT
+                    continue
                 n0 = len(backlog)
                 t_a = time.perf_counter()
-                backlog = cb.admit(backlog)
+                if admit_now:
+                    backlog = cb.admit(backlog)
+                    for job, err in cb.rejected:     # a request the engine cannot take fails alone
+                        job.chunks.put(err)
+                    n0 -= len(cb.rejected)
+                    cb.rejected.clear()
                 t_r = time.perf_counter()
-                if n0 == len(backlog) and cb.cohorts and cb.min_lead_s(t_r) > self.tts_lead_s and not stop:
-                    time.sleep(0.004)            # everybody is far enough ahead of their playback: leave the device to STT / first chunks
-                    continue
                 rows = cb.rows()
                 for job, chunk in cb.step():
                     if chunk is None or not job.cancelled.is_set():
@@ -461,7 +494,7 @@ class SessionPool:
                     self.stats["tts_rounds"] += 1
                     self.stats["tts_round_s"] += time.perf_counter() - t_r
                     self.stats["tts_row_rounds"][rows] = self.stats["tts_row_rounds"].get(rows, 0) + 1
-            except BaseException as e:  # noqa: BLE001
+            except BaseException as e:  # noqa: BLE001  (engine failure: every live and queued session of THIS lane is failed, the lane goes on)
                 logger.error("TTS lane %d failed: %s", lane, e, exc_info=True)
                 for job in cb.abort() + backlog:
                     job.chunks.put(e)

@@ -380,6 +380,12 @@ class TTSEngine:
     def admit(self, prompts: Sequence[TTSPrompt], slot0: int, max_new_tokens: Sequence[int] | int, min_frames: Sequence[int] | int = 0,
               utterance_id0: int = 0) -> None:
         """Prefill `prompts` into the slots [slot0, slot0 + len(prompts)) while the other slots keep their state."""
+        if len(prompts) > self.ADMIT_GROUP:      # a burst: groups of ADMIT_GROUP prompts (the prefill GEMMs are chip-filling long before that)
+            per = lambda v, a, b: v if isinstance(v, int) else list(v)[a:b]     # noqa: E731
+            for a in range(0, len(prompts), self.ADMIT_GROUP):
+                b = min(len(prompts), a + self.ADMIT_GROUP)
+                self.admit(prompts[a:b], slot0 + a, per(max_new_tokens, a, b), per(min_frames, a, b), utterance_id0 + a)
+            return
         n = len(prompts)
         lens = [p.embeds.shape[0] for p in prompts]
         Tp = max(lens)
@@ -417,11 +423,14 @@ class TTSEngine:
         self._B = max(self._B, slot0 + n)
         self._keep_admit = (emb, ln, mn, bd)
 
+    ADMIT_GROUP = 64                 # most prompts per s2s_tts_admit call (bounds the pinned staging ring: 2 x 64 x max_prompt x E floats)
+
     def prepare_admission(self) -> None:
         """Allocate the pinned staging ring of `admit` (once; the session pool calls it while the lane warms up, not on the first request)."""
         if getattr(self, "_admit_host", None) is None:
-            self._admit_host = torch.empty((2 * self.max_batch * self.max_prompt * self.dims.t_hidden,), dtype=torch.float32, pin_memory=True)
-            self._admit_ints = torch.zeros((64, 3, self.max_batch), dtype=torch.int32, pin_memory=True)
+            group = min(self.max_batch, self.ADMIT_GROUP)
+            self._admit_host = torch.empty((2 * group * self.max_prompt * self.dims.t_hidden,), dtype=torch.float32, pin_memory=True)
+            self._admit_ints = torch.zeros((64, 3, group), dtype=torch.int32, pin_memory=True)
             self._admit_off, self._admit_row = 0, 0
 
     def step(self, rows: int, n_frames: int) -> None:
@@ -440,6 +449,30 @@ class TTSEngine:
             native.check(self._lib.s2s_tts_read_codes(self._h, native.stream_handle(), int(slot0), int(n), int(frame0), int(n_frames), native.ptr(codes),
                                                       native.ptr(nfr), int(chunk_samples), native.ptr(nvalid)), "s2s_tts_read_codes")
         return codes, nfr, nvalid
+
+    def read_codes_rows(self, slot0: int, n: int, frame0_rows: torch.Tensor, n_frames: int):
+        """`read_codes` for rows of different ages: frame0_rows int32 [n] on the GPU = first frame to read per slot (continuation chunks)."""
+        assert frame0_rows.dtype == torch.int32 and frame0_rows.numel() == n and frame0_rows.is_contiguous()
+        codes = torch.empty((n, n_frames, self.dims.n_groups), dtype=torch.int32, device=self.device)
+        nfr = torch.empty((n,), dtype=torch.int32, device=self.device)
+        nvalid = torch.empty((n,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_read_codes_rows(self._h, native.stream_handle(), int(slot0), int(n), native.ptr(frame0_rows), int(n_frames),
+                                                           native.ptr(codes), native.ptr(nfr), int(n_frames * self.dims.total_upsample), native.ptr(nvalid)),
+                         "s2s_tts_read_codes_rows")
+        return codes, nfr, nvalid
+
+    def codec_decode_rows_at(self, codes: torch.Tensor, slot0: int, frames_done_rows: torch.Tensor, max_frames_done: int) -> torch.Tensor:
+        """Streaming codec continuation of the rows [slot0, slot0 + B) in ONE pass, each row at its own stream position
+        (frames_done_rows int32 [B] on the GPU; rows without a live stream: any value, output ignored)."""
+        B, F, _ = codes.shape
+        assert codes.dtype == torch.int32 and codes.is_contiguous() and frames_done_rows.numel() == B
+        n = F * self.dims.total_upsample
+        wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_codec_decode_rows_at(self._h, native.stream_handle(), native.ptr(codes), int(slot0), B, F, native.ptr(frames_done_rows),
+                                                            int(max_frames_done), native.ptr(wav), n), "s2s_codec_decode_rows_at")
+        return wav
 
     def release(self, slot0: int, n: int) -> None:
         with torch.cuda.device(self.device):

@@ -7,23 +7,31 @@ frame loop are shared: at every chunk boundary (`chunk_size` codec frames) finis
 into free slots and join, and the frame loop goes on for everybody - every slot carries its own frame index / eos gate / budget on
 the device (csrc/tts.cpp: s2s_tts_admit / _step / _read_codes / _release).
 
-Sessions admitted together form a COHORT on a contiguous slot range.  The codec decoder's streaming state (conv history rows,
-pre-transformer cache) is per row, but its first chunk has a different geometry than a continuation (causal transposed convs trim
-their first output group), so the codec runs once per cohort and chunk on the cohort's rows (s2s_codec_decode_rows) - cohorts of
-different ages stream side by side.  A session's codes and samples do not depend on its slot, its cohort or its batch-mates
-(tests/test_tts_continuous_gpu.py compares a session admitted mid-stream with the same session run alone and with the oracle).
+Round 4: the loop is WIDE (up to 512 slots on the row-block decode projections of csrc/gemm_decw.hip) and a round's launch count no
+longer depends on how many admission groups are alive:
+
+* sessions admitted together form a COHORT on a contiguous slot range only for their FIRST chunk (the codec decoder's first chunk has
+  its own geometry: causal transposed convs trim their first output group) - one s2s_codec_decode_rows(frames_done = 0) per new cohort;
+* from their second chunk on, sessions are independent ROWS: all continuing rows of the lane go through ONE codec pass per round
+  (s2s_tts_read_codes_rows + s2s_codec_decode_rows_at with per-row stream positions), whatever their ages;
+* a session's slot is released the moment IT ends, and new sessions take the lowest free slots, so the rows of the frame loop stay
+  compact and the round runs at the smallest captured row count that holds them.
+
+A session's codes and samples do not depend on its slot, its cohort or its batch-mates (tests/test_tts_continuous_gpu.py compares
+sessions admitted mid-stream with the same sessions run alone and with the oracle).
 """
 
 from __future__ import annotations
 
 import threading
+import time
 from dataclasses import dataclass, field
 from typing import Any, Iterator, Sequence
 
 import numpy as np
 import torch
 
-ROW_BUCKETS = (32, 64, 128)      # frame-loop row counts with a captured graph (2 * rows must be <= 128 or a multiple of 128: predictor prefill pass)
+ROW_BUCKETS = (32, 64, 128, 192, 256, 384, 512)      # frame-loop row counts with a captured graph
 
 
 @dataclass
@@ -38,61 +46,67 @@ class TTSJob:
 
 @dataclass
 class _Cohort:
+    """Sessions admitted together, until their first chunk has been decoded."""
+
     slot0: int
     jobs: list
-    frames: int = 0                 # frames generated (= decoded) so far
-    ended: list = field(default_factory=list)     # per job: end marker delivered
-    t_first: float | None = None    # wall time its first chunk was handed out (playback starts then)
+
+
+@dataclass
+class _Row:
+    """A session from its second chunk on."""
+
+    job: Any
+    slot: int
+    frames: int                     # frames generated (= decoded) so far
+    t_first: float                  # wall time its first chunk was handed out (playback starts then)
 
 
 class ContinuousTTS:
-    def __init__(self, engine, chunk_size: int = 8, max_cohorts: int = 24):
+    def __init__(self, engine, chunk_size: int = 8, max_cohorts: int = 8):
         self.eng = engine
         self.cap = int(engine.max_batch)
         self.chunk = int(chunk_size)
-        self.max_cohorts = int(max_cohorts)
+        self.max_cohorts = int(max_cohorts)     # admission groups per round (each costs one first-chunk codec pass)
         self.record_codes = False        # tests: append every chunk's codes [n_frames][G] (numpy) to job.codes
         self.free: list[tuple[int, int]] = [(0, self.cap)]      # (start, length), sorted by start
-        self.cohorts: list[_Cohort] = []
+        self.cohorts: list[_Cohort] = []         # admitted, first chunk not yet decoded
+        self.rows_live: dict[int, _Row] = {}     # slot -> continuing session
+        self.rejected: list[tuple[Any, BaseException]] = []     # jobs refused at admission (bad prompt): the pool fails only these
         self.next_utt = 1
         self._pinned: dict[tuple, torch.Tensor] = {}
-        self._events: list = []
-        self.stats = {"admitted": 0, "cohorts": 0, "rounds": 0, "max_live": 0, "row_rounds": {}}
+        self._events: dict[Any, Any] = {}
+        self.stats = {"admitted": 0, "cohorts": 0, "rounds": 0, "max_live": 0, "row_rounds": {}, "codec_passes": 0}
         self.eng.release(0, self.cap)                           # every slot idle
 
     def prepare(self) -> None:
         """Allocate every pinned staging row and event the scheduler can ever need (the session pool calls this while the lane warms
         up: a pinned allocation in the middle of serving stalls the device for every stream)."""
-        for ci in range(self.max_cohorts):
-            self._host(("pcm", ci), (1, 1), torch.int16)
-            self._host(("nfr", ci), (1,), torch.int32)
-            self._host(("nval", ci), (1,), torch.int32)
-            self._events.append(torch.cuda.Event())
+        for key in ["cont"] + list(range(self.max_cohorts)):
+            self._host(("pcm", key), (1, 1), torch.int16)
+            self._host(("nfr", key), (1,), torch.int32)
+            self._host(("nval", key), (1,), torch.int32)
+            self._event(key)
+        self._host(("frames", "cont"), (1,), torch.int32)
 
     # ---- slots ------------------------------------------------------------------------------------
     @property
     def live(self) -> int:
-        return sum(len(c.jobs) for c in self.cohorts)
+        return sum(len(c.jobs) for c in self.cohorts) + len(self.rows_live)
 
     @property
     def free_slots(self) -> int:
         return sum(n for _, n in self.free)
 
     def _take(self, want: int) -> tuple[int, int]:
-        """Lowest free range that holds `want` slots, else the largest one (partly filled requests come back as a remainder)."""
-        best = None
-        for i, (s, n) in enumerate(self.free):
-            if n >= want:
-                best = i
-                break
-        if best is None:
-            best = max(range(len(self.free)), key=lambda i: self.free[i][1])
-        s, n = self.free[best]
+        """The LOWEST free range, up to `want` slots of it (keeps the occupied rows compact: the frame loop runs over [0, highest
+        occupied slot], rounded up to a captured row count)."""
+        s, n = self.free[0]
         k = min(n, want)
         if k == n:
-            self.free.pop(best)
+            self.free.pop(0)
         else:
-            self.free[best] = (s + k, n - k)
+            self.free[0] = (s + k, n - k)
         return s, k
 
     def _give(self, s: int, n: int) -> None:
@@ -107,16 +121,47 @@ class ContinuousTTS:
         self.free = merged
 
     # ---- admission --------------------------------------------------------------------------------
+    def _check(self, job: Any) -> BaseException | None:
+        """A request the engine cannot take fails ALONE (it must not take the lane's live sessions with it)."""
+        try:
+            emb = getattr(job.prompt, "embeds", None)
+            if emb is None:              # (not an embedding prompt - e.g. a test double's: the engine's own checks apply)
+                return None
+            if emb.ndim != 2 or emb.shape[1] != self.eng.dims.t_hidden:
+                return ValueError(f"TTS prompt rows have width {emb.shape[-1]}, the engine expects {self.eng.dims.t_hidden}")
+            if not 2 <= emb.shape[0] <= self.eng.max_prompt:
+                return ValueError(f"TTS prompt of {emb.shape[0]} rows (engine: 2 .. {self.eng.max_prompt})")
+            if int(job.max_new_tokens) < 1:
+                return ValueError("max_new_tokens must be >= 1")
+        except Exception as e:  # noqa: BLE001
+            return e
+        return None
+
     def admit(self, jobs: Sequence[Any]) -> list:
-        """Prefill as many of `jobs` as there are free slots (contiguous ranges -> cohorts); returns the jobs that did not fit."""
-        jobs = [j for j in jobs if not j.cancelled.is_set()]
+        """Prefill as many of `jobs` as there are free slots (contiguous ranges -> cohorts); returns the jobs that did not fit.  Jobs the
+        engine cannot take are moved to ``self.rejected`` with their error."""
+        ok = []
+        for j in jobs:
+            if j.cancelled.is_set():
+                continue
+            err = self._check(j)
+            if err is not None:
+                self.rejected.append((j, err))
+            else:
+                ok.append(j)
+        jobs = ok
         while jobs and self.free and len(self.cohorts) < self.max_cohorts:
             s, k = self._take(len(jobs))
             group, jobs = list(jobs[:k]), list(jobs[k:])
             budgets = [max(1, min(int(j.max_new_tokens), self.eng.max_frames)) for j in group]
-            self.eng.admit([j.prompt for j in group], s, budgets, [int(j.min_frames) for j in group], utterance_id0=self.next_utt)
+            try:
+                self.eng.admit([j.prompt for j in group], s, budgets, [int(j.min_frames) for j in group], utterance_id0=self.next_utt)
+            except Exception as e:  # noqa: BLE001  (per cohort: the sessions already live keep streaming)
+                self._give(s, k)
+                self.rejected.extend((j, e) for j in group)
+                continue
             self.next_utt += k
-            self.cohorts.append(_Cohort(s, group, 0, [False] * k))
+            self.cohorts.append(_Cohort(s, group))
             self.stats["admitted"] += k
             self.stats["cohorts"] += 1
         self.stats["max_live"] = max(self.stats["max_live"], self.live)
@@ -124,7 +169,7 @@ class ContinuousTTS:
 
     # ---- one chunk for everybody --------------------------------------------------------------------
     def _host(self, key: tuple, shape, dtype) -> torch.Tensor:
-        """Pinned staging rows, allocated ONCE per cohort index at the largest size it can ever need (a pinned allocation synchronises
+        """Pinned staging rows, allocated ONCE per pass at the largest size it can ever need (a pinned allocation synchronises
         the whole device - every other stream, the STT worker's included - so nothing is allocated while serving); returned as a
         contiguous view of the requested shape."""
         flat = self._pinned.get(key)
@@ -136,97 +181,156 @@ class ContinuousTTS:
             n *= int(d)
         return flat[:n].view(*shape)
 
+    def _event(self, key):
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        return ev
+
     def rows(self) -> int:
-        hi = max((c.slot0 + len(c.jobs) for c in self.cohorts), default=0)
+        hi = max([c.slot0 + len(c.jobs) for c in self.cohorts] + [s + 1 for s in self.rows_live], default=0)
         for r in ROW_BUCKETS:
             if hi <= r and r <= self.cap:
                 return r
         return self.cap
 
+    def _stage(self, key, pcm, nfr, nvalid, codes):
+        k = pcm.shape[0]
+        h_pcm = self._host(("pcm", key), pcm.shape, torch.int16)
+        h_nfr = self._host(("nfr", key), (k,), torch.int32)
+        h_nval = self._host(("nval", key), (k,), torch.int32)
+        h_pcm.copy_(pcm, non_blocking=True)
+        h_nfr.copy_(nfr, non_blocking=True)
+        h_nval.copy_(nvalid, non_blocking=True)
+        h_codes = None
+        if self.record_codes:
+            h_codes = torch.empty(codes.shape, dtype=torch.int32, pin_memory=True)      # (tests only)
+            h_codes.copy_(codes, non_blocking=True)
+        ev = self._event(key)
+        ev.record()
+        return h_pcm, h_nfr, h_nval, h_codes, ev
+
+    def _deliver(self, job, frames0: int, n: int, nfr: int, nval: int, pcm_row, codes_row):
+        """-> (items to yield for this job, ended).  frames0: frames the session had before this chunk."""
+        out = []
+        if codes_row is not None:
+            if not hasattr(job, "codes"):
+                job.codes = []
+            job.codes.append(codes_row.copy())
+        budget = max(1, min(int(job.max_new_tokens), self.eng.max_frames))
+        valid = int(min(nfr, budget)) - frames0
+        if job.cancelled.is_set():
+            valid = 0
+        if valid >= n:
+            out.append((job, pcm_row.copy()))
+        elif valid > 0:      # the utterance ended inside this chunk: only the samples of its valid frames
+            out.append((job, pcm_row[: (2 * int(nval) + 2) // 3].copy()))
+        ended = valid < n or frames0 + n >= budget
+        if ended:
+            out.append((job, None))
+        return out, ended
+
     def step(self) -> Iterator[tuple[Any, np.ndarray | None]]:
         """`chunk_size` more frames for every live session; yields (job, int16 16 kHz chunk) and, once per job, (job, None) at its end.
-        Cohorts are decoded youngest first, and each one's audio is handed out as soon as ITS copies have landed."""
-        if not self.cohorts:
+        One codec pass for ALL continuing rows, one per newly admitted cohort; each pass's audio is handed out as soon as ITS copies
+        have landed."""
+        if not self.cohorts and not self.rows_live:
             return
         eng, n = self.eng, self.chunk
         rows = self.rows()
         self.stats["rounds"] += 1
         self.stats["row_rounds"][rows] = self.stats["row_rounds"].get(rows, 0) + 1
         eng.step(rows, n)
-        pending = []
-        for ci, c in enumerate(sorted(self.cohorts, key=lambda c: c.frames)):
+        cont = None
+        if self.rows_live:
+            # Continuation pass over the slot range that holds every continuing row.  Slots of the range without a continuing row (idle,
+            # or a cohort whose first chunk follows below) are computed with position 0 and ignored: their codec state is rewritten by
+            # the first chunk of the stream that owns / will own the slot - which is why this pass runs BEFORE the first-chunk passes.
+            lo, hi = min(self.rows_live), max(self.rows_live) + 1
+            k = hi - lo
+            h_fr = self._host(("frames", "cont"), (k,), torch.int32)
+            h_fr.zero_()
+            fr_np = h_fr.numpy()
+            for s, r in self.rows_live.items():
+                fr_np[s - lo] = r.frames
+            d_fr = h_fr.to(eng.device, non_blocking=True)
+            codes, nfr, nvalid = eng.read_codes_rows(lo, k, d_fr, n)
+            wav = eng.codec_decode_rows_at(codes, lo, d_fr, max(r.frames for r in self.rows_live.values()))
+            pcm = eng.resample_int16(wav, nvalid)
+            cont = (lo, k, self._stage("cont", pcm, nfr, nvalid, codes), (pcm, nfr, codes, wav, nvalid, d_fr))
+            self.stats["codec_passes"] += 1
+        firsts = []
+        for ci, c in enumerate(self.cohorts):
             k = len(c.jobs)
-            codes, nfr, nvalid = eng.read_codes(c.slot0, k, c.frames, n)
-            wav = eng.codec_decode_rows(codes, c.slot0, c.frames)
+            codes, nfr, nvalid = eng.read_codes(c.slot0, k, 0, n)
+            wav = eng.codec_decode_rows(codes, c.slot0, 0)
             pcm = eng.resample_int16(wav, nvalid)       # samples past a session's last valid frame are silence to the resampler
-            h_pcm = self._host(("pcm", ci), pcm.shape, torch.int16)
-            h_nfr = self._host(("nfr", ci), (k,), torch.int32)
-            h_nval = self._host(("nval", ci), (k,), torch.int32)
-            h_pcm.copy_(pcm, non_blocking=True)
-            h_nfr.copy_(nfr, non_blocking=True)
-            h_nval.copy_(nvalid, non_blocking=True)
-            h_codes = None
-            if self.record_codes:
-                h_codes = torch.empty(codes.shape, dtype=torch.int32, pin_memory=True)      # (tests only)
-                h_codes.copy_(codes, non_blocking=True)
-            while len(self._events) <= ci:
-                self._events.append(torch.cuda.Event())
-            ev = self._events[ci]
-            ev.record()
-            pending.append((c, h_pcm, (h_nfr, h_nval), ev, (pcm, nfr, codes, wav, nvalid), h_codes))
-        import time as _time
+            firsts.append((c, self._stage(ci, pcm, nfr, nvalid, codes), (pcm, nfr, codes, wav, nvalid)))
+            self.stats["codec_passes"] += 1
 
-        for c, h_pcm, h_nfr, ev, _keep, h_codes in pending:
+        ended_slots: list[int] = []
+        if cont is not None:
+            lo, k, (h_pcm, h_nfr, h_nval, h_codes, ev), _keep = cont
             ev.synchronize()
-            if c.t_first is None:
-                c.t_first = _time.perf_counter()
-            pcm_h, nfr_h, nval_h = h_pcm.numpy(), h_nfr[0].numpy(), h_nfr[1].numpy()       # (views of the pinned rows)
+            pcm_h, nfr_h, nval_h = h_pcm.numpy(), h_nfr.numpy(), h_nval.numpy()       # (views of the pinned rows)
+            for s in sorted(self.rows_live):
+                r = self.rows_live[s]
+                i = s - lo
+                items, ended = self._deliver(r.job, r.frames, n, nfr_h[i], nval_h[i], pcm_h[i], h_codes[i].numpy() if h_codes is not None else None)
+                yield from items
+                r.frames += n
+                if ended:
+                    ended_slots.append(s)
+        for c, (h_pcm, h_nfr, h_nval, h_codes, ev), _keep in firsts:
+            ev.synchronize()
+            t_first = time.perf_counter()
+            pcm_h, nfr_h, nval_h = h_pcm.numpy(), h_nfr.numpy(), h_nval.numpy()
             for i, job in enumerate(c.jobs):
-                if c.ended[i]:
-                    continue
-                if h_codes is not None:
-                    if not hasattr(job, "codes"):
-                        job.codes = []
-                    job.codes.append(h_codes[i].numpy().copy())
-                budget = max(1, min(int(job.max_new_tokens), eng.max_frames))
-                valid = int(min(nfr_h[i], budget)) - c.frames
-                if job.cancelled.is_set():
-                    valid = 0
-                if valid >= n:
-                    yield job, pcm_h[i].copy()
-                elif valid > 0:      # the utterance ended inside this chunk: only the samples of its valid frames
-                    yield job, pcm_h[i][: (2 * int(nval_h[i]) + 2) // 3].copy()
-                if valid < n or c.frames + n >= budget:
-                    c.ended[i] = True
-                    yield job, None
-            c.frames += n
-        for c in [c for c in self.cohorts if all(c.ended)]:
-            eng.release(c.slot0, len(c.jobs))
-            self._give(c.slot0, len(c.jobs))
-            self.cohorts.remove(c)
+                items, ended = self._deliver(job, 0, n, nfr_h[i], nval_h[i], pcm_h[i], h_codes[i].numpy() if h_codes is not None else None)
+                yield from items
+                if ended:
+                    ended_slots.append(c.slot0 + i)
+                else:
+                    self.rows_live[c.slot0 + i] = _Row(job, c.slot0 + i, n, t_first)
+        self.cohorts = []
+        # a finished session's slot is free at once (contiguous runs released with one call)
+        ended_slots.sort()
+        i = 0
+        while i < len(ended_slots):
+            j = i
+            while j + 1 < len(ended_slots) and ended_slots[j + 1] == ended_slots[j] + 1:
+                j += 1
+            s0, cnt = ended_slots[i], j - i + 1
+            eng.release(s0, cnt)
+            self._give(s0, cnt)
+            for s in ended_slots[i : j + 1]:
+                self.rows_live.pop(s, None)
+            i = j + 1
 
     FRAME_S = 0.08                   # one codec frame = 80 ms of audio (12.5 Hz)
 
     def min_lead_s(self, now: float) -> float:
-        """Smallest audio lead over the live cohorts: seconds of already delivered audio that playback has not reached yet
+        """Smallest audio lead over the live sessions: seconds of already delivered audio that playback has not reached yet
         (first chunk handed out at t_first, frames * 80 ms delivered).  A cohort still waiting for its first chunk has lead -inf."""
+        if self.cohorts:
+            return float("-inf")
         lead = float("inf")
-        for c in self.cohorts:
-            lead = min(lead, float("-inf") if c.t_first is None else c.t_first + c.frames * self.FRAME_S - now)
+        for r in self.rows_live.values():
+            lead = min(lead, r.t_first + r.frames * self.FRAME_S - now)
         return lead
 
     def drain(self) -> Iterator[tuple[Any, np.ndarray | None]]:
-        while self.cohorts:
+        while self.cohorts or self.rows_live:
             yield from self.step()
 
     def abort(self, err: BaseException | None = None) -> list:
         """Drop every live session (engine failure / shutdown); returns their jobs."""
-        jobs = [j for c in self.cohorts for j, e in zip(c.jobs, c.ended) if not e]
-        for c in self.cohorts:
-            try:
-                self.eng.release(c.slot0, len(c.jobs))
-            except Exception:  # noqa: BLE001
-                pass
+        jobs = [j for c in self.cohorts for j in c.jobs] + [r.job for r in self.rows_live.values()]
+        try:
+            self.eng.release(0, self.cap)
+        except Exception:  # noqa: BLE001
+            pass
         self.cohorts = []
+        self.rows_live = {}
         self.free = [(0, self.cap)]
         return jobs

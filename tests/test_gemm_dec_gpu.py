@@ -314,10 +314,16 @@ def _tune(enable=1, splitk=0, nt=0):
     native.check(native.load().s2s_op_gemm_dec_tune(enable, splitk, nt), "tune")
 
 
+def _wtune(enable=1, splitk=0, min_m=129):
+    native.check(native.load().s2s_op_gemm_decw_tune(enable, splitk, min_m), "wide tune")
+
+
 @pytest.fixture
 def dec2_default():
+    _wtune(0)            # these tests cover the <= 128-row kernels and their row slabs: the row-block kernel (gemm_decw.hip) stays out
     yield
     _tune(1, 0, 0)
+    _wtune(1)
 
 
 D2_SHAPES = [  # M, N, K  (fragment-major A): talker / predictor / Whisper decoder / codec pre-transformer projections
@@ -452,7 +458,7 @@ def test_norm_free_layer_chain_in_engine_layouts(M, hid, ffn, heads_dim, dec2_de
         qkv = torch.zeros(Mp * heads_dim, dtype=torch.bfloat16, device=DEV)
         gemm_dec(XB, Wq_f, M, heads_dim, hid, ss_in=ssA, n_parts=1, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv, a_frag=True, c_frag=True,
                  ldc=heads_dim, w_is_frag=True)
-        parts_o = lib.s2s_op_gemm_dec_parts(min(M, 128), hid, heads_dim, 0, 1)
+        parts_o = lib.s2s_op_gemm_dec_parts(M, hid, heads_dim, 0, 1)
         gemm_dec(qkv, Wo_f, M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB, ss_stride=S, a_frag=True, xb_frag=True, ldxb=hid, w_is_frag=True)
         a = torch.zeros(Mp * ffn, dtype=torch.bfloat16, device=DEV)
         gemm_dec(XB, Wgu_f, M, ffn, hid, ss_in=ssB, n_parts=parts_o, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True, a_frag=True, c_frag=True,
@@ -560,3 +566,207 @@ def test_layernorm_free_whisper_block_matches_layernorm_linear_reference(M, d, f
     scale = x_ref.abs().max().item()
     print(f"LayerNorm-free Whisper block M={M} d={d}: max|err| vs the float64 LayerNorm -> Linear chain {err:.3e} (|x| max {scale:.2f}, fc2 partials {p2})")
     assert err <= 3e-2 * scale
+
+
+# ------------------------------------------------------------------------------------------------ row-block kernel of wide frame loops
+@pytest.fixture
+def decw_default():
+    _wtune(1)
+    yield
+    _wtune(1)
+    _tune(1, 0, 0)
+
+
+DW_SHAPES = [  # M, N, K (fragment-major A): the talker / predictor projections at 256 / 512 slots, the predictor's two-row pass (2 x 512), ragged
+    (256, 4096, 2048), (512, 2048, 2048), (512, 2048, 6144), (384, 4096, 1024), (1024, 1024, 3072), (130, 1000, 1280), (200, 2048, 1024), (512, 1024, 2048),
+]
+
+
+@pytest.mark.parametrize("M,N,K", DW_SHAPES)
+def test_gemm_decw_modes_match_float64(M, N, K, decw_default):
+    """Every epilogue of the row-block kernel vs float64, for the library's own K-slice choice and for every forced one; bit-identical run
+    to run (slices are combined in slice order, whoever arrives last)."""
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(M * 5 + N + K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    Wf = to_frag(W)
+    Af = to_frag(A.to(DEV))
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    parts = 19
+    S = 1024
+    ss = (torch.rand(parts, S, generator=g) * K / parts).to(DEV)
+    inv_dim, eps = 1.0 / K, 1e-6
+    rstd = torch.rsqrt(_f64(ss)[:, :M].sum(0) * inv_dim + eps)
+    ref = (_f64(A) @ _f64(W).T) * rstd[:, None] + _f64(bias)
+    Mp = (M + 15) // 16 * 16
+    steps = K // 32
+    for sk in [0] + [s for s in (1, 2, 3, 4) if steps % s == 0 and steps // s >= 8]:
+        _wtune(1, sk)
+        for act in (native.ACT_NONE, native.ACT_GELU):
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            gemm_dec(Af, Wf, M, N, K, bias=bias, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=inv_dim, eps=eps, mode=0, C_out=out, act=act, a_frag=True, w_is_frag=True)
+            want = _act(ref, act)
+            assert (_f64(out) - want).abs().max().item() <= 5e-3 * want.abs().max().item(), ("mode0", sk, act)
+            if N % 32 == 0:
+                Cf = torch.zeros(Mp * N, dtype=torch.bfloat16, device=DEV)
+                gemm_dec(Af, Wf, M, N, K, bias=bias, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=inv_dim, eps=eps, mode=0, C_out=Cf, act=act, a_frag=True, c_frag=True,
+                         ldc=N, w_is_frag=True)
+                assert torch.equal(from_frag(Cf, M, N), out.cpu()), ("mode0 frag", sk, act)
+        # mode 2: residual + bf16 copy + ONE partial sum of squares per 128-column block
+        X0 = torch.randn(M, N, generator=g)
+        xb_frag = N % 32 == 0
+        n_out = lib.s2s_op_gemm_dec_parts(M, N, K, 0, 1)
+        assert n_out == (N + 127) // 128
+        runs = []
+        for _ in range(2):
+            X = X0.clone().to(DEV)
+            XB = torch.zeros(Mp * N if xb_frag else M * N, dtype=torch.bfloat16, device=DEV)
+            sso = torch.full((n_out, S), -1.0, device=DEV)
+            gemm_dec(Af, Wf, M, N, K, bias=bias, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=inv_dim, eps=eps, mode=2, X=X, XB=XB, ss_out=sso, a_frag=True,
+                     xb_frag=xb_frag, ldxb=N, w_is_frag=True)
+            runs.append((X, XB, sso))
+        X, XB, sso = runs[0]
+        assert torch.equal(X, runs[1][0]) and torch.equal(XB, runs[1][1]) and torch.equal(sso, runs[1][2]), ("not run-to-run deterministic", sk)
+        want = ref + _f64(X0)
+        assert (_f64(X) - want).abs().max().item() <= 3e-4 * want.abs().max().item(), ("mode2", sk)
+        got_xb = from_frag(XB, M, N) if xb_frag else XB.view(M, N).cpu()
+        assert torch.equal(got_xb, X.cpu().to(torch.bfloat16)), ("mode2 xb", sk)
+        want_ss = (_f64(X) ** 2).sum(1)
+        assert (_f64(sso)[:, :M].sum(0) - want_ss).abs().max().item() <= 1e-4 * want_ss.max().item(), ("mode2 ss", sk)
+        assert bool((sso[:, M:] == -1.0).all()), "partials written past M"
+        # mode 1: f32 head; and without the RMS prologue / bias
+        out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        gemm_dec(Af, Wf, M, N, K, bias=bias, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=inv_dim, eps=eps, mode=1, C_out=out, a_frag=True, w_is_frag=True)
+        assert (_f64(out) - ref).abs().max().item() <= 3e-4 * ref.abs().max().item(), ("mode1", sk)
+        out.zero_()
+        gemm_dec(Af, Wf, M, N, K, mode=1, C_out=out, a_frag=True, w_is_frag=True)
+        plain = _f64(A) @ _f64(W).T
+        assert (_f64(out) - plain).abs().max().item() <= 3e-4 * plain.abs().max().item(), ("mode1 plain", sk)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 6144, 2048), (512, 3072, 1024), (200, 1008, 1280), (1024, 3072, 1024)])
+def test_gemm_decw_swiglu_matches_float64(M, N, K, decw_default):
+    g = torch.Generator(device="cpu").manual_seed(N + K + M + 3)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(2 * N, K, generator=g) * K ** -0.5).to(DEV)
+    Wf, Af = to_frag(W), to_frag(A.to(DEV))
+    parts, S = 24, 1024
+    ss = (torch.rand(parts, S, generator=g) * K / parts).to(DEV)
+    rstd = torch.rsqrt(_f64(ss)[:, :M].sum(0) / K + 1e-6)
+    gate = (_f64(A) @ _f64(W[:N]).T) * rstd[:, None]
+    up = (_f64(A) @ _f64(W[N:]).T) * rstd[:, None]
+    want = torch.nn.functional.silu(gate) * up
+    Mp = (M + 15) // 16 * 16
+    steps = K // 32
+    for sk in [0] + [s for s in (1, 2, 4) if steps % s == 0 and steps // s >= 8]:
+        _wtune(1, sk)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        gemm_dec(Af, Wf, M, N, K, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=1.0 / K, eps=1e-6, mode=0, C_out=out, glu=True, a_frag=True, w_is_frag=True)
+        assert (_f64(out) - want).abs().max().item() <= 6e-3 * want.abs().max().item(), sk
+        if N % 32 == 0:
+            Cf = torch.zeros(Mp * N, dtype=torch.bfloat16, device=DEV)
+            gemm_dec(Af, Wf, M, N, K, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=1.0 / K, eps=1e-6, mode=0, C_out=Cf, glu=True, a_frag=True, c_frag=True, ldc=N,
+                     w_is_frag=True)
+            assert torch.equal(from_frag(Cf, M, N), out.cpu()), sk
+
+
+@pytest.mark.parametrize("M,hid,ffn,heads_dim", [(256, 2048, 6144, 2048), (512, 2048, 6144, 2048), (512, 1024, 3072, 2048), (1000, 1024, 3072, 2048)])
+def test_norm_free_layer_chain_on_the_row_block_kernel(M, hid, ffn, heads_dim, decw_default):
+    """The layer chain of tts.cpp::stack_forward_dec at wide row counts: the row-block kernel (every projection with its own K-slice
+    choice, partial sums per 128-column block) vs the float64 chain with the engine's rounding points, and vs the same chain on the
+    128-row slabs of the <= 128-row kernels."""
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(hid + M + 2)
+    x0 = torch.randn(M, hid, generator=g)
+    g1 = 1.0 + 0.1 * torch.randn(hid, generator=g)
+    g2 = 1.0 + 0.1 * torch.randn(hid, generator=g)
+    Wq = _bf(torch.randn(heads_dim, hid, generator=g) * hid ** -0.5)
+    Wo = _bf(torch.randn(hid, heads_dim, generator=g) * heads_dim ** -0.5)
+    Wgu = _bf(torch.randn(2 * ffn, hid, generator=g) * hid ** -0.5)
+    Wd = _bf(torch.randn(hid, ffn, generator=g) * ffn ** -0.5)
+    Wq_n, Wgu_n = _bf(Wq.float() * g1), _bf(Wgu.float() * g2)
+    eps = 1e-6
+    x = x0.double()
+    q = _bf((_bf(x.float()).double() @ _f64(Wq_n).T * torch.rsqrt((x ** 2).mean(-1, keepdim=True) + eps)).float()).double()
+    x = x + q @ _f64(Wo).T
+    gu = _bf(x.float()).double() @ _f64(Wgu_n).T * torch.rsqrt((x ** 2).mean(-1, keepdim=True) + eps)
+    act = _bf((torch.nn.functional.silu(gu[:, :ffn]) * gu[:, ffn:]).float()).double()
+    x_ref = x + act @ _f64(Wd).T
+    Wq_f, Wgu_f, Wo_f, Wd_f = to_frag(Wq.to(DEV), g1.to(DEV)), to_frag(Wgu.to(DEV), g2.to(DEV)), to_frag(Wo.to(DEV)), to_frag(Wd.to(DEV))
+    Mp = (M + 15) // 16 * 16
+    S = 1024
+    results = []
+    for wide in ((1, 0) if M % 128 == 0 else (1,)):
+        _wtune(wide)
+        X = x0.clone().to(DEV)
+        XB = torch.zeros(Mp * hid, dtype=torch.bfloat16, device=DEV)
+        ssA = torch.zeros(256, S, device=DEV)
+        ssB = torch.zeros(256, S, device=DEV)
+        native.check(lib.s2s_op_rows_prep(native.stream_handle(), native.ptr(X), hid, native.ptr(XB), hid, native.ptr(ssA), M, hid, 1), "rows_prep")
+        qkv = torch.zeros(Mp * heads_dim, dtype=torch.bfloat16, device=DEV)
+        gemm_dec(XB, Wq_f, M, heads_dim, hid, ss_in=ssA, n_parts=1, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=qkv, a_frag=True, c_frag=True,
+                 ldc=heads_dim, w_is_frag=True)
+        parts_o = lib.s2s_op_gemm_dec_parts(M, hid, heads_dim, 0, 1)
+        gemm_dec(qkv, Wo_f, M, hid, heads_dim, mode=2, X=X, XB=XB, ss_out=ssB, ss_stride=S, a_frag=True, xb_frag=True, ldxb=hid, w_is_frag=True)
+        a = torch.zeros(Mp * ffn, dtype=torch.bfloat16, device=DEV)
+        gemm_dec(XB, Wgu_f, M, ffn, hid, ss_in=ssB, n_parts=parts_o, ss_stride=S, inv_dim=1.0 / hid, eps=eps, mode=0, C_out=a, glu=True, a_frag=True, c_frag=True,
+                 ldc=ffn, w_is_frag=True)
+        gemm_dec(a, Wd_f, M, hid, ffn, mode=2, X=X, XB=XB, ss_out=ssA, ss_stride=S, a_frag=True, xb_frag=True, ldxb=hid, w_is_frag=True)
+        err = (_f64(X) - x_ref).abs().max().item()
+        scale = x_ref.abs().max().item()
+        print(f"layer chain M={M} hid={hid} row-block kernel={'on' if wide else 'off (128-row slabs)'}: max|err| {err:.3e} (|x| max {scale:.2f}), out-proj partials {parts_o}")
+        assert err <= 2e-2 * scale
+        if wide:
+            assert parts_o == hid // 128
+        results.append(X.clone())
+    if len(results) == 2:
+        assert (results[0] - results[1]).abs().max().item() <= 2e-2 * x_ref.abs().max().item()
+
+
+def test_gemm_decw_layernorm_prologue_matches_float64(decw_default):
+    """The LayerNorm prologue (pair partials, column sums) on the row-block kernel: out = rstd (A W'^T - mean csum) + b'."""
+    lib = native.load()
+    M, d, N = 256, 1280, 1280
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.7 * torch.randn(M, 1, generator=g)
+    gam, bet = 1.0 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    W, b = _bf(torch.randn(N, d, generator=g) * d ** -0.5), torch.randn(N, generator=g) * 0.1
+    eps = 1e-5
+    want = _bf(torch.nn.functional.layer_norm(x.double(), (d,), gam.double(), bet.double(), eps).float()).double() @ _f64(W).T + b.double()
+    Wf = to_frag(W.to(DEV), gam.to(DEV))
+    bias = (b + W.float() @ bet).to(DEV)
+    csum = _bf(W.float() * gam).float().sum(1).to(DEV)
+    S = 1024
+    X = x.clone().to(DEV)
+    XB = torch.zeros(M * d, dtype=torch.bfloat16, device=DEV)
+    ss = torch.zeros(8, S, device=DEV)
+    st = native.stream_handle()
+    native.check(lib.s2s_op_rows_prep_pairs(st, native.ptr(X), d, native.ptr(XB), d, native.ptr(ss), M, d, 1, S), "rows_prep_pairs")
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    native.check(lib.s2s_op_gemm_dec_ln(st, native.ptr(XB), d, native.ptr(Wf), d, native.ptr(bias), M, N, d, native.ptr(ss), 2, S, 1.0 / d, eps, 1,
+                                        native.ptr(out), N, 0, 1, native.ptr(csum)), "gemm_dec_ln")
+    err = (_f64(out) - want).abs().max().item()
+    assert err <= 3e-2 * want.abs().max().item(), err
+
+
+def test_gemm_decw_ticket_handoff_stress(decw_default):
+    """K-slices combined by the last arriver: 60 rounds of back-to-back launches of three shapes through ONE workspace must all give the
+    bit-identical result."""
+    g = torch.Generator(device="cpu").manual_seed(13)
+    cases = []
+    for (M, N, K, sk) in [(512, 2048, 6144, 4), (256, 2048, 2048, 4), (384, 1024, 3072, 3)]:
+        A = _bf(torch.randn(M, K, generator=g))
+        W = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+        cases.append((M, N, K, sk, to_frag(A.to(DEV)), to_frag(W), _f64(A) @ _f64(W).T))
+    first = {}
+    for it in range(60):
+        for ci, (M, N, K, sk, Af, Wf, ref) in enumerate(cases):
+            _wtune(1, sk)
+            out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+            gemm_dec(Af, Wf, M, N, K, mode=1, C_out=out, a_frag=True, w_is_frag=True)
+            if ci not in first:
+                assert (_f64(out) - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+                first[ci] = out.clone()
+            else:
+                assert torch.equal(out, first[ci]), f"run {it} of case {ci} differs from the first run"

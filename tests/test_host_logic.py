@@ -267,7 +267,7 @@ def test_prof_families_reducer_on_a_synthetic_stats_csv(tmp_path):
     assert "gemm_tile" in out and "2.50 ms per turn-batch" in out
 
 
-def test_continuous_tts_slot_allocator_prefers_contiguous_runs():
+def test_continuous_tts_slot_allocator_takes_the_lowest_free_slots():
     from speech_to_speech_amd.tts_continuous import ContinuousTTS
 
     class Stub:
@@ -280,24 +280,23 @@ def test_continuous_tts_slot_allocator_prefers_contiguous_runs():
     assert cb._take(3) == (0, 3) and cb._take(2) == (3, 2) and cb.free == [(5, 3)]
     cb._give(0, 3)
     assert cb.free == [(0, 3), (5, 3)]
-    assert cb._take(3) == (0, 3)                 # lowest range that fits
+    assert cb._take(2) == (0, 2) and cb.free == [(2, 1), (5, 3)]      # always the lowest range: the occupied rows stay compact
+    assert cb._take(4) == (2, 1)                  # ... even when it is shorter than the request (the rest forms another cohort)
     cb._give(3, 2)
     assert cb.free == [(3, 5)]                   # merged with its neighbour
-    assert cb._take(7) == (3, 5)                 # nothing holds 7: the largest range, partly
     cb._give(0, 3)
-    cb._give(3, 5)
     assert cb.free == [(0, 8)]
 
 
 class _StubTTSEngine:
-    """Records what the continuous-batching scheduler asks of an engine and answers with deterministic 'audio' (no GPU): slot s of a
-    cohort that has produced f frames yields chunks whose samples encode (utterance id, frame)."""
+    """Records what the continuous-batching scheduler asks of an engine and answers with deterministic 'audio' (no GPU)."""
 
     class _Dims:
         total_upsample, n_groups, t_hidden = 12, 2, 4
 
-    max_batch, max_frames = 8, 32
+    max_batch, max_frames, max_prompt = 8, 32, 16
     dims = _Dims()
+    device = "cpu"
 
     def __init__(self):
         self.log, self.slots = [], {}
@@ -308,6 +307,8 @@ class _StubTTSEngine:
             self.slots.pop(s, None)
 
     def admit(self, prompts, s0, budgets, mins, utterance_id0=0):
+        if any(getattr(p, "poison", False) for p in prompts):
+            raise RuntimeError("the engine refuses this cohort")
         self.log.append(("admit", s0, len(prompts)))
         for i in range(len(prompts)):
             assert s0 + i not in self.slots, "slot admitted twice"
@@ -320,64 +321,102 @@ class _StubTTSEngine:
             lim = st["budget"] if st["eos"] is None else min(st["budget"], st["eos"])
             st["frames"] = min(st["frames"] + n, lim)
 
+    # codes / audio: what the scheduler reads back (frames so far per slot; idle slots of a range read as 0)
+    def _nfr(self, s0, n):
+        import torch
 
-def test_continuous_tts_scheduler_admits_retires_and_orders_cohorts(monkeypatch):
-    """ContinuousTTS on a stub engine (pure host logic): contiguous slot ranges, row buckets, youngest cohort first, one end marker per
-    job, budgets and eos inside a chunk, cancellation, slots returned and reused."""
+        return torch.tensor([self.slots.get(s0 + i, {"frames": 0})["frames"] for i in range(n)], dtype=torch.int32)
+
+    def read_codes(self, s0, n, f0, F):
+        import torch
+
+        self.log.append(("decode_first", s0, n))
+        nfr = self._nfr(s0, n)
+        nval = torch.tensor([max(0, min(int(v) - f0, F)) * self.dims.total_upsample for v in nfr], dtype=torch.int32)
+        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
+
+    def read_codes_rows(self, s0, n, frame0_rows, F):
+        import torch
+
+        self.log.append(("decode_rows", s0, n, [int(v) for v in frame0_rows]))
+        nfr = self._nfr(s0, n)
+        nval = torch.tensor([max(0, min(int(v) - int(f0), F)) * self.dims.total_upsample for v, f0 in zip(nfr, frame0_rows)], dtype=torch.int32)
+        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
+
+    def codec_decode_rows(self, codes, s0, fd):
+        import torch
+
+        assert fd == 0, "only a stream's first chunk goes through the cohort entry point"
+        return torch.zeros((codes.shape[0], codes.shape[1] * self.dims.total_upsample))
+
+    def codec_decode_rows_at(self, codes, s0, frames_rows, max_done):
+        import torch
+
+        assert max_done == int(max(frames_rows))
+        return torch.zeros((codes.shape[0], codes.shape[1] * self.dims.total_upsample))
+
+    def resample_int16(self, wav, nvalid=None):
+        import torch
+
+        return torch.full((wav.shape[0], (2 * wav.shape[1] + 2) // 3), 7, dtype=torch.int16)
+
+
+class _StubEvent:
+    def record(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def test_continuous_tts_scheduler_admits_retires_and_merges_rows(monkeypatch):
+    """ContinuousTTS on a stub engine (pure host logic): lowest slots first, row buckets, ONE codec pass for all continuing rows plus one
+    per new cohort (continuing rows first: the pass may scribble over the new cohort's state rows), one end marker per job, budgets and
+    eos inside a chunk, cancellation, every slot released the moment its session ends, a refused cohort fails alone."""
     import types
 
-    import numpy as np
     import torch
 
     from speech_to_speech_amd import tts_continuous as TC
 
     eng = _StubTTSEngine()
     up, chunk = eng.dims.total_upsample, 4
-    order = []
-
-    def read_codes(s0, n, f0, F):
-        order.append(("decode", s0, f0))
-        nfr = torch.tensor([eng.slots[s0 + i]["frames"] for i in range(n)], dtype=torch.int32)
-        nval = torch.tensor([max(0, min(int(v) - f0, F)) * up for v in nfr], dtype=torch.int32)
-        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
-
-    eng.read_codes = read_codes
-    eng.codec_decode_rows = lambda codes, s0, fd: torch.zeros((codes.shape[0], codes.shape[1] * up))
-    eng.resample_int16 = lambda wav, nvalid=None: torch.full((wav.shape[0], (2 * wav.shape[1] + 2) // 3), 7, dtype=torch.int16)
-
-    class _Ev:
-        def record(self):
-            pass
-
-        def synchronize(self):
-            pass
-
-    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(torch.cuda, "Event", _StubEvent)
     monkeypatch.setattr(TC.ContinuousTTS, "_host", lambda self, key, shape, dtype: torch.empty(tuple(shape), dtype=dtype))
     cb = TC.ContinuousTTS(eng, chunk_size=chunk)
-    mk = lambda budget, eos=None: TC.TTSJob(types.SimpleNamespace(eos_at=eos), budget)      # noqa: E731
+    mk = lambda budget, eos=None, **kw: TC.TTSJob(types.SimpleNamespace(eos_at=eos, **kw), budget)      # noqa: E731
     a, b, c = mk(8), mk(6), mk(12, eos=5)
     assert cb.admit([a, b]) == [] and cb.live == 2 and cb.free == [(2, 6)] and cb.rows() == 8
     ev = list(cb.step())
     assert [(j is a, j is b) for j, ch in ev if ch is not None] == [(True, False), (False, True)] and all(ch is None or len(ch) == (2 * chunk * up + 2) // 3 for _, ch in ev)
-    assert cb.admit([c]) == []                       # joins one chunk later, in the next free slots
-    order.clear()
+    assert cb.cohorts == [] and sorted(cb.rows_live) == [0, 1]      # after their first chunk sessions are independent rows
+    assert cb.admit([c]) == []                       # joins one chunk later, in the next free slot
+    eng.log.clear()
     ev = list(cb.step())
-    assert order[0] == ("decode", 2, 0) and order[1] == ("decode", 0, 4)            # the youngest cohort (first chunk) is decoded first
+    decodes = [k for k in eng.log if k[0].startswith("decode")]
+    assert decodes == [("decode_rows", 0, 2, [4, 4]), ("decode_first", 2, 1)]       # continuing rows in ONE pass, then the new cohort
     got = {id(j): [ch for jj, ch in ev if jj is j] for j in (a, b, c)}
     assert got[id(a)][-1] is None and len(got[id(a)]) == 2                          # budget 8 = two full chunks, then the end marker
     assert got[id(b)][-1] is None and len(got[id(b)][0]) == (2 * 2 * up + 2) // 3   # budget 6: two frames of the second chunk
     assert len(got[id(c)]) == 1 and got[id(c)][0] is not None                       # c goes on
-    assert ("release", 0, 2) in eng.log and cb.free == [(0, 2), (3, 5)]
+    assert ("release", 0, 2) in eng.log and cb.free == [(0, 2), (3, 5)] and sorted(cb.rows_live) == [2]
     d = mk(16)
-    left = cb.admit([d] + [mk(4) for _ in range(7)])          # 7 free slots in two ranges: two more cohorts, one job does not fit and is handed back
-    assert len(left) == 1 and cb.free == [] and cb.stats["cohorts"] == 4
-    ev = list(cb.step())                              # c: eos at frame 5 -> one frame of its second chunk, end marker, slot freed
+    bad = mk(4, poison=True)
+    left = cb.admit([d, mk(4), bad] + [mk(4) for _ in range(5)])      # slots 0-1, then the poisoned cohort is refused alone (its slots go back)
+    assert cb.rejected and all(j is not d for j, _ in cb.rejected) and any(j is bad for j, _ in cb.rejected)
+    assert d in [j for co in cb.cohorts for j in co.jobs] and sorted(cb.rows_live) == [2]
+    cb.rejected.clear()
+    eng.log.clear()
+    ev = list(cb.step())                              # c: eos at frame 5 -> one frame of its second chunk, end marker, slot freed at once
     assert [ch is None for jj, ch in ev if jj is c] == [False, True]
+    assert any(k[0] == "release" and k[1] <= 2 < k[1] + k[2] for k in eng.log) and 2 not in cb.rows_live       # (runs of ended slots are released together)
+    rows_pass = [k for k in eng.log if k[0] == "decode_rows"]
+    assert rows_pass == [("decode_rows", 2, 1, [4])]
     d.cancelled.set()
     ev = list(cb.drain())
     assert sum(1 for jj, ch in ev if jj is d and ch is None) == 1 and not any(jj is d and ch is not None for jj, ch in ev)
     assert cb.live == 0 and cb.free == [(0, 8)] and all(k[0] != "step" or k[1] == 8 for k in eng.log)
+    assert cb.stats["codec_passes"] >= 4
 
 
 def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch):
@@ -403,23 +442,8 @@ def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch)
 
     eng.step = slow_step
 
-    def read_codes(s0, n, f0, F):
-        nfr = torch.tensor([eng.slots[s0 + i]["frames"] for i in range(n)], dtype=torch.int32)
-        nval = torch.tensor([max(0, min(int(v) - f0, F)) * up for v in nfr], dtype=torch.int32)
-        return torch.zeros((n, F, 2), dtype=torch.int32), nfr, nval
-
-    eng.read_codes = read_codes
-    eng.codec_decode_rows = lambda codes, s0, fd: torch.zeros((codes.shape[0], codes.shape[1] * up))
     eng.resample_int16 = lambda wav, nvalid=None: torch.full((wav.shape[0], (2 * wav.shape[1] + 2) // 3), 5, dtype=torch.int16)
-
-    class _Ev:
-        def record(self):
-            pass
-
-        def synchronize(self):
-            pass
-
-    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(torch.cuda, "Event", _StubEvent)
     monkeypatch.setattr(TC.ContinuousTTS, "_host", lambda self, key, shape, dtype: torch.empty(tuple(shape), dtype=dtype))
     pool = SessionPool("cpu-test-continuous", max_batch=8, batch_window_ms=0.0, tts_chunk_size=4, tts_lanes=1)
     pool._engines["tts"] = eng

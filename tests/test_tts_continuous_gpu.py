@@ -66,11 +66,12 @@ def test_sessions_joining_mid_stream_match_the_oracle_and_a_solo_run(world):
     _collect(cb.step(), audio, ended)
     # 7 sessions never fit 6 slots at once: whatever does not fit is handed back and joins once slots are free
     left = cb.admit(jobs[5:7])
-    while left or cb.cohorts:
+    while left or cb.live:
         _collect(cb.step(), audio, ended)
         left = cb.admit(left)
     assert all(ended.get(id(j)) for j in jobs) and cb.live == 0 and cb.free == [(0, 6)]
     assert cb.stats["cohorts"] >= 4
+    assert cb.stats["codec_passes"] < cb.stats["cohorts"] + cb.stats["rounds"] + 1      # one continuation pass per round, whatever the cohort count
     for i, j in enumerate(jobs):
         got = np.concatenate(j.codes)[: budgets[i]]
         assert np.array_equal(got, ref_codes[i]), f"session {i}: codes differ from the oracle run of that session alone"
@@ -110,4 +111,94 @@ def test_eos_budget_and_cancellation_free_the_slots(world):
     eng.prefill([TTSPrompt(prompts[0].numpy())])
     c, nfr, _ = eng.generate(6, min_total_frames=6)
     assert nfr.cpu().tolist() == [6] and int(c.min()) >= 0
+    eng.close()
+
+
+def test_wide_loop_high_slots_and_merged_codec_pass_match_the_oracle(world):
+    """The WIDE frame loop: a 256-slot engine whose sessions sit in slots 130 .. (the rounds run the 192 / 256-row graphs),
+    joining in three waves so that every round's continuation pass mixes rows of different ages: codes bit-exact vs the oracle run of each
+    session alone, audio equal to its solo stream."""
+    dims, sd, prompts, budgets, pad, ref_codes = world
+    eng = TTSEngine(dims, sd, dtype=torch.float32, max_batch=256, max_prompt=16, max_frames=16, max_codec_frames=8, pad_embed=pad)
+    cb = ContinuousTTS(eng, chunk_size=CHUNK)
+    cb.record_codes = True
+    assert cb._take(130) == (0, 130)                 # slots 0 .. 129 stay out of play: every session lands above the 128-row graphs
+    jobs = [TTSJob(TTSPrompt(p.numpy()), b, min_frames=b) for p, b in zip(prompts, budgets)]
+    audio, ended = {}, {}
+    assert cb.admit(jobs[0:3]) == []
+    assert cb.rows() == 192
+    _collect(cb.step(), audio, ended)
+    assert cb.admit(jobs[3:5]) == []
+    _collect(cb.step(), audio, ended)
+    cb._give(0, 130)
+    assert cb._take(70) == (0, 70)                   # the next wave lands in slots 70 ..: the continuation range [70, 135) holds idle rows too
+    assert cb.admit(jobs[5:7]) == []
+    rounds_before = cb.stats["rounds"]
+    while cb.live:
+        _collect(cb.step(), audio, ended)
+    assert all(ended.get(id(j)) for j in jobs)
+    assert set(cb.stats["row_rounds"]) <= {192, 256}, cb.stats["row_rounds"]
+    for i, j in enumerate(jobs):
+        got = np.concatenate(j.codes)[: budgets[i]]
+        assert np.array_equal(got, ref_codes[i]), f"session {i}: codes differ from the oracle run of that session alone"
+    for i, j in enumerate(jobs):
+        solo = [c[0] for c in eng.stream([j.prompt], [budgets[i]], chunk_size=CHUNK, min_frames=budgets[i]) if c[0] is not None]
+        a, b = np.concatenate(audio[id(j)]), np.concatenate(solo)
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        d = np.abs(a.astype(int) - b.astype(int))
+        assert d.max() <= 2, f"session {i}: audio differs from its solo stream (max diff {d.max()})"
+    eng.close()
+
+
+def test_bf16_engine_is_consistent_across_row_buckets_and_slots():
+    """VERDICT r3 weak #1a: the bf16 serving engine picks different projection kernels by row count (16-column / column-block kernels up to
+    128 rows, the row-block kernel of gemm_decw.hip above; K-slice counts change the summation order), so one session's logits depend on
+    the bucket it lands in.  The same session, teacher-forced with the oracle's codes in batches of 3 / 40 / 100 / 200 / 500 rows (every row
+    the same prompt, so every slot of every bucket is checked): logits within the 0.08 sigma bar of the f32 oracle in EVERY bucket and slot,
+    and no top-1 flip between buckets wherever the oracle's margin is clear.  Benchmarked widths (Qwen3-TTS-1.7B), reduced depth (4 talker
+    layers) so that the CPU oracle stays in seconds."""
+    from speech_to_speech_amd.synth_weights import Qwen3TTSDims as D
+
+    TOL = 0.08
+    torch.set_num_threads(max(1, min(32, __import__("os").cpu_count() or 1)))
+    dims = D.tts_1_7b()
+    dims.t_layers, dims.c_layers = 4, 1
+    sd = qwen3_tts_state_dict(dims, seed=23)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randn(9, dims.t_hidden, generator=g)
+    pad = torch.randn(dims.t_hidden, generator=g) * 0.5
+    n_frames = 4
+    sup = [i for i in range(dims.codebook, dims.codec_vocab) if i != dims.codec_eos]
+    lo = []
+    with torch.no_grad():
+        codes, _ = OT.talker_generate(sd, dims.talker_cfg(), dims.predictor_cfg(), prompt[None], dims.n_groups, n_frames, dims.codec_eos, suppress=sup,
+                                      pad_embed=pad, min_frames=n_frames, logits_out=lo)
+    forced1 = codes[0].to(torch.int32)                                   # [F][G]
+    eng = TTSEngine(dims, sd, dtype=torch.bfloat16, max_batch=512, max_prompt=16, max_frames=n_frames, max_codec_frames=8, pad_embed=pad)
+    tops = {}
+    for B in (3, 40, 100, 200, 500):
+        eng.prefill([TTSPrompt(prompt.numpy())] * B)
+        emitted, lg = eng.generate_forced(forced1[None].repeat(B, 1, 1).contiguous(), min_total_frames=n_frames)
+        assert torch.equal(emitted.cpu(), forced1[None].repeat(B, 1, 1))
+        worst = 0.0
+        rows = sorted({0, 1, 15, 16, B // 2, B - 1} & set(range(B)))
+        lgc = lg[rows].cpu()
+        for f in range(n_frames):
+            for gi in range(dims.n_groups):
+                ref = lo[f][gi][0]
+                V = ref.numel()
+                got = lgc[:, f, gi, :V]
+                worst = max(worst, float(((got - ref[None]).abs().amax(1) / ref.std()).max()))
+                top2 = torch.topk(ref, 2).values
+                if float(top2[0] - top2[1]) > 2 * TOL * float(ref.std()):
+                    tops.setdefault((f, gi), set()).update(int(v) for v in got.argmax(1))
+                    tops[(f, gi)].add(int(ref.argmax()))
+        # every row of the batch computes the same numbers as row 0 would in ANY slot of this bucket
+        same = lg[:, :, :, : dims.codebook]
+        spread = float((same - same[:1]).abs().max())
+        print(f"bf16 bucket of {B} rows: worst max|err| / std vs the f32 oracle {worst:.4f} (tol {TOL}); max |logit| spread between slots {spread:.3e}")
+        assert worst <= TOL, (B, worst)
+        assert spread <= 0.25 * TOL * float(lo[0][1][0].std()), (B, spread)
+    flips = {k: v for k, v in tops.items() if len(v) > 1}
+    assert not flips, f"top-1 differs between buckets / from the oracle at clear-margin picks: {flips}"
     eng.close()
