@@ -564,8 +564,10 @@ extern "C" int32_t s2s_op_gemm_dec_ln(void* stream, const void* A, int64_t lda, 
                                       int32_t K, const float* ss_in, int32_t n_parts_in, int32_t ss_stride, float inv_dim, float eps, int32_t mode,
                                       void* C, int64_t ldc, int32_t act, int32_t layout, const float* csum_dev) {
     S2S_REQUIRE(csum_dev && ss_in && mode != 2, "op_gemm_dec_ln: needs csum, pair partials and an output mode 0 / 1");
+    // (up to 128 rows the call is pinned to the 16-column kernel's one-fragment variant; wider calls take the library's own choice - the
+    // row-block kernel of gemm_decw.hip when the rows are fragment-major)
     return op_gemm_dec_impl(stream, A, lda, W, ldw, bias, M, N, K, ss_in, n_parts_in, ss_stride, inv_dim, eps, mode, C, ldc, act, nullptr, 0, nullptr, 0, nullptr, 0,
-                            1, layout, csum_dev);
+                            M > 128 ? 0 : 1, layout, csum_dev);
 }
 
 /* number of partial sums of squares per row s2s_op_gemm_dec (mode 2) writes for this shape (nf 0 -> the library's choice); layout as
