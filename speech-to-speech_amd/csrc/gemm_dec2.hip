@@ -566,6 +566,7 @@ void* dec2_default_ws(size_t* bytes) {
     return default_ws().p;
 }
 
+void decw_set_debug(unsigned long long* dbg);      // gemm_decw.hip
 void dec2_set_debug(unsigned long long* dbg) { tune().dbg = dbg; }
 
 void dec2_set_tune(int enable, int splitk, int nt) {
@@ -686,6 +687,7 @@ int gemm_dec2(hipStream_t st, const DecGemm& a) {
  * dbg (device memory, >= 8 * workgroups u64), null switches it off. */
 extern "C" int32_t s2s_op_gemm_dec_debug(void* dbg) {
     s2s::dec2_set_debug(reinterpret_cast<unsigned long long*>(dbg));
+    s2s::decw_set_debug(reinterpret_cast<unsigned long long*>(dbg));
     return S2S_OK;
 }
 

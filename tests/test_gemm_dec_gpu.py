@@ -601,8 +601,10 @@ def test_gemm_decw_modes_match_float64(M, N, K, decw_default):
     ref = (_f64(A) @ _f64(W).T) * rstd[:, None] + _f64(bias)
     Mp = (M + 15) // 16 * 16
     steps = K // 32
-    for sk in [0] + [s for s in (1, 2, 3, 4) if steps % s == 0 and steps // s >= 8]:
-        _wtune(1, sk)
+    configs = [(1, sk) for sk in [0] + [s for s in (1, 2, 3, 4) if steps % s == 0 and steps // s >= 8]] + [(shape, sk) for shape in (44, 42, 24, 22) for sk in (1, 2)]
+    for shape, sk in configs:
+        _wtune(shape, sk)
+        sk = (shape, sk)
         for act in (native.ACT_NONE, native.ACT_GELU):
             out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
             gemm_dec(Af, Wf, M, N, K, bias=bias, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=inv_dim, eps=eps, mode=0, C_out=out, act=act, a_frag=True, w_is_frag=True)
@@ -617,7 +619,7 @@ def test_gemm_decw_modes_match_float64(M, N, K, decw_default):
         X0 = torch.randn(M, N, generator=g)
         xb_frag = N % 32 == 0
         n_out = lib.s2s_op_gemm_dec_parts(M, N, K, 0, 1)
-        assert n_out == (N + 127) // 128
+        assert n_out in ((N + 127) // 128, (N + 63) // 64)          # one partial per column block of the chosen tile shape
         runs = []
         for _ in range(2):
             X = X0.clone().to(DEV)
@@ -659,8 +661,9 @@ def test_gemm_decw_swiglu_matches_float64(M, N, K, decw_default):
     want = torch.nn.functional.silu(gate) * up
     Mp = (M + 15) // 16 * 16
     steps = K // 32
-    for sk in [0] + [s for s in (1, 2, 4) if steps % s == 0 and steps // s >= 8]:
-        _wtune(1, sk)
+    for shape, sk in [(1, sk) for sk in [0] + [s for s in (1, 2, 4) if steps % s == 0 and steps // s >= 8]] + [(44, 1), (24, 1), (24, 2)]:
+        _wtune(shape, sk)
+        sk = (shape, sk)
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
         gemm_dec(Af, Wf, M, N, K, ss_in=ss, n_parts=parts, ss_stride=S, inv_dim=1.0 / K, eps=1e-6, mode=0, C_out=out, glu=True, a_frag=True, w_is_frag=True)
         assert (_f64(out) - want).abs().max().item() <= 6e-3 * want.abs().max().item(), sk
@@ -718,7 +721,7 @@ def test_norm_free_layer_chain_on_the_row_block_kernel(M, hid, ffn, heads_dim, d
         print(f"layer chain M={M} hid={hid} row-block kernel={'on' if wide else 'off (128-row slabs)'}: max|err| {err:.3e} (|x| max {scale:.2f}), out-proj partials {parts_o}")
         assert err <= 2e-2 * scale
         if wide:
-            assert parts_o == hid // 128
+            assert parts_o in (hid // 128, hid // 64)
         results.append(X.clone())
     if len(results) == 2:
         assert (results[0] - results[1]).abs().max().item() <= 2e-2 * x_ref.abs().max().item()
@@ -762,7 +765,7 @@ def test_gemm_decw_ticket_handoff_stress(decw_default):
     first = {}
     for it in range(60):
         for ci, (M, N, K, sk, Af, Wf, ref) in enumerate(cases):
-            _wtune(1, sk)
+            _wtune((44, 42, 22)[ci], sk)
             out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
             gemm_dec(Af, Wf, M, N, K, mode=1, C_out=out, a_frag=True, w_is_frag=True)
             if ci not in first:

@@ -137,7 +137,7 @@ def test_wide_loop_high_slots_and_merged_codec_pass_match_the_oracle(world):
     while cb.live:
         _collect(cb.step(), audio, ended)
     assert all(ended.get(id(j)) for j in jobs)
-    assert set(cb.stats["row_rounds"]) <= {192, 256}, cb.stats["row_rounds"]
+    assert 192 in cb.stats["row_rounds"] and set(cb.stats["row_rounds"]) <= {128, 192, 256}, cb.stats["row_rounds"]
     for i, j in enumerate(jobs):
         got = np.concatenate(j.codes)[: budgets[i]]
         assert np.array_equal(got, ref_codes[i]), f"session {i}: codes differ from the oracle run of that session alone"
