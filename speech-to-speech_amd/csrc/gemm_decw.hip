@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_decw_kernel(DecGemm a, DecwPlan p
 struct WideTune {
     int enable = 1;       // 0: never (row slabs of the 16-column / column-block kernels); 44 / 42 / 24 / 22: that tile shape (10 TMW + TNW)
     int splitk = 0;       // 0: chosen from the shape
-    int min_m = 129;      // smallest M this kernel takes
+    int min_m = 65;       // smallest M this kernel takes (the 128-row bucket of the frame loops: 76 vs 94 us per talker layer, r04 microbench)
     unsigned long long* dbg = nullptr;
 };
 WideTune& wtune() {
@@ -500,8 +500,11 @@ constexpr size_t DW_CNT_BYTES = 16384;       // 4096 tickets (shared with gemm_d
 
 struct WideChoice { int tmw, tnw, ncb, nrb, splitk, nsteps; };
 
-// The plan for a shape.  Cost model (bytes the busiest CU pulls through its global -> LDS path, the measured bound of the main loop):
-//   k-steps per slice x stage bytes x ceil(workgroups / 256)   +   (K-slices: publish / ticket / slab reads of the last arriver).
+// The plan for a shape, from the sweep of profiles/r04_microbench_decode_gemm.txt (every tile shape x K-slice count at 128 / 256 / 512
+// rows).  What the sweep says: a workgroup's ring holds two to three k-steps in flight, so ONE workgroup pulls about 52 GB/s whatever
+// its tile; a CU reaches 120 GB/s once four workgroups share it.  Linear projections therefore take the 64 x 64 tile (33 KiB of LDS,
+// < 80 VGPRs: four workgroups per CU) with as many K-slices (<= 4) as bring the launch to about two workgroups per CU; SwiGLU
+// projections (twice the weight blocks per output tile) keep the 128 x 128 tile while it yields >= 192 workgroups, else 64 x 128.
 WideChoice decw_choose(const DecGemm& a) {
     WideChoice c{};
     const WideTune& t = wtune();
@@ -510,41 +513,33 @@ WideChoice decw_choose(const DecGemm& a) {
     if (a.glu && a.N % 16 != 0) return c;
     if (a.ss_in && a.n_parts_in > 256) return c;
     const int ntiles = (a.N + 15) / 16, steps = a.K / 32;
-    static const int shapes_glu[][2] = {{4, 4}, {2, 4}};
-    static const int shapes_lin[][2] = {{4, 4}, {4, 2}, {2, 4}, {2, 2}};
-    const int (*shapes)[2] = a.glu ? shapes_glu : shapes_lin;
-    const int n_shapes = a.glu ? 2 : 4;
-    bool forced = false;      // a forced tile shape this kind of projection has (else: the library's choice)
-    for (int si = 0; si < n_shapes; ++si) forced = forced || t.enable == shapes[si][0] * 10 + shapes[si][1];
-    double best = 1e300;
-    for (int si = 0; si < n_shapes; ++si) {
-        const int tmw = shapes[si][0], tnw = shapes[si][1];
-        if (forced && t.enable != tmw * 10 + tnw) continue;
+    auto plan = [&](int tmw, int tnw, int sk) {
         const int out_tiles = a.glu ? tnw : 2 * tnw;             // output column tiles per block
-        const int ncb = (ntiles + out_tiles - 1) / out_tiles, nrb = (a.M + 32 * tmw - 1) / (32 * tmw);
-        const long tiles = (long)ncb * nrb;
-        const double stage = (2 * tmw + 2 * tnw) * 1024.0, slab = 4.0 * tmw * tnw * 1024.0;
-        for (int sk = 1; sk <= 4; ++sk) {
-            if (t.splitk > 0 && sk != t.splitk) continue;
-            if (steps % sk != 0 || (sk > 1 && steps / sk < 4)) continue;
-            if (sk > 1 && tiles * sk > 1024) continue;
-            const double rounds = (double)((tiles * sk + 255) / 256);
-            double cost = (double)(steps / sk) * stage * rounds;
-            if (sk > 1) cost += 130e3 + 0.5 * sk * slab;
-            cost *= 1.0 + 0.02 * si;                              // ties: the larger tile
-            if (cost < best) {
-                best = cost;
-                c = WideChoice{tmw, tnw, ncb, nrb, sk, steps / sk};
-            }
+        return WideChoice{tmw, tnw, (ntiles + out_tiles - 1) / out_tiles, (a.M + 32 * tmw - 1) / (32 * tmw), sk, steps / sk};
+    };
+    int tmw = 2, tnw = 2;
+    if (a.glu) {
+        tnw = 4;
+        tmw = (long)plan(4, 4, 1).ncb * plan(4, 4, 1).nrb >= 192 ? 4 : 2;
+    }
+    if (t.enable >= 10) {         // a forced tile shape (sweeps), when this kind of projection has it
+        const int ftm = t.enable / 10, ftn = t.enable % 10;
+        if ((ftm == 4 || ftm == 2) && (ftn == 4 || ftn == 2) && (!a.glu || ftn % 2 == 0)) {
+            tmw = ftm;
+            tnw = ftn;
         }
     }
-    if (best == 1e300 && t.splitk > 1) {      // a forced K-slice count that does not divide K: one slice
-        WideTune& tt = wtune();
-        const int keep = tt.splitk;
-        tt.splitk = 1;
-        c = decw_choose(a);
-        tt.splitk = keep;
+    int sk = 1;
+    if (t.splitk > 0) sk = t.splitk;
+    else if (!a.glu) {
+        const long tiles = (long)plan(tmw, tnw, 1).ncb * plan(tmw, tnw, 1).nrb;
+        sk = (int)(512 / (tiles > 0 ? tiles : 1));
+        if (sk > 4) sk = 4;
+        if (sk < 1) sk = 1;
     }
+    while (sk > 1 && (steps % sk != 0 || steps / sk < 4)) --sk;
+    c = plan(tmw, tnw, sk);
+    if ((long)c.ncb * c.nrb > (long)(DW_CNT_BYTES / 4)) c.splitk = 1, c.nsteps = steps;
     return c;
 }
 
@@ -594,7 +589,9 @@ int gemm_decw(hipStream_t st, const DecGemm& a) {
     const int shape = c.tmw * 10 + c.tnw;
     if (a.glu) {
         if (shape == 44) decw_launch<true, 4, 4>(st, a, p);
-        else decw_launch<true, 2, 4>(st, a, p);
+        else if (shape == 24) decw_launch<true, 2, 4>(st, a, p);
+        else if (shape == 42) decw_launch<true, 4, 2>(st, a, p);
+        else decw_launch<true, 2, 2>(st, a, p);
     } else {
         if (shape == 44) decw_launch<false, 4, 4>(st, a, p);
         else if (shape == 42) decw_launch<false, 4, 2>(st, a, p);

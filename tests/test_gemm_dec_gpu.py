@@ -314,7 +314,7 @@ def _tune(enable=1, splitk=0, nt=0):
     native.check(native.load().s2s_op_gemm_dec_tune(enable, splitk, nt), "tune")
 
 
-def _wtune(enable=1, splitk=0, min_m=129):
+def _wtune(enable=1, splitk=0, min_m=65):
     native.check(native.load().s2s_op_gemm_decw_tune(enable, splitk, min_m), "wide tune")
 
 
@@ -661,7 +661,7 @@ def test_gemm_decw_swiglu_matches_float64(M, N, K, decw_default):
     want = torch.nn.functional.silu(gate) * up
     Mp = (M + 15) // 16 * 16
     steps = K // 32
-    for shape, sk in [(1, sk) for sk in [0] + [s for s in (1, 2, 4) if steps % s == 0 and steps // s >= 8]] + [(44, 1), (24, 1), (24, 2)]:
+    for shape, sk in [(1, sk) for sk in [0] + [s for s in (1, 2, 4) if steps % s == 0 and steps // s >= 8]] + [(44, 1), (24, 1), (24, 2), (42, 1), (22, 2)]:
         _wtune(shape, sk)
         sk = (shape, sk)
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
