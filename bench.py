@@ -105,6 +105,7 @@ def parse(argv=None):
     ap.add_argument("--confirm-probes", type=int, default=1, help="repeats (other arrival phases) of the probe at the sustained session count; a failed repeat steps the figure down")
     ap.add_argument("--tts-admit-wait-s", type=float, default=0.15, help="pacing of the pool's continuous TTS lane: a queued request joins the frame loop once it has waited this long "
                     "(at once when the lane is idle or a round is due): rounds are fuller, TTFA grows by at most this")
+    ap.add_argument("--probe-only", action="store_true", help="A/B runs: skip the single-session and warm-up probes (use with --probe-sessions and a short timed region)")
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
     ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
     ap.add_argument("--tts-lead-s", type=float, default=2.0, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
@@ -112,6 +113,7 @@ def parse(argv=None):
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
     ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
                     "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
+    ap.add_argument("--stt-stages", type=int, default=2, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
     ap.add_argument("--max-probes", type=int, default=5, help="open-loop probes of the sustained-sessions bisection")
@@ -343,7 +345,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0):
+                   admit_wait_s=0.0, stt_stages=2):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -365,11 +367,12 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
 
     B = int(getattr(stt_engine, "max_batch", tts_engine.max_batch))      # STT batches; the TTS lane's rows are the TTS engine's slots
     pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus, stt_max_batch=stt_max_batch,
-                       tts_admit_wait_s=admit_wait_s)
+                       tts_admit_wait_s=admit_wait_s, stt_stages=stt_stages)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
     pool.warm_tts_lanes()
+    pool.warm_stt(stt_model)
     turn_period = utt_s + n_frames * FRAME_S
     workers = int(min(1024, max(8, n_sessions * (n_frames * FRAME_S + 3.0) / turn_period + 8)))      # turns in flight at once (a paced reply streams for up to its own duration)
 
@@ -765,9 +768,9 @@ def main():
             def probe(n, window=args.boundary_seconds, seed=0):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch,
-                                      admit_wait_s=args.tts_admit_wait_s, seed=seed)
+                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages)
 
-            single = probe(1, window=12.0)
+            single = None if args.probe_only else probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
                 probe(max(8, int(0.3 * xrt / world)), window=5.0)      # untimed warm-up at a moderate load: allocator pools and batch shapes of a loaded pool
             best, tried = (None, [])

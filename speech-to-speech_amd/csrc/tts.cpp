@@ -118,6 +118,7 @@ struct Tts {
     PickDebug dbg{};                   // teacher forcing / logit capture (s2s_tts_generate_forced); null on the serving path
     int* forced_buf = nullptr;         // [max_batch][max_frames][G], allocated on first forced call
     int xb_width = 0;                  // columns of xb
+    size_t act_elems = 0;              // elements per session of each codec activation buffer (ca / cb_ / cc)
     int ss_parts_A = 0;                // parts currently valid in ssA (written by the last residual projection / rows_prep)
     std::vector<void*> owned;          // device buffers created at finalize (folded weights)
 };
@@ -162,6 +163,15 @@ struct Plan {
     size_t off = 0;
     size_t take(size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; }
 };
+
+// rows of a stage for a streamed CONTINUATION chunk of F frames: every frame contributes its full upsampling product (the first chunk
+// of a stream is shorter: each causal transposed conv trims its first output group) - this is what the activation buffers must hold
+static long codec_len_cont(const s2s_tts_config& c, long F, int stage) {
+    long T = F;
+    for (int i = 0; i < 2; ++i) T *= c.up_ratio[i];
+    for (int i = 0; i < stage; ++i) T *= c.up_rate[i];
+    return T;
+}
 
 static long codec_len(const s2s_tts_config& c, long F, int stage) {
     // stage 0: after the two x2 upsamplers; stage i (1..4): after decoder block i
@@ -257,11 +267,13 @@ static int finalize(Tts* m) {
     // codec conv stack: the widest stage decides (rows * channels)
     size_t act_elems = 0;
     {
-        size_t r0 = codec_len(c, F, 0);
+        // (sized for a continuation chunk of max_codec_frames frames - longer than a first chunk of the same frames, codec_len_cont)
+        size_t r0 = codec_len_cont(c, F, 0);
         act_elems = std::max<size_t>(act_elems, (LPAD + r0) * (size_t)std::max<long>(4 * H, Dd));
-        for (int i = 1; i <= c.n_dec_blocks; ++i) act_elems = std::max<size_t>(act_elems, (LPAD + codec_len(c, F, i)) * (size_t)(Dd >> i));
-        act_elems = std::max<size_t>(act_elems, (LPAD + codec_len(c, F, c.n_dec_blocks)) * 8);   // final 1-channel conv output
+        for (int i = 1; i <= c.n_dec_blocks; ++i) act_elems = std::max<size_t>(act_elems, (LPAD + codec_len_cont(c, F, i)) * (size_t)(Dd >> i));
+        act_elems = std::max<size_t>(act_elems, (LPAD + codec_len_cont(c, F, c.n_dec_blocks)) * 8);   // final 1-channel conv output
     }
+    m->act_elems = act_elems;
     T(B * F * 4 * H * 4);                      // 22 cx (f32 residual for the pre-transformer / unused later)
     T(B * act_elems * e);                      // 23 ca
     T(B * act_elems * e);                      // 24 cb
@@ -968,6 +980,15 @@ static int codec_run(Tts* m, hipStream_t st, const int* codes_dev, int B, int F,
         fprintf(stderr, "[codec] %s %d.%d: %s\n", what, i, j, hipGetErrorString(er));
         fflush(stderr);
     };
+    {   // the widest stage of THIS call's geometry must fit the activation buffers (a continuation chunk is longer than a first chunk)
+        size_t need_e = 0;
+        for (int i = 0; i <= c.n_dec_blocks; ++i) {
+            const long Ti = first ? codec_len(c, F, i) : codec_len_cont(c, F, i);
+            need_e = std::max<size_t>(need_e, (size_t)(LPAD + Ti) * (size_t)(i == 0 ? std::max<long>(4 * H, c.c_decoder_dim) : (c.c_decoder_dim >> i)));
+        }
+        if (need_e > m->act_elems) return done(fail(S2S_ERR_ARG, "codec: %d frames need %zu activation elements per session, the engine holds %zu (max_codec_frames %d)", F, need_e,
+                                                   m->act_elems, c.max_codec_frames));
+    }
     // code embeddings -> sliding-window transformer (KV cache continues across streamed chunks)
     if ((rc = code_embed_mean(st, TP(m, "codec.emb"), codes_dev, m->cx, (long)B * F, G, c.codebook, H, dt))) return done(rc);
     const int f0 = streaming ? frames_done : 0;

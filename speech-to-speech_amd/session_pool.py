@@ -80,7 +80,7 @@ class SessionPool:
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
                  tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
-                 tts_admit_wait_s: float = 0.0):
+                 tts_admit_wait_s: float = 0.0, stt_stages: int = 2):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -91,6 +91,16 @@ class SessionPool:
         # ... and a queued request joins the loop once it has waited this long (at once when the lane is idle or a round is due anyway):
         # bounds what pacing adds to a session's time-to-first-audio
         self.tts_admit_wait_s = float(tts_admit_wait_s)
+        # STT as a two-stage pipeline (engines with stt_begin / stt_finish / replica, i.e. Whisper): the worker thread runs log-mel + encoder
+        # of batch k + 1 on its stream while a second thread runs the token loop of batch k on another stream, each batch on its own engine
+        # replica (weights shared).  The encoder fills the chip for 5 ms per session, the token loop is a chain of 35 x 256 latency-bound
+        # launches (72 ms whatever the batch): back to back on one stream they made a batch of 14 take 160 ms (260 ms under the TTS lane).
+        # 1 = one stage (round 3).
+        self.stt_stages = max(1, int(stt_stages))
+        self._stt_reps: dict[str, list] = {}          # model -> engines of the pipeline (the pool's engine + replicas)
+        self._stt_free: dict[str, "queue.Queue[int]"] = {}
+        self._stt_dq: "queue.Queue[Any]" = queue.Queue()
+        self._stt_dthread: threading.Thread | None = None
         # lane admission policy: 0 = the least loaded lanes take new sessions (spreads them over all lanes); T > 0 = fill first: lane k only
         # takes new sessions once every lane below it holds at least T live sessions (fewer frame loops running, fuller rows)
         self.tts_fill_first = int(tts_fill_first)
@@ -169,6 +179,15 @@ class SessionPool:
         for ev in list(self._lane_ready):
             ev.wait(timeout)
 
+    def warm_stt(self, model: str, timeout: float = 300.0) -> None:
+        """Build the replicas of the two-stage STT pipeline now (on the worker thread), not on the first request."""
+        if self.stt_stages <= 1:
+            return
+        fut: Future = Future()
+        self._stt_q.put(("call", lambda: self._stt_pipeline_build(model), fut))
+        self._wake.set()
+        fut.result(timeout)
+
     # ---- client API (handler threads) -----------------------------------------------------------
     def transcribe(self, model: str, audio: np.ndarray, **options) -> dict:
         if self._stopping:
@@ -220,6 +239,8 @@ class SessionPool:
                     it.chunks.put(err)
                 elif isinstance(it, tuple) and it[0] == "build" and not it[3].done():
                     it[3].set_exception(err)
+                elif isinstance(it, tuple) and it[0] == "call" and not it[2].done():
+                    it[2].set_exception(err)
 
     def shutdown(self, close_engines: bool = True) -> None:
         """close_engines=False leaves the engines registered with the pool open (they belong to the caller); lane replicas the pool
@@ -231,8 +252,16 @@ class SessionPool:
             self._tts_q.put(_STOP)
         self._wake.set()
         self._thread.join(timeout=10)
-        for t in self._stt_extra + self._lanes:
+        for t in self._stt_extra + self._lanes + ([self._stt_dthread] if self._stt_dthread is not None else []):
             t.join(timeout=10)
+        while True:
+            try:
+                item = self._stt_dq.get_nowait()
+            except queue.Empty:
+                break
+            for r in item[2]:
+                if not r.future.done():
+                    r.future.set_exception(RuntimeError("SessionPool is shut down"))
         self._fail_pending()
         for e in (list(self._engines.values()) if close_engines else []) + self._lane_replicas:
             try:
@@ -263,7 +292,7 @@ class SessionPool:
                 if self._stopping:
                     return
                 continue
-            if self.batch_window_s > 0 and not (isinstance(first, tuple) or first is _STOP):
+            if self.batch_window_s > 0 and isinstance(first, _STTRequest):
                 time.sleep(self.batch_window_s)      # let concurrent sessions' finals join the batch
             cap = self.max_batch
             if isinstance(first, _STTRequest):
@@ -275,10 +304,19 @@ class SessionPool:
             for it in items:
                 if it is _STOP:
                     self._stopping = True
+                elif isinstance(it, tuple) and it[0] == "call":      # host-side set-up that must run on this thread (warm_stt)
+                    _, fn, fut = it
+                    try:
+                        fn()
+                        self._sync_current_stream()
+                        fut.set_result(True)
+                    except BaseException as e:  # noqa: BLE001
+                        fut.set_exception(e)
                 elif isinstance(it, tuple) and it[0] == "build":
                     _, name, factory, fut = it
                     try:
                         self._engines[name] = factory()
+                        self._stt_pipeline_build(name)   # (replicas are built HERE, with the engine - never while serving)
                         self._sync_current_stream()      # uploads / conversions of the build are complete before any lane uses the weights
                         fut.set_result(True)
                     except BaseException as e:  # noqa: BLE001
@@ -286,9 +324,114 @@ class SessionPool:
                 else:
                     reqs.append(it)
             for model in sorted({r.model for r in reqs}):
-                self._run_stt([r for r in reqs if r.model == model], model)
+                mine = [r for r in reqs if r.model == model]
+                if self.stt_stages > 1 and model not in self._stt_reps:
+                    self._stt_pipeline_build(model)      # (an engine registered directly, e.g. by bench.py: first use)
+                if self._stt_reps.get(model):
+                    self._run_stt_staged(mine, model)
+                else:
+                    self._run_stt(mine, model)
             if self._stopping and self._stt_q.empty():
                 return
+
+    # ---- two-stage STT ---------------------------------------------------------------------------
+    def _stt_pipeline_build(self, model: str) -> None:
+        eng = self._engines.get(model)
+        if self.stt_stages <= 1 or model in self._stt_reps or eng is None:
+            return
+        if not all(hasattr(eng, a) for a in ("stt_begin", "stt_finish", "replica")):
+            self._stt_reps[model] = []
+            return
+        cap = min(self.max_batch, int(getattr(eng, "max_batch", self.max_batch)))
+        if self.stt_max_batch > 0:
+            cap = min(cap, self.stt_max_batch)
+        reps = [eng]
+        try:
+            for _ in range(self.stt_stages - 1):
+                try:
+                    rep = eng.replica(max_batch=cap)
+                except TypeError:
+                    rep = eng.replica()
+                reps.append(rep)
+                self._lane_replicas.append(rep)
+        except BaseException as e:  # noqa: BLE001
+            logger.error("STT pipeline: could not build the %s replicas (%s); one stage", model, e, exc_info=True)
+            self._stt_reps[model] = []
+            return
+        self._stt_reps[model] = reps
+        self._stt_free[model] = queue.Queue()
+        for i in range(len(reps)):
+            self._stt_free[model].put(i)
+        if self._stt_dthread is None:
+            self._stt_dthread = threading.Thread(target=self._run_stt_decode, name=f"s2s-pool-{self.device}-sttdec", daemon=True)
+            self._stt_dthread.start()
+
+    def _run_stt_staged(self, reqs: list[_STTRequest], model: str) -> None:
+        """Stage 1 (this thread, its stream): features + encoder of the batch on a free replica, then hand it to the decode thread."""
+        if not reqs:
+            return
+        with self._stats_lock:
+            self.stats["stt_batches"] += 1
+            self.stats["stt_requests"] += len(reqs)
+            self.stats["max_stt_batch"] = max(self.stats["max_stt_batch"], len(reqs))
+        idx = None
+        try:
+            while idx is None:
+                try:
+                    idx = self._stt_free[model].get(timeout=0.05)
+                except queue.Empty:
+                    if self._stopping:
+                        raise RuntimeError("SessionPool is shut down")
+            t_b = time.perf_counter()
+            eng = self._stt_reps[model][idx]
+            state = eng.stt_begin([r.audio for r in reqs], [r.options for r in reqs])
+            ev = None
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    ev = torch.cuda.Event()
+                    ev.record()
+            except Exception:  # noqa: BLE001
+                ev = None
+            self._stt_dq.put((model, idx, reqs, state, ev, t_b))
+        except BaseException as e:  # noqa: BLE001
+            logger.error("%s encoder stage failed: %s", model, e, exc_info=True)
+            if idx is not None:
+                self._stt_free[model].put(idx)
+            for r in reqs:
+                if not r.future.done():
+                    r.future.set_exception(e)
+
+    def _run_stt_decode(self) -> None:
+        """Stage 2 (own thread + stream): the token loop of every encoded batch, in order."""
+        ctx = self._lane_stream_ctx(self.stt_priority)
+        ctx.__enter__()
+        while True:
+            try:
+                item = self._stt_dq.get(timeout=0.05)
+            except queue.Empty:
+                if self._stopping:
+                    return
+                continue
+            model, idx, reqs, state, ev, t_b = item
+            try:
+                if ev is not None:
+                    import torch
+
+                    torch.cuda.current_stream().wait_event(ev)
+                results = self._stt_reps[model][idx].stt_finish(state)
+                with self._stats_lock:
+                    self.stats["stt_busy_s"] += time.perf_counter() - t_b
+                for r, res in zip(reqs, results):
+                    r.future.set_result(res)
+            except BaseException as e:  # noqa: BLE001
+                logger.error("%s decode stage failed: %s", model, e, exc_info=True)
+                for r in reqs:
+                    if not r.future.done():
+                        r.future.set_exception(e)
+            finally:
+                self._stt_free[model].put(idx)
 
     def _run_stt_extra(self, k: int) -> None:
         """STT worker k > 0: same batching as the first worker, on replicas that share the engines' weights.  Engine builds, and requests for

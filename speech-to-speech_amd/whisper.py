@@ -254,14 +254,20 @@ class WhisperEngine:
             return ids, filled, logits
         return ids, filled
 
-    def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
-        """SessionPool entry point: one dict per request {"ids": [...], "language": code | None}.
-        options per request: language (code | "auto" | None), max_new_tokens, vocab (text.WhisperVocab)."""
+    def stt_begin(self, audios: Sequence[np.ndarray], options: Sequence[dict]):
+        """First stage of a batch (asynchronous on the current stream): log-mel + encoder + cross K/V of every session.  The session pool
+        runs it on one stream while `stt_finish` of the PREVIOUS batch - the latency-bound token loop - runs on another (two engine
+        replicas; SessionPool stt_stages)."""
         vocab = options[0]["vocab"]
         max_new = max(int(o.get("max_new_tokens", 128)) for o in options)
         vocab.validate(self.dims.vocab)
         prompts = [vocab.prompt(o.get("language"), o.get("task", "transcribe")) for o in options]
         self.encode(self.features(audios))
+        return vocab, prompts, max_new, list(options)
+
+    def stt_finish(self, state) -> list[dict]:
+        """Second stage: greedy decode of the batch `stt_begin` encoded on THIS engine; one dict per request."""
+        vocab, prompts, max_new, options = state
         ids, filled = self.decode(prompts, vocab.eot, max_new, suppress=vocab.suppress, begin_suppress=vocab.begin_suppress,
                                   lang_ids=list(vocab.lang_to_id.values()) or None)
         out = []
@@ -269,6 +275,11 @@ class WhisperEngine:
             n = int(o.get("max_new_tokens", 128))
             out.append({"ids": ids[i][:n], "language": vocab.id_to_lang(filled[i][1]) if vocab.multilingual else "en"})
         return out
+
+    def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
+        """SessionPool entry point: one dict per request {"ids": [...], "language": code | None}.
+        options per request: language (code | "auto" | None), max_new_tokens, vocab (text.WhisperVocab)."""
+        return self.stt_finish(self.stt_begin(audios, options))
 
     def transcribe_ids(self, audios: Sequence[np.ndarray], prompt: Sequence[int], eos: int, max_new_tokens: int = 128, **kw):
         self.encode(self.features(audios))

@@ -481,3 +481,69 @@ def test_session_pool_runs_continuous_lanes_on_an_engine_with_slots(monkeypatch)
         assert sum(k[2] for k in eng.log if k[0] == "release" and k[2] < 8) == 3          # every admitted slot was given back
     finally:
         pool.shutdown(close_engines=False)
+
+
+def test_session_pool_two_stage_stt_overlaps_encoder_and_token_loop():
+    """SessionPool(stt_stages=2) on a stub engine with stt_begin / stt_finish / replica: every request gets ITS result, a batch's two
+    stages run on the SAME replica, and the encoder stage of a later batch runs while an earlier batch is still in its token loop."""
+    import threading
+    import time
+
+    import numpy as np
+
+    from speech_to_speech_amd.session_pool import SessionPool
+
+    log, lock = [], threading.Lock()
+
+    class Eng:
+        max_batch = 4
+        n = 0
+
+        def __init__(self, name="e0"):
+            self.name = name
+
+        def replica(self, max_batch=None):
+            Eng.n += 1
+            return Eng(f"e{Eng.n}")
+
+        def stt_begin(self, audios, options):
+            with lock:
+                log.append(("begin", self.name, time.perf_counter(), len(audios)))
+            time.sleep(0.02)
+            return [float(a[0]) for a in audios]
+
+        def stt_finish(self, state):
+            t0 = time.perf_counter()
+            time.sleep(0.08)
+            with lock:
+                log.append(("finish", self.name, t0, time.perf_counter()))
+            return [{"ids": [int(v)], "language": "en"} for v in state]
+
+        def close(self):
+            pass
+
+    pool = SessionPool("cpu-test-stt-stages", max_batch=4, batch_window_ms=1.0, tts_lanes=1, stt_stages=2)
+    pool._engines["whisper"] = Eng()
+    try:
+        out = {}
+
+        def ask(i):
+            out[i] = pool.transcribe("whisper", np.full(8, float(i), np.float32))
+
+        ths = []
+        for i in range(12):
+            t = threading.Thread(target=ask, args=(i,))
+            t.start()
+            ths.append(t)
+            time.sleep(0.012)
+        [t.join(timeout=20) for t in ths]
+        assert all(out[i]["ids"] == [i] for i in range(12)), out
+        begins = [k for k in log if k[0] == "begin"]
+        finishes = [k for k in log if k[0] == "finish"]
+        assert len(begins) == len(finishes) >= 2 and {k[1] for k in begins} <= {"e0", "e1"}
+        assert [k[1] for k in begins] == [k[1] for k in finishes]          # batches finish in order, each on the replica that encoded it
+        # overlap: some encoder stage started while another batch's token loop was running
+        assert any(f[2] < b[2] < f[3] for b in begins for f in finishes), (begins, finishes)
+        assert pool.stats["stt_requests"] == 12
+    finally:
+        pool.shutdown()
