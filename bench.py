@@ -103,17 +103,17 @@ def parse(argv=None):
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=30.0, help="measurement window of one open-loop probe")
     ap.add_argument("--confirm-probes", type=int, default=1, help="repeats (other arrival phases) of the probe at the sustained session count; a failed repeat steps the figure down")
-    ap.add_argument("--tts-admit-wait-s", type=float, default=0.15, help="pacing of the pool's continuous TTS lane: a queued request joins the frame loop once it has waited this long "
+    ap.add_argument("--tts-admit-wait-s", type=float, default=0.25, help="pacing of the pool's continuous TTS lane: a queued request joins the frame loop once it has waited this long "
                     "(at once when the lane is idle or a round is due): rounds are fuller, TTFA grows by at most this")
     ap.add_argument("--probe-only", action="store_true", help="A/B runs: skip the single-session and warm-up probes (use with --probe-sessions and a short timed region)")
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
     ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
-    ap.add_argument("--tts-lead-s", type=float, default=2.0, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
+    ap.add_argument("--tts-lead-s", type=float, default=0.5, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
     ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
     ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
                     "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
-    ap.add_argument("--stt-stages", type=int, default=2, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
+    ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
     ap.add_argument("--max-probes", type=int, default=5, help="open-loop probes of the sustained-sessions bisection")
@@ -345,7 +345,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0, stt_stages=2):
+                   admit_wait_s=0.0, stt_stages=1):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of

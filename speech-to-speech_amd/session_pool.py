@@ -80,7 +80,7 @@ class SessionPool:
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
                  tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
-                 tts_admit_wait_s: float = 0.0, stt_stages: int = 2):
+                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -94,8 +94,9 @@ class SessionPool:
         # STT as a two-stage pipeline (engines with stt_begin / stt_finish / replica, i.e. Whisper): the worker thread runs log-mel + encoder
         # of batch k + 1 on its stream while a second thread runs the token loop of batch k on another stream, each batch on its own engine
         # replica (weights shared).  The encoder fills the chip for 5 ms per session, the token loop is a chain of 35 x 256 latency-bound
-        # launches (72 ms whatever the batch): back to back on one stream they made a batch of 14 take 160 ms (260 ms under the TTS lane).
-        # 1 = one stage (round 3).
+        # launches (72 ms whatever the batch).  MEASURED NEGATIVE on C3 (profiles/r04_open_loop_ab.txt): with the wide TTS lane on a third
+        # stream the token loop's 9 000 dependent launches wait behind the encoder's and the frame loop's workgroups - p95 TTFA at 1 100
+        # sessions 1 085 ms with two stages vs 848 ms with one.  Default 1 = one stage; the option stays for lighter loads.
         self.stt_stages = max(1, int(stt_stages))
         self._stt_reps: dict[str, list] = {}          # model -> engines of the pipeline (the pool's engine + replicas)
         self._stt_free: dict[str, "queue.Queue[int]"] = {}
