@@ -101,7 +101,7 @@ def parse(argv=None):
                     "experimental, default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
-    ap.add_argument("--boundary-seconds", type=float, default=30.0, help="measurement window of one open-loop probe")
+    ap.add_argument("--boundary-seconds", type=float, default=25.0, help="measurement window of one open-loop probe")
     ap.add_argument("--confirm-probes", type=int, default=1, help="repeats (other arrival phases) of the probe at the sustained session count; a failed repeat steps the figure down")
     ap.add_argument("--tts-admit-wait-s", type=float, default=0.25, help="pacing of the pool's continuous TTS lane: a queued request joins the frame loop once it has waited this long "
                     "(at once when the lane is idle or a round is due): rounds are fuller, TTFA grows by at most this")
@@ -116,7 +116,7 @@ def parse(argv=None):
     ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
-    ap.add_argument("--max-probes", type=int, default=5, help="open-loop probes of the sustained-sessions bisection")
+    ap.add_argument("--max-probes", type=int, default=4, help="open-loop probes of the sustained-sessions bisection")
     ap.add_argument("--turn-batches", action="store_true", help="open-loop probe with round-2 turn-batch TTS lanes instead of continuous batching (A/B)")
     ap.add_argument("--pool-lanes", type=int, default=1, help="TTS lanes of the SessionPool in the open-loop probe (round 4: ONE wide, paced lane; round 3 ran 3 eager lanes of 128 slots)")
     ap.add_argument("--pool-max-batch", type=int, default=None, help="largest STT / TTS batch the SessionPool of the open-loop probe may form (default: 128 for c3, else --sessions)")
