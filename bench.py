@@ -93,7 +93,7 @@ def parse(argv=None):
     ap.add_argument("--reply-frames", type=int, default=None, help="codec frames of the reply (default: 128 = 10.24 s; 64 for c1); reduced runs for counter collection")
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream")
-    ap.add_argument("--tts-lanes", type=int, default=2, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
+    ap.add_argument("--tts-lanes", type=int, default=None, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
     ap.add_argument("--tts-slots", type=int, default=None, help="rows (slots) of the TTS engine's frame loop (default: 512 for c3 - the wide loop of csrc/gemm_decw.hip -, else --sessions)")
     ap.add_argument("--lane-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the TTS lanes (-1 = high: their short latency-bound "
                     "kernels are dispatched ahead of the encoder's workgroups; experimental, default 0)")
@@ -624,7 +624,7 @@ def main():
     tts_replicas = []
     front = None
     if not args.stt_only:
-        K = 1 if args.serial else max(1, args.tts_lanes)
+        K = 1 if args.serial else max(1, args.tts_lanes if args.tts_lanes is not None else (2 if wl == "c3" else 3))      # (c3: 2 lanes x 256-row runs; small workloads: 3 as in round 3)
         tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=TMB, max_prompt=128, max_frames=n_frames, max_codec_frames=CHUNK_FRAMES, device=dev, seed=rank)
         tts_replicas = [tts] + [tts.replica() for _ in range(K - 1)]
         g = torch.Generator().manual_seed(7)

@@ -225,6 +225,9 @@ class MI355XQwen3TTSHandler(BaseHandler):
                         first = False
                     for block in blocker.push(np.asarray(chunk, dtype=np.int16)):
                         total += len(block)
+                        started = getattr(chunks, "started", None)
+                        if started is not None and not started.is_set():
+                            started.set()        # first audible block: from here on the pool may pace this reply by its audio lead
                         yield block
             for block in blocker.flush():
                 total += len(block)

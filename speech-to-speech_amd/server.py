@@ -147,6 +147,7 @@ def create_app(pool: Any, stt_model: str = "whisper", tokenizer: Any = None, stt
         def gen():
             try:
                 for c in chunks:
+                    chunks.started.set()      # (no silence trimming on this path: the first chunk is the first audio)
                     yield np.asarray(c, dtype="<i2").tobytes()
             finally:
                 cancel.set()         # client gone (generator closed) or stream complete: the lane stops generating for this request

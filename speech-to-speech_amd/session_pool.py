@@ -49,6 +49,28 @@ class _TTSRequest:
     chunks: "queue.Queue[Any]" = field(default_factory=queue.Queue)
     cancelled: threading.Event = field(default_factory=threading.Event)
     t_submit: float = field(default_factory=time.perf_counter)
+    # set by the consumer once it has handed out its first AUDIBLE block (the handler trims leading silence): until then the lane does not
+    # pace this session by its audio lead - a reply that starts with silent chunks would otherwise reach its first audio at playback speed
+    started: threading.Event = field(default_factory=threading.Event)
+
+
+class _ChunkStream:
+    """What `synthesize` hands to a handler thread: an iterator over int16 chunks; `started` is the request's event (see _TTSRequest)."""
+
+    def __init__(self, req: "_TTSRequest"):
+        self._req = req
+        self.started = req.started
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._req.chunks.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
 
 
 class SessionPool:
@@ -214,16 +236,7 @@ class SessionPool:
         self._tts_q.put(req)
         self._wake.set()
 
-        def it():
-            while True:
-                item = req.chunks.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                yield item
-
-        return it(), req.cancelled
+        return _ChunkStream(req), req.cancelled
 
     def _fail_pending(self) -> None:
         """Requests still queued at shutdown are failed, so no handler thread blocks forever on a future / chunk queue."""

@@ -308,6 +308,7 @@ class ContinuousTTS:
             i = j + 1
 
     FRAME_S = 0.08                   # one codec frame = 80 ms of audio (12.5 Hz)
+    HUNGRY_FRAMES = 32               # a session whose consumer has not reported audible audio yet is served eagerly for this many frames
 
     def min_lead_s(self, now: float) -> float:
         """Smallest audio lead over the live sessions: seconds of already delivered audio that playback has not reached yet
@@ -316,6 +317,9 @@ class ContinuousTTS:
             return float("-inf")
         lead = float("inf")
         for r in self.rows_live.values():
+            st = getattr(r.job, "started", None)
+            if st is not None and not st.is_set() and r.frames < self.HUNGRY_FRAMES:
+                return float("-inf")         # (leading silence is trimmed by the handler: nothing audible has left yet)
             lead = min(lead, r.t_first + r.frames * self.FRAME_S - now)
         return lead
 
