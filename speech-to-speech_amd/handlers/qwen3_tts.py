@@ -33,6 +33,47 @@ MIN_UTTERANCE_TOKENS = 360
 TOKENS_PER_SECOND = 12.5
 WORDS_PER_SECOND, CHARS_PER_SECOND, CJK_CHARS_PER_SECOND = 2.6, 14.0, 5.5
 SAFETY_MARGIN, BASE_PROMPT_SECONDS, PUNCTUATION_PAUSE_SECONDS = 1.35, 1.0, 0.5
+# language codes a session may carry -> the names a Qwen3-TTS checkpoint's layout uses (same table as the reference's
+# QWEN3_LANGUAGE_ALIASES, TTS/qwen3_tts_handler.py:68-89; unknown values pass through lower-cased)
+LANGUAGE_ALIASES = {"zh": "chinese", "zh-cn": "chinese", "zh-hans": "chinese", "zh-hant": "chinese", "cmn": "chinese", "en": "english", "en-us": "english",
+                    "en-gb": "english", "ja": "japanese", "jp": "japanese", "ko": "korean", "kr": "korean", "de": "german", "fr": "french", "ru": "russian",
+                    "pt": "portuguese", "pt-br": "portuguese", "pt-pt": "portuguese", "es": "spanish", "it": "italian"}
+
+
+def normalize_language(language: Optional[str]) -> str:
+    """`_normalize_language` of the reference (TTS/qwen3_tts_handler.py:394-400): None / empty -> "auto"; '_' -> '-', lower case, aliases."""
+    if language is None:
+        return "auto"
+    n = str(language).strip().replace("_", "-").lower()
+    return LANGUAGE_ALIASES.get(n, n) if n else "auto"
+
+
+def resolve_voice(layout: Any, speaker: Optional[str], language: Optional[str]) -> tuple[Optional[str], Optional[str]]:
+    """(speaker key, language key) of a checkpoint layout for a session's settings: the language goes through `normalize_language` and is
+    matched case-insensitively ("auto" / a language the layout does not list -> no language row, like the reference's 'auto'); the speaker is
+    matched case-insensitively, an unknown name is an error listing the supported ones, and no speaker on a layout that HAS speakers
+    resolves to its first one (reference `_resolve_speaker` :596-610, `_validate...` :525-531)."""
+    lang_ids = dict(getattr(layout, "language_ids", None) or {})
+    spk_ids = dict(getattr(layout, "speaker_ids", None) or {})
+    lang = normalize_language(language)
+    lang_key = None
+    if lang != "auto" and lang_ids:
+        by_lower = {k.lower(): k for k in lang_ids}
+        lang_key = by_lower.get(lang)
+        if lang_key is None:
+            logger.warning("Qwen3-TTS: language %r is not in the checkpoint's language table %s; using auto", language, sorted(lang_ids))
+    spk_key = None
+    if spk_ids:
+        if speaker:
+            by_lower = {k.lower(): k for k in spk_ids}
+            spk_key = by_lower.get(str(speaker).strip().lower())
+            if spk_key is None:
+                raise ValueError(f"speaker {speaker!r} is not supported by this checkpoint; supported: {', '.join(sorted(spk_ids, key=str.lower)) or 'unknown'}")
+        else:
+            spk_key = next(iter(spk_ids))
+    return spk_key, lang_key
+
+
 CJK_PATTERN = re.compile(r"[぀-ヿ㐀-䶿一-鿿가-힯豈-﫿\U00020000-\U0002fa1f]")
 
 
@@ -106,6 +147,10 @@ class MI355XQwen3TTSHandler(BaseHandler):
         eng = self.pool.engine("tts")
         if hasattr(eng, "configure_sampling"):
             eng.configure_sampling(gen_kwargs)      # before the lanes clone the engine
+        # the session's voice is resolved ONCE, here (a bad speaker name fails setup, not every turn): language aliases ('en' -> 'english'),
+        # case-insensitive speaker, first supported speaker when none is given
+        layout = getattr(getattr(eng, "text_frontend", None), "layout", None)
+        self._voice = resolve_voice(layout, speaker, language) if layout is not None else (None, None)
         self.pool.warm_tts_lanes()       # load + warm up synchronously, like the reference's setup()
 
     def _estimate_max_new_tokens(self, text: Optional[str]) -> int:
@@ -161,8 +206,10 @@ class MI355XQwen3TTSHandler(BaseHandler):
         eng = self.pool.engine("tts")
         fe = eng.text_frontend
         if getattr(fe, "layout", None) is not None:      # checkpoint front-end: the session's voice / language select codec-side control rows
-            lang = getattr(self, "language", None)
-            return TTSPrompt(fe.embed(text, eng.max_prompt, speaker=getattr(self, "speaker", None), language=None if lang in (None, "auto") else lang))
+            voice = getattr(self, "_voice", None)
+            if voice is None:                            # (handlers built without setup(): resolve on first use)
+                voice = self._voice = resolve_voice(fe.layout, getattr(self, "speaker", None), getattr(self, "language", None))
+            return TTSPrompt(fe.embed(text, eng.max_prompt, speaker=voice[0], language=voice[1]))
         return TTSPrompt(fe.embed(text, eng.max_prompt))
 
     def _build_prompts(self, text: str) -> list[tuple[str, TTSPrompt]]:

@@ -547,3 +547,60 @@ def test_session_pool_two_stage_stt_overlaps_encoder_and_token_loop():
         assert pool.stats["stt_requests"] == 12
     finally:
         pool.shutdown()
+
+
+def test_tts_handler_language_aliases_and_speaker_resolution():
+    """Reference behaviour (TTS/qwen3_tts_handler.py:394-400, 525-531, 596-610): 'en' / 'EN_us' -> 'english', unknown language -> auto,
+    speaker matched case-insensitively, no speaker -> the checkpoint's first, unknown speaker -> an error naming the supported ones."""
+    import types
+
+    import pytest
+
+    from speech_to_speech_amd.handlers.qwen3_tts import normalize_language, resolve_voice
+
+    assert normalize_language(None) == "auto" and normalize_language("  ") == "auto" and normalize_language("EN_us") == "english"
+    assert normalize_language("zh-Hant") == "chinese" and normalize_language("Klingon") == "klingon"
+    lay = types.SimpleNamespace(language_ids={"English": 7, "chinese": 8}, speaker_ids={"Vivian": 3, "ryan": 4})
+    assert resolve_voice(lay, None, "en") == ("Vivian", "English")
+    assert resolve_voice(lay, "RYAN", "auto") == ("ryan", None)
+    assert resolve_voice(lay, "vivian", "tlh") == ("Vivian", None)
+    with pytest.raises(ValueError, match="supported: ryan, Vivian"):
+        resolve_voice(lay, "nobody", "en")
+    assert resolve_voice(types.SimpleNamespace(language_ids={}, speaker_ids={}), None, "en") == (None, None)
+
+
+def test_smart_turn_tick_batcher_serves_concurrent_sessions_with_one_batch():
+    """f1: concurrent sessions' `predict()` calls share ONE feature launch and ONE classifier call per tick; every caller gets
+    the decision for ITS audio; a bad argument fails only its caller; close() fails what is still queued.  Host stand-ins for the GPU
+    feature extractor and the ONNX session (the GPU half: tests/test_logmel_gpu.py)."""
+    import threading
+    import time
+
+    import numpy as np
+    import pytest
+
+    from speech_to_speech_amd.smart_turn import MI355XSmartTurnAnalyzer
+
+    calls = []
+
+    def features(audios, sample_rate):
+        calls.append(len(audios))
+        time.sleep(0.01)
+        return np.stack([np.full((80, 800), float(a[-1]), np.float32) for a in audios])          # the "feature" is the utterance's last sample
+
+    an = MI355XSmartTurnAnalyzer(lambda f: f[:, 0, 0], threshold=0.5, max_batch=16, warmup=False, tick_ms=30.0, features=features)
+    out = {}
+
+    def ask(i):
+        out[i] = an.predict(np.full(1600, i / 10.0, np.float32))
+
+    ths = [threading.Thread(target=ask, args=(i,)) for i in range(8)]
+    [t.start() for t in ths]
+    [t.join(timeout=10) for t in ths]
+    assert sorted(out) == list(range(8)) and all(abs(out[i].probability - i / 10.0) < 1e-6 and out[i].complete == (i / 10.0 > 0.5) for i in range(8))
+    assert sum(calls) == 8 and max(calls) >= 4 and an.stats["max_tick_batch"] == max(calls) and an.stats["ticks"] == len(calls)       # one batch per tick, not eight B = 1 calls
+    with pytest.raises(ValueError, match="mono"):
+        an.predict(np.zeros((2, 100), np.float32))
+    an.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        an.predict(np.zeros(100, np.float32))

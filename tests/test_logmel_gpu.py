@@ -123,3 +123,34 @@ def test_smart_turn_features_match_oracle_and_golden(golden_dir):
     feats = sess.feeds[0]["input_features"]
     assert feats.shape == (1, 80, 800) and feats.dtype == np.float32
     an2.features.close()
+
+
+def test_smart_turn_tick_batcher_one_launch_same_features():
+    """B sessions whose `predict()` calls fall into one tick are served by ONE `s2s_logmel_whisper_window` launch (the classifier sees one
+    [B, 80, 800] batch) and get exactly the features B single calls produce."""
+    import threading
+
+    from speech_to_speech_amd.smart_turn import MI355XSmartTurnAnalyzer, SmartTurnFeatures
+
+    rng = np.random.default_rng(5)
+    lens = [16000, 128000, 40000, 200000, 9000]
+    audios = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    st = SmartTurnFeatures(max_batch=8, device="cuda:0")
+    single = [st([a]).cpu().numpy()[0] for a in audios]
+    seen = []
+
+    def classifier(f):
+        seen.append(np.array(f))
+        return f.reshape(f.shape[0], -1).mean(1)
+
+    an = MI355XSmartTurnAnalyzer(classifier, threshold=0.5, max_batch=8, warmup=False, tick_ms=80.0, features=st)
+    res = {}
+    ths = [threading.Thread(target=lambda i=i: res.__setitem__(i, an.predict(audios[i]))) for i in range(5)]
+    [t.start() for t in ths]
+    [t.join(timeout=30) for t in ths]
+    assert len(res) == 5 and len(seen) == 1 and seen[0].shape == (5, 80, 800), [x.shape for x in seen]
+    want = sorted(float(s.mean()) for s in single)
+    assert np.allclose(sorted(r.probability for r in res.values()), want, rtol=0, atol=1e-7)
+    for row in seen[0]:
+        assert any(np.array_equal(row, s) for s in single)            # bit-identical to the B = 1 launches
+    an.close()
