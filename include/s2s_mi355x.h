@@ -50,30 +50,11 @@ int32_t s2s_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails */
 int32_t s2s_device_count(void);
 
-/* Kernel timing for bench.py's roofline line: while a category bit is enabled every launch of that
- * kernel family is bracketed by HIP events on its own stream; s2s_prof_collect waits for them and
- * returns (and resets) the summed device time, the algorithmic FLOPs / bytes the launches were
- * asked to do, and their count. */
-#define S2S_PROF_GEMM_TILE 0   /* bf16/f32 MFMA tile GEMM (encoder projections, conv stems) */
-#define S2S_PROF_GEMM_SKINNY 1 /* weight-streaming decode GEMM (M <= 64) */
-#define S2S_PROF_ATTN_MFMA 2   /* flash attention */
-#define S2S_PROF_ATTN_ROWS 3   /* decode / parity attention */
-#define S2S_PROF_LOGMEL 4
-#define S2S_PROF_NCAT 8
-int32_t s2s_prof_enable(uint32_t category_mask);
-int32_t s2s_prof_collect(int32_t category, double* total_ms, double* flops, double* bytes, int64_t* launches);
-/* Device time of an empty start/stop event pair (median, measured on first collect); s2s_prof_collect subtracts it from
- * every launch so that the family averages match profiler kernel durations.  0 before the first collect. */
-double s2s_prof_event_overhead_us(void);
 /* The autoregressive loops (TTS codec frames, Whisper decode steps) keep every per-step quantity on the
  * device and replay one captured hipGraph per step.  on = 0 forces plain stream launches (the same kernels,
  * the same results); graphs are also bypassed while kernel timing is enabled.  Default on; the environment
  * variable S2S_NO_GRAPHS=1 starts with it off. */
 int32_t s2s_graphs_enable(int32_t on);
-/* A HIP stream restricted to cus_per_8 of every 8 consecutive compute units (hipExtStreamCreateWithCUMask; 8 = all CUs).  For hosts
- * that run the latency-bound TTS lanes next to the STT encoder on one GPU (speech-to-speech_amd/session_pool.py `tts_lane_cus`). */
-int32_t s2s_stream_create_masked(int32_t cus_per_8, void** out_stream);
-int32_t s2s_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Log-mel front-ends.
@@ -185,15 +166,6 @@ int32_t s2s_op_gemm_dec_ln(void* stream, const void* A, int64_t lda, const void*
                            void* C, int64_t ldc, int32_t act, int32_t layout, const float* csum_dev);
 int32_t s2s_op_rows_prep_pairs(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
                                int32_t frag, int64_t pair_stride);
-/* Tuning hook of the decode projections (microbenchmarks, parity sweeps): enable = 0 keeps every call on the 16-column kernel;
- * splitk / nt > 0 force the K-slices per column block / the 16-column tiles per wave of the column-block kernel (0 = chosen
- * from the shape).  Process-wide: not for use while engines are serving. */
-int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt);
-/* The same for the row-block kernel of wide frame loops (129 .. 1024 rows, csrc/gemm_decw.hip): enable = 0 sends such calls down the
- * 128-row slab path, splitk > 0 forces the K-slices per tile, min_m > 0 moves the smallest row count the kernel takes (default 129). */
-int32_t s2s_op_gemm_decw_tune(int32_t enable, int32_t splitk, int32_t min_m);
-/* development: per-workgroup phase timestamps of the column-block decode kernel (8 x u64 per workgroup, 100 MHz), null = off */
-int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
 /* xb = bf16(x) (frag != 0: fragment-major [rows][cols]) and ss[r] = sum_c x[r][c]^2 (one partial per row): entry of a norm-free decode pass */
 int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, int64_t xb_rs, float* ss, int32_t rows, int32_t cols,
                          int32_t frag);
@@ -201,10 +173,6 @@ int32_t s2s_op_rows_prep(void* stream, const float* x, int64_t x_rs, void* xb, i
  * gamma (optional f32 [K]) is folded into the columns (out = W * gamma rounded once to bf16). */
 int32_t s2s_op_to_frag(void* stream, const void* W, int64_t ld, const float* gamma, void* out, int32_t rows, int32_t K);
 
-/* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
- * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */
-int32_t s2s_graph_bench_begin(void** out_stream);
-int32_t s2s_graph_bench_end(int32_t warm, int32_t reps, double* us_per_replay);
 
 /* y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x f32 [rows][cols], y y_dtype */
 int32_t s2s_op_layernorm(void* stream, const float* x, const float* gamma, const float* beta,

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/s2s_mi355x.h"
+#include "../../include/s2s_mi355x_dev.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;

@@ -158,30 +158,6 @@ extern "C" int32_t s2s_prof_collect(int32_t category, double* total_ms, double* 
 static hipStream_t g_bench_stream = nullptr;
 static bool g_bench_capturing = false;
 
-/* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): `cus_per_8` of every 8 consecutive CU
- * indices are enabled (1 .. 8; 8 = all).  The session pool can put its latency-bound TTS lanes on such a stream so that they stop
- * evicting the STT encoder's LDS-heavy tiles from EVERY CU.  Destroy with s2s_stream_destroy. */
-extern "C" int32_t s2s_stream_create_masked(int32_t cus_per_8, void** out_stream) {
-    S2S_REQUIRE(out_stream && cus_per_8 >= 1 && cus_per_8 <= 8, "stream_create_masked: cus_per_8 must be 1 .. 8");
-    int dev = 0;
-    S2S_HIP_CHECK(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    S2S_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    const int ncu = prop.multiProcessorCount;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; ++i)
-        if ((i & 7) < cus_per_8) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t st = nullptr;
-    S2S_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
-    *out_stream = (void*)st;
-    return S2S_OK;
-}
-
-extern "C" int32_t s2s_stream_destroy(void* stream) {
-    if (stream) S2S_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
-    return S2S_OK;
-}
-
 extern "C" int32_t s2s_graph_bench_begin(void** out_stream) {
     S2S_REQUIRE(out_stream && !g_bench_capturing, "graph_bench_begin: bad state");
     if (!g_bench_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&g_bench_stream, hipStreamNonBlocking));

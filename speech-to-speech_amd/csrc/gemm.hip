@@ -750,9 +750,9 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
 constexpr int T4_M = 256, T4_N = 256, T4_BK = 32, T4_ROWB = 64, T4_A_BYTES = T4_M * T4_ROWB, T4_W_BYTES = T4_N * T4_ROWB,
               T4_STAGE = T4_A_BYTES + T4_W_BYTES, T4_NST = 4;
 
-// NWN = 2: 4 waves (2 x 2), wave tile 128 x 128 (64 flop per LDS byte, one wave per SIMD).
 // NWN = 4: 8 waves (2 x 4), wave tile 128 x 64 (44 flop per LDS byte, 128 accumulator registers, TWO waves per SIMD that hide
-//          each other's fragment reads).  Which one wins is a measurement (S2S_TILE4=1 / =2).
+//          each other's fragment reads).  (The 4-wave NWN = 2 variant - 128 x 128 wave tiles, one wave per SIMD - measured slower than
+//          gemm_tile3 in round 3 and is no longer instantiated.)
 template <typename CT, int NWN>
 __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
@@ -1141,11 +1141,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(
 
 // the 256x256 kernel serves the encoder-sized bf16 projections (S2S_TILE4=0 keeps them on gemm_tile3; measured round 3,
 // profiles/r03_tile4_check.txt: parity OK on every shape, 8-wave variant +2 .. +19 % over gemm_tile3 on the Whisper encoder GEMMs,
-// the 4-wave variant slower than gemm_tile3 - it stays selectable with S2S_TILE4=1 for A/B runs only)
+// the 4-wave variant slower than gemm_tile3 - deleted in round 4)
 static int tile4_mode() {
     static const int mode = [] {
         const char* e = getenv("S2S_TILE4");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;
     }();
     return mode;
 }
@@ -1238,19 +1238,13 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             int dev = 0;
             S2S_HIP_CHECK(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr4[dev]) {
-                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                 if (dev >= 0 && dev < 64) attr4[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                            ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-            const bool eight_waves = tile4_mode() >= 2;
-            if (eight_waves)
-                launch_k(gemm_tile4_kernel<CT, 4>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
-            else
-                launch_k(gemm_tile4_kernel<CT, 2>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            launch_k(gemm_tile4_kernel<CT, 4>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
         }
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
                (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {

@@ -15,6 +15,7 @@ from . import PACKAGE_DIR, REPO_ROOT
 
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libs2s_mi355x.so")
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "s2s_mi355x.h")
+DEV_HEADER_PATH = os.path.join(REPO_ROOT, "include", "s2s_mi355x_dev.h")
 
 S2S_F32, S2S_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -61,12 +62,7 @@ _SIGNATURES = {
     "s2s_last_error": [],
     "s2s_abi_version": [],
     "s2s_device_count": [],
-    "s2s_prof_enable": [C.c_uint32],
     "s2s_graphs_enable": [_i32],
-    "s2s_stream_create_masked": [_i32, C.POINTER(_vp)],
-    "s2s_stream_destroy": [_vp],
-    "s2s_prof_event_overhead_us": [],
-    "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_frontend_create": [_i32, _i32, _vp, _i32, C.POINTER(_vp)],
     "s2s_frontend_destroy": [_vp],
     "s2s_logmel_whisper": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
@@ -78,12 +74,8 @@ _SIGNATURES = {
     "s2s_op_gemm_dec_parts": [_i32, _i32, _i32, _i32, _i32],
     "s2s_op_gemm_dec_ln": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _i32, _vp],
     "s2s_op_rows_prep_pairs": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i64],
-    "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
-    "s2s_op_gemm_dec_debug": [_vp],
     "s2s_op_rows_prep": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32],
     "s2s_op_to_frag": [_vp, _vp, _i64, _vp, _vp, _i32, _i32],
-    "s2s_graph_bench_begin": [C.POINTER(_vp)],
-    "s2s_graph_bench_end": [_i32, _i32, C.POINTER(C.c_double)],
     "s2s_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_op_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
     "s2s_logmel_whisper_tm": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
@@ -121,7 +113,6 @@ _SIGNATURES = {
     "s2s_tts_release": [_vp, _vp, _i32, _i32],
     "s2s_tts_read_codes_rows": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp],
     "s2s_codec_decode_rows_at": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32],
-    "s2s_op_gemm_decw_tune": [_i32, _i32, _i32],
     "s2s_op_sample_tokens": [_vp, _vp, _i32, _i32, _f32, _i32, _f32, _f32, C.c_uint64, _vp, _i32, _vp],
     "s2s_tts_set_sampling": [_vp, _i32, _f32, _i32, _f32, _f32, C.c_uint64],
     "s2s_tts_generate_forced": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
@@ -133,6 +124,17 @@ _SIGNATURES = {
     "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_resample_poly_int16": [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+}
+# development / measurement hooks (include/s2s_mi355x_dev.h): bench.py's kernel timers, tools/, the parity sweeps of tests/
+_DEV_SIGNATURES = {
+    "s2s_prof_enable": [C.c_uint32],
+    "s2s_prof_event_overhead_us": [],
+    "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
+    "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
+    "s2s_op_gemm_dec_debug": [_vp],
+    "s2s_graph_bench_begin": [C.POINTER(_vp)],
+    "s2s_graph_bench_end": [_i32, _i32, C.POINTER(C.c_double)],
+    "s2s_op_gemm_decw_tune": [_i32, _i32, _i32],
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
              "s2s_parakeet_workspace_bytes": C.c_int64, "s2s_tts_workspace_bytes": C.c_int64,
@@ -157,7 +159,7 @@ def load():
         except Exception:  # pragma: no cover - torch is optional for symbol checks
             pass
         lib = C.CDLL(LIB_PATH)
-        for name, argtypes in _SIGNATURES.items():
+        for name, argtypes in list(_SIGNATURES.items()) + list(_DEV_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, _i32)
@@ -165,11 +167,11 @@ def load():
         return lib
 
 
-def declared_symbols() -> list[str]:
-    """Every function name the public header declares (used by the export test)."""
+def declared_symbols(header: str | None = None) -> list[str]:
+    """Every function name the public header (or `header`) declares (used by the export test)."""
     import re
 
-    with open(HEADER_PATH) as f:
+    with open(header or HEADER_PATH) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(s2s_[a-z0-9_]+)\s*\(", text)))

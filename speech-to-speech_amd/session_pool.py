@@ -130,8 +130,7 @@ class SessionPool:
         # largest final-STT batch (0: the engine's max_batch).  A cap keeps a backlog from locking the pool into long STT batches whose
         # sessions then all start their TTS at the same instant (bursty prefills against the next batch's encoder)
         self.stt_max_batch = int(stt_max_batch)
-        # CU mask of the TTS lanes' streams: lanes run on `tts_lane_cus` of every 8 compute units (8 = all, no mask)
-        self.tts_lane_cus = int(tts_lane_cus)
+        self.tts_lane_cus = 8                    # (round 3's CU-masked lane streams measured negative and were removed; the argument is accepted and ignored)
         self.continuous = bool(continuous)       # TTS lanes admit / retire sessions at chunk boundaries (tts_continuous.py); False: turn-batches
         self._lane_live: dict[int, int] = {}     # live sessions per continuous lane (load balancing between lanes)
         self.tts_lanes = max(1, int(tts_lanes))
@@ -508,14 +507,6 @@ class SessionPool:
             dev = torch.device(self.device)
             if dev.type == "cuda" and torch.cuda.is_available():
                 torch.cuda.set_device(dev)
-                if 1 <= cus_per_8 < 8:           # a stream confined to a subset of the CUs (created by the library, wrapped for torch)
-                    import ctypes as C
-
-                    from . import native
-
-                    h = C.c_void_p()
-                    native.check(native.load().s2s_stream_create_masked(int(cus_per_8), C.byref(h)), "s2s_stream_create_masked")
-                    return torch.cuda.stream(torch.cuda.ExternalStream(h.value, device=dev))
                 # (no device-wide synchronise here: it would collide with another lane's stream capture; the worker that builds an
                 # engine synchronises ITS stream before the build is reported done)
                 return torch.cuda.stream(torch.cuda.Stream(device=dev, priority=priority))

@@ -16,7 +16,7 @@ def test_library_loads_and_reports_version():
 
 def test_every_declared_symbol_is_exported():
     lib = native.load()
-    declared = native.declared_symbols()
+    declared = native.declared_symbols() + native.declared_symbols(native.DEV_HEADER_PATH)
     assert len(declared) >= 10
     missing = [s for s in declared if not hasattr(lib, s)]
     assert missing == []
@@ -27,6 +27,10 @@ def test_every_declared_symbol_has_a_binding():
     bound = set(native._SIGNATURES)
     assert declared - bound == set(), "header symbols without ctypes signature"
     assert bound - declared == set(), "ctypes signatures for symbols missing from the header"
+    # the development / measurement hooks live in their own header and binding table: none of them leaks into the public boundary
+    dev_declared, dev_bound = set(native.declared_symbols(native.DEV_HEADER_PATH)), set(native._DEV_SIGNATURES)
+    assert dev_declared == dev_bound and not (dev_declared & declared)
+    assert not any(n.endswith(("_tune", "_debug")) or "graph_bench" in n or "s2s_prof" in n for n in declared)
 
 
 def test_argument_errors_are_status_codes_not_crashes():
