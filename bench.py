@@ -345,7 +345,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0, stt_stages=1):
+                   admit_wait_s=0.0, stt_stages=1, partial_windows=()):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -375,6 +375,8 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     pool.warm_stt(stt_model)
     turn_period = utt_s + n_frames * FRAME_S
     workers = int(min(1024, max(8, n_sessions * (n_frames * FRAME_S + 3.0) / turn_period + 8)))      # turns in flight at once (a paced reply streams for up to its own duration)
+    if partial_windows:      # C5: a session's thread also lives through its utterance (live partials every 0.5 s)
+        workers = int(min(2048, n_sessions * 1.2 + 8))
 
     def make_handlers():
         if stt_model == "whisper":
@@ -406,6 +408,18 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
         if not hasattr(local, "h"):
             local.h = make_handlers()
         stt, tts, llm = local.h
+        n_part, n_part_ans = 0, 0
+        full_audio = audios[session % len(audios)]
+        for w in partial_windows:            # C5: progressive VADAudio while the user is still speaking (reference VAD handler: 0.5 s cadence)
+            tgt = t_arr - utt_s + w
+            now = time.perf_counter()
+            if tgt > now:
+                time.sleep(tgt - now)
+            elif now - tgt > 0.45:
+                continue                     # the previous partial is still running: this tick is skipped (the reference's try-lock-and-skip)
+            n_part += 1
+            pa = VADAudio(audio=full_audio[: int(w * 16000)], mode="progressive", turn_id=f"s{session}", turn_revision=0, created_at_s=tgt)
+            n_part_ans += len(list(stt.process(pa)))
         now = time.perf_counter()
         if t_arr > now:
             time.sleep(t_arr - now)
@@ -428,7 +442,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
             n_blocks += 1
         with lock:
             results.append({"in_window": in_window, "stt": t_stt, "ttfa": None if t_first is None else t_first - t_arr, "done": time.perf_counter() - t_arr,
-                            "blocks": n_blocks, "late": late})
+                            "blocks": n_blocks, "late": late, "partials": n_part, "partials_answered": n_part_ans})
 
     rng = np.random.default_rng(seed)
     cpu0 = os.times()
@@ -436,10 +450,12 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     t0 = time.perf_counter() + 0.2
     arrivals = []
     if n_sessions == 1:       # an idle system: a few turns of one session, spaced far enough apart to never overlap
-        ramp, arrivals = 0.0, [(0.3 + 4.0 * k, 0) for k in range(max(2, int(window_s // 4.0)))]
+        lead_in = utt_s if partial_windows else 0.0      # (C5: the utterance itself takes place inside the probe)
+        ramp, arrivals = 0.0, [(lead_in + 0.3 + (4.0 + lead_in) * k, 0) for k in range(max(2, int(window_s // (4.0 + lead_in))))]
     else:
         phases = rng.uniform(0.0, turn_period, n_sessions)
-        ramp = min(3.0, turn_period)
+        ramp = min(3.0, turn_period) + (utt_s if partial_windows else 0.0)      # (C5: the first utterances START at t0)
+        phases = phases + (utt_s if partial_windows else 0.0)
         for s in range(n_sessions):
             t = phases[s]
             while t < ramp + window_s:
@@ -474,6 +490,9 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
            "pool": {k: (round(stats[k], 2) if isinstance(stats[k], float) else stats[k]) for k in ("stt_batches", "max_stt_batch", "tts_batches", "tts_requests", "stt_busy_s",
                                                                                                     "tts_rounds", "tts_round_s", "tts_admit_s", "tts_row_rounds", "host_cores_busy") if k in stats},
            "p50_ttfa_ms": None, "p95_ttfa_ms": None, "max_playback_lag_ms": None}
+    if partial_windows and win:
+        res.update(partials_sent=int(sum(r["partials"] for r in win)), partials_answered=int(sum(r["partials_answered"] for r in win)),
+                   partial_passes_per_turn=len(partial_windows))
     if win:
         stt_l = np.array([r["stt"] for r in win]) * 1e3
         res.update(p50_stt_ms=round(float(np.percentile(stt_l, 50)), 1), p95_stt_ms=round(float(np.percentile(stt_l, 95)), 1))      # arrival -> transcript
@@ -760,7 +779,7 @@ def main():
     # ---- the SURVEY 8d metric through the boundary (handlers + SessionPool): every rank probes ITS GPU's pool (sessions are pinned to a
     # pool, nothing is exchanged), the whole-job figure is the sum over ranks
     boundary = None
-    if not args.no_boundary and tts is not None and wl in ("c3", "c1", "c2", "tiny"):
+    if not args.no_boundary and tts is not None and wl in ("c3", "c1", "c2", "c5", "tiny"):
         try:
             lanes = max(1, args.pool_lanes)
             sys.setswitchinterval(max(1e-4, args.gil_switch_ms * 1e-3))
@@ -768,7 +787,7 @@ def main():
             def probe(n, window=args.boundary_seconds, seed=0):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch,
-                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages)
+                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows))
 
             single = None if args.probe_only else probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
