@@ -367,6 +367,18 @@ int32_t s2s_tts_step(void* model, void* stream, int32_t rows, int32_t n_frames);
 int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, int32_t n, int32_t frame0, int32_t n_frames, int32_t* codes_dev,
                            int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev);
 int32_t s2s_tts_release(void* model, void* stream, int32_t slot0, int32_t n);
+/* Move n live sessions from the slots [src_slot0, ..) of src_model into the slots [dst_slot0, ..) of dst_model - two engines of the same
+ * model (replicas sharing the weights, same max_prompt / max_frames): the talker cache rows of the first n_pos positions, the next input
+ * row, frame index / eos gate / budget / sampler key, the codes emitted so far, the codec decoder's history rows and the first n_codec_pos
+ * positions of its pre-transformer cache.  Asynchronous device copies on `stream`, which the caller has ordered behind the source engine's
+ * last launch; the source slots may be re-admitted once the copies have completed.  Lets a session's latency-critical FIRST chunk run in a
+ * small eager frame loop and its continuation in the wide, paced one (the reference streams every session independently,
+ * TTS/qwen3_tts_handler.py:695-749; its output does not depend on which loop produced which chunk).
+ * x_rows_dev (optional, f32 [n][t_hidden]): the sessions' next input rows as snapshotted by s2s_tts_read_x right behind their last frame -
+ * needed when the source loop has stepped since (a parked = released slot keeps everything except that row).  The destination slots are live. */
+int32_t s2s_tts_migrate(void* dst_model, void* src_model, void* stream, int32_t src_slot0, int32_t dst_slot0, int32_t n, int32_t n_pos,
+                        int32_t n_codec_pos, const float* x_rows_dev);
+int32_t s2s_tts_read_x(void* model, void* stream, int32_t slot0, int32_t n, float* x_out_dev);
 /* s2s_tts_read_codes for rows of DIFFERENT ages in one call: frame0_rows_dev int32[n] (device) = first frame to read per slot; chunk_samples
  * = n_frames * total_upsample (continuation chunks only - a stream's first chunk goes through s2s_tts_read_codes). */
 int32_t s2s_tts_read_codes_rows(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* frame0_rows_dev, int32_t n_frames,

@@ -96,6 +96,7 @@ struct Tts {
     // codec decoder buffers
     float* cx;  void *ca, *cb_, *cc;   // residual stream + ping-pong activations
     std::vector<void*> cstate;         // streaming history rows, one [B][LPAD][C] block per history-carrying stage
+    std::vector<int> cstate_c;         // channels C of each of them (the order codec_run visits them in)
     int* pos_c = nullptr;              // codec transformer positions (device, [B])
     int codec_frames_done = 0;
     int* host_flag = nullptr;
@@ -311,6 +312,12 @@ static int finalize(Tts* m) {
     {
         const size_t cmax = (size_t)std::max<long>(H, Dd);
         const int n_slots = 4 + 4 * c.n_dec_blocks + 1;
+        // channels per history block, in codec_run's order: 2 x (upsampler dw input, ConvNeXt output) at H, the decoder in-conv's snake at
+        // Dd, then per decoder block the transposed conv's snake + the three units' next snakes at Dd >> (i + 1)
+        m->cstate_c.assign(4, (int)H);
+        m->cstate_c.push_back((int)Dd);
+        for (int i = 0; i < c.n_dec_blocks; ++i)
+            for (int j = 0; j < 4; ++j) m->cstate_c.push_back((int)(Dd >> (i + 1)));
         for (int i = 0; i < n_slots; ++i) {
             void* p = nullptr;
             S2S_HIP_CHECK(hipMalloc(&p, B * LPAD * cmax * e));
@@ -771,6 +778,66 @@ extern "C" int32_t s2s_tts_admit(void* model, void* stream, const float* prompt_
     m->cur_B = std::max(m->cur_B, slot0 + n);
     return tts_admit_impl(m, (hipStream_t)stream, prompt_embeds_dev, prompt_len_dev, n, Tp, slot0, min_frames_dev, budget_dev, min_frames, max_new_frames,
                           utterance_id0);
+}
+
+/* Move n live sessions from the slots [src_slot0, ..) of ONE engine into the slots [dst_slot0, ..) of ANOTHER engine of the same model
+ * (replicas sharing the weights; same max_prompt / max_frames): everything a slot owns - the talker cache rows of its first n_pos
+ * positions, its next input row, frame index / eos gate / budget / sampler key, the codes emitted so far, the codec decoder's history rows
+ * and the first n_codec_pos positions of its pre-transformer cache.  Asynchronous copies on `stream`, which must already be ordered behind
+ * the source engine's last launch (event); the source slots may be re-admitted once these copies have completed.
+ * Why: a session's FIRST chunk is latency-critical and runs in a small, eager frame loop (a "nursery" engine); from its second chunk on it
+ * only has to stay ahead of its playback and continues in the wide, paced loop (speech-to-speech_amd/tts_continuous.py). */
+extern "C" int32_t s2s_tts_migrate(void* dst_model, void* src_model, void* stream, int32_t src_slot0, int32_t dst_slot0, int32_t n, int32_t n_pos,
+                                   int32_t n_codec_pos, const float* x_rows_dev) {
+    Tts *d = (Tts*)dst_model, *s = (Tts*)src_model;
+    S2S_REQUIRE(d && s && d != s && d->finalized && s->finalized, "tts_migrate: two finalized engines");
+    const auto &a = d->cfg, &b = s->cfg;
+    S2S_REQUIRE(a.dtype == b.dtype && a.t_hidden == b.t_hidden && a.t_layers == b.t_layers && a.t_kv_heads == b.t_kv_heads && a.t_head_dim == b.t_head_dim &&
+                    a.max_pos == b.max_pos && a.max_frames == b.max_frames && a.n_groups == b.n_groups && a.c_hidden == b.c_hidden && a.c_layers == b.c_layers &&
+                    a.c_heads == b.c_heads && a.c_decoder_dim == b.c_decoder_dim && a.n_dec_blocks == b.n_dec_blocks && d->codec.c.max_pos == s->codec.c.max_pos,
+                "tts_migrate: the engines must be replicas of one model with the same max_prompt / max_frames");
+    S2S_REQUIRE(n > 0 && src_slot0 >= 0 && src_slot0 + n <= s->max_batch && dst_slot0 >= 0 && dst_slot0 + n <= d->max_batch && n_pos >= 0 && n_pos <= a.max_pos &&
+                    n_codec_pos >= 0 && n_codec_pos <= d->codec.c.max_pos, "tts_migrate: bad slot range / positions");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t e = d->esz;
+    auto copy_cache = [&](const Stack& ss, const Stack& ds, int npos) -> int {
+        const size_t row = (size_t)ss.c.kv_heads * ss.c.head_dim * e, slot = (size_t)ss.c.max_pos * row;
+        if (npos <= 0) return S2S_OK;
+        for (int l = 0; l < ss.c.layers; ++l)
+            for (int kv = 0; kv < 2; ++kv) {
+                const char* sp = (const char*)(kv ? ss.vc : ss.kc) + ((size_t)l * s->max_batch + src_slot0) * slot;
+                char* dp = (char*)(kv ? ds.vc : ds.kc) + ((size_t)l * d->max_batch + dst_slot0) * slot;
+                S2S_HIP_CHECK(hipMemcpy2DAsync(dp, slot, sp, slot, (size_t)npos * row, n, hipMemcpyDeviceToDevice, st));
+            }
+        return S2S_OK;
+    };
+    int rc;
+    if ((rc = copy_cache(s->talker, d->talker, n_pos))) return rc;
+    if ((rc = copy_cache(s->codec, d->codec, n_codec_pos))) return rc;
+    for (size_t k = 0; k < s->cstate.size() && k < s->cstate_c.size(); ++k) {
+        const size_t rowb = (size_t)LPAD * s->cstate_c[k] * e;
+        S2S_HIP_CHECK(hipMemcpyAsync((char*)d->cstate[k] + dst_slot0 * rowb, (const char*)s->cstate[k] + src_slot0 * rowb, rowb * n, hipMemcpyDeviceToDevice, st));
+    }
+    const size_t E = a.t_hidden;
+    // the next input rows: a snapshot taken right behind the sessions' last frame (s2s_tts_read_x) when the source loop has gone on since -
+    // a parked slot's row of x is recomputed (as garbage) by every later frame of the source loop; everything else a parked slot owns stands still
+    S2S_HIP_CHECK(hipMemcpyAsync(d->x + dst_slot0 * E, x_rows_dev ? x_rows_dev : s->x + src_slot0 * E, sizeof(float) * E * n, hipMemcpyDeviceToDevice, st));
+    int* const dsti[] = {d->pos_t, d->frame_b, d->min_b, d->budget_b, d->utt_b, d->n_frames, d->code0};
+    int* const srci[] = {s->pos_t, s->frame_b, s->min_b, s->budget_b, s->utt_b, s->n_frames, s->code0};
+    for (int k = 0; k < 7; ++k) S2S_HIP_CHECK(hipMemcpyAsync(dsti[k] + dst_slot0, srci[k] + src_slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    S2S_HIP_CHECK(hipMemsetAsync(d->finished + dst_slot0, 0, sizeof(int) * n, st));       // live in the destination (the source parks its slots as finished)
+    const size_t cw = (size_t)a.max_frames * a.n_groups;
+    S2S_HIP_CHECK(hipMemcpyAsync(d->codes_out + dst_slot0 * cw, s->codes_out + src_slot0 * cw, sizeof(int) * cw * n, hipMemcpyDeviceToDevice, st));
+    d->cur_B = std::max(d->cur_B, dst_slot0 + n);
+    return S2S_OK;
+}
+
+/* The next talker input rows of the slots [slot0, slot0 + n) -> x_out_dev f32 [n][t_hidden] (a snapshot for s2s_tts_migrate). */
+extern "C" int32_t s2s_tts_read_x(void* model, void* stream, int32_t slot0, int32_t n, float* x_out_dev) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized && slot0 >= 0 && n > 0 && slot0 + n <= m->max_batch && x_out_dev, "tts_read_x: bad arguments");
+    S2S_HIP_CHECK(hipMemcpyAsync(x_out_dev, m->x + (size_t)slot0 * m->cfg.t_hidden, sizeof(float) * (size_t)n * m->cfg.t_hidden, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return S2S_OK;
 }
 
 extern "C" int32_t s2s_tts_release(void* model, void* stream, int32_t slot0, int32_t n) {

@@ -111,6 +111,8 @@ _SIGNATURES = {
     "s2s_tts_step": [_vp, _vp, _i32, _i32],
     "s2s_tts_read_codes": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "s2s_tts_release": [_vp, _vp, _i32, _i32],
+    "s2s_tts_migrate": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "s2s_tts_read_x": [_vp, _vp, _i32, _i32, _vp],
     "s2s_tts_read_codes_rows": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp],
     "s2s_codec_decode_rows_at": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32],
     "s2s_op_sample_tokens": [_vp, _vp, _i32, _i32, _f32, _i32, _f32, _f32, C.c_uint64, _vp, _i32, _vp],

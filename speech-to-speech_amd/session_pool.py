@@ -102,7 +102,7 @@ class SessionPool:
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
                  tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
-                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1):
+                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1, tts_nursery_slots: int = 0):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -120,6 +120,10 @@ class SessionPool:
         # stream the token loop's 9 000 dependent launches wait behind the encoder's and the frame loop's workgroups - p95 TTFA at 1 100
         # sessions 1 085 ms with two stages vs 848 ms with one.  Default 1 = one stage; the option stays for lighter loads.
         self.stt_stages = max(1, int(stt_stages))
+        # > 0: every session's FIRST chunk runs in a small, eager frame loop of this many slots (an engine replica on its own thread and
+        # stream); the session is then moved (s2s_tts_migrate) into the wide loop, whose rounds are paced by audio lead alone - so the wide
+        # loop's pace no longer sits in anybody's time-to-first-audio.  0: one loop does both (admission wait `tts_admit_wait_s`).
+        self.tts_nursery_slots = max(0, int(tts_nursery_slots))
         self._stt_reps: dict[str, list] = {}          # model -> engines of the pipeline (the pool's engine + replicas)
         self._stt_free: dict[str, "queue.Queue[int]"] = {}
         self._stt_dq: "queue.Queue[Any]" = queue.Queue()
@@ -555,6 +559,8 @@ class SessionPool:
         defaults (inf / 0) every round runs as soon as the previous one has been handed out (eager)."""
         from .tts_continuous import ROW_BUCKETS, ContinuousTTS
 
+        if self.tts_nursery_slots > 0 and hasattr(eng, "migrate_from") and hasattr(eng, "replica"):
+            return self._run_tts_lane_wide(lane, eng, first, ready)
         backlog: list = [first] if first is not None else []
         cb = None
         try:
@@ -647,6 +653,149 @@ class SessionPool:
                 for job in cb.abort() + backlog:
                     job.chunks.put(e)
                 backlog = []
+
+    def _run_tts_lane_wide(self, lane: int, eng: Any, first: Any, ready: threading.Event | None = None) -> None:
+        """A lane as TWO frame loops: a nursery (small engine replica, own thread + stream, eager) that admits the requests and produces every
+        session's first chunk, and this thread's wide loop that adopts the sessions afterwards and runs only when some session's audio lead
+        drops below `tts_lead_s` (tts_continuous.py NurseryTTS / ContinuousTTS.adopt, csrc/tts.cpp s2s_tts_migrate)."""
+        from .tts_continuous import ROW_BUCKETS, ContinuousTTS, NurseryTTS
+
+        state = {"stop": False, "nursery_done": False, "error": None}
+        grad_q: "queue.Queue[Any]" = queue.Queue()
+        cb = nb = None
+        try:
+            cb = ContinuousTTS(eng, chunk_size=self.tts_chunk_size)
+            neng = eng.replica(max_batch=min(self.tts_nursery_slots, int(eng.max_batch)))
+            self._lane_replicas.append(neng)
+            if hasattr(eng, "prepare_admission"):
+                cb.prepare()
+            for r in [r for r in ROW_BUCKETS if r <= cb.cap] or [cb.cap]:
+                eng.step(r, 1)
+            self._sync_current_stream()
+        except BaseException as e:  # noqa: BLE001
+            logger.error("TTS lane %d could not start: %s", lane, e, exc_info=True)
+            if first is not None:
+                first.chunks.put(e)
+            self._lane_live[lane] = 1 << 30
+            if ready is not None:
+                ready.set()
+            return
+        nursery_ready = threading.Event()
+
+        def nursery_loop():
+            nonlocal nb
+            ctx = self._lane_stream_ctx(0)
+            ctx.__enter__()
+            backlog: list = [first] if first is not None else []
+            try:
+                nb = NurseryTTS(neng, chunk_size=self.tts_chunk_size)
+                if hasattr(neng, "prepare_admission"):
+                    neng.prepare_admission()
+                    nb.prepare()
+                for r in [r for r in ROW_BUCKETS if r <= nb.cap] or [nb.cap]:
+                    neng.step(r, 1)
+                self._sync_current_stream()
+            except BaseException as e:  # noqa: BLE001
+                state["error"] = e
+                logger.error("TTS lane %d: the nursery could not start: %s", lane, e, exc_info=True)
+                for job in backlog:
+                    job.chunks.put(e)
+                state["nursery_done"] = True
+                nursery_ready.set()
+                return
+            nursery_ready.set()
+            while True:
+                try:
+                    nb.reclaim()
+                    self._lane_live[lane] = cb.live + nb.live + len(backlog)
+                    if not nb.cohorts and not backlog:
+                        if state["stop"] or self._stopping:
+                            break
+                        try:
+                            it = self._tts_q.get(timeout=0.02)
+                        except queue.Empty:
+                            continue
+                        if it is _STOP:
+                            state["stop"] = True
+                            continue
+                        backlog.append(it)
+                        if self.batch_window_s > 0:
+                            time.sleep(self.batch_window_s)
+                    room = nb.free_slots - len(backlog)
+                    if room > 0 and not state["stop"]:
+                        for it in self._drain(self._tts_q, room):
+                            if it is _STOP:
+                                state["stop"] = True
+                                break
+                            backlog.append(it)
+                    backlog = [r for r in backlog if not r.cancelled.is_set()]
+                    n0 = len(backlog)
+                    t_a = time.perf_counter()
+                    backlog = nb.admit(backlog)
+                    for job, err in nb.rejected:
+                        job.chunks.put(err)
+                    n0 -= len(nb.rejected)
+                    nb.rejected.clear()
+                    if not nb.cohorts:
+                        time.sleep(0.002)            # (every slot is parked, waiting for the wide loop to take its sessions over)
+                        continue
+                    t_r = time.perf_counter()
+                    for job, chunk in nb.step():
+                        if chunk is None or not job.cancelled.is_set():
+                            job.chunks.put(chunk)
+                    for g in nb.take_graduates():
+                        grad_q.put(g)
+                    with self._stats_lock:
+                        self.stats["tts_batches"] += 1 if n0 > len(backlog) else 0
+                        self.stats["tts_requests"] += max(0, n0 - len(backlog))
+                        self.stats["tts_admit_s"] += t_r - t_a
+                        self.stats["tts_nursery_rounds"] = self.stats.get("tts_nursery_rounds", 0) + 1
+                        self.stats["tts_nursery_s"] = self.stats.get("tts_nursery_s", 0.0) + time.perf_counter() - t_r
+                except BaseException as e:  # noqa: BLE001
+                    logger.error("TTS lane %d nursery failed: %s", lane, e, exc_info=True)
+                    for job in nb.abort() + backlog:
+                        job.chunks.put(e)
+                    backlog = []
+            state["nursery_done"] = True
+
+        nt = threading.Thread(target=nursery_loop, name=f"s2s-pool-{self.device}-tts{lane}-nursery", daemon=True)
+        nt.start()
+        nursery_ready.wait(300)
+        if ready is not None:
+            ready.set()
+        pending: list = []
+        while True:
+            try:
+                while True:
+                    try:
+                        pending.append(grad_q.get_nowait())
+                    except queue.Empty:
+                        break
+                if pending and nb is not None:
+                    pending = cb.adopt(pending, nb)
+                if not cb.live:
+                    if state["nursery_done"] and not pending and grad_q.empty():
+                        return
+                    time.sleep(0.002)
+                    continue
+                now = time.perf_counter()
+                if not (state["stop"] or cb.min_lead_s(now) <= self.tts_lead_s):
+                    time.sleep(0.002)                # everybody is far enough ahead of their playback: leave the device to STT and the nursery
+                    continue
+                t_r = time.perf_counter()
+                rows = cb.rows()
+                for job, chunk in cb.step():
+                    if chunk is None or not job.cancelled.is_set():
+                        job.chunks.put(chunk)
+                with self._stats_lock:
+                    self.stats["tts_rounds"] += 1
+                    self.stats["tts_round_s"] += time.perf_counter() - t_r
+                    self.stats["tts_row_rounds"][rows] = self.stats["tts_row_rounds"].get(rows, 0) + 1
+            except BaseException as e:  # noqa: BLE001
+                logger.error("TTS lane %d failed: %s", lane, e, exc_info=True)
+                for job in cb.abort() + [j for g in pending for j in g.jobs]:
+                    job.chunks.put(e)
+                pending = []
 
     def _run_tts_lane(self, lane: int) -> None:
         eng, ctx = None, None

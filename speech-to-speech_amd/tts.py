@@ -332,10 +332,10 @@ class TTSEngine:
         for _ in self.stream([prompt], [f], chunk_size=f, min_frames=f):
             pass
 
-    def replica(self) -> "TTSEngine":
+    def replica(self, max_batch: int | None = None) -> "TTSEngine":
         """A second engine instance on the same GPU that shares this one's weight tensors (no copy) and owns only its KV
-        caches / workspace / decode graphs - one per TTS lane of the session pool."""
-        rep = TTSEngine(self.dims, None, self.dtype, self.max_batch, self.max_prompt, self.max_frames, self.max_codec_frames, None, self.device,
+        caches / workspace / decode graphs - one per TTS lane of the session pool (max_batch: its own slot count, e.g. a small nursery)."""
+        rep = TTSEngine(self.dims, None, self.dtype, int(max_batch or self.max_batch), self.max_prompt, self.max_frames, self.max_codec_frames, None, self.device,
                         engine_tensors=self._weights)
         for which, kw in getattr(self, "_sampling", {}).items():      # lanes sample like the engine they were cloned from
             rep.set_sampling(which, **kw)
@@ -473,6 +473,23 @@ class TTSEngine:
             native.check(self._lib.s2s_codec_decode_rows_at(self._h, native.stream_handle(), native.ptr(codes), int(slot0), B, F, native.ptr(frames_done_rows),
                                                             int(max_frames_done), native.ptr(wav), n), "s2s_codec_decode_rows_at")
         return wav
+
+    def migrate_from(self, src: "TTSEngine", src_slot0: int, dst_slot0: int, n: int, n_pos: int, n_codec_frames: int, x_rows: torch.Tensor | None = None) -> None:
+        """Adopt n live sessions from `src`'s slots [src_slot0, ..) into this engine's slots [dst_slot0, ..) (csrc/tts.cpp s2s_tts_migrate);
+        the current stream must already wait for `src`'s last launch.  x_rows: `src.read_x` snapshot of those slots (float32 [n][t_hidden])."""
+        assert x_rows is None or (x_rows.dtype == torch.float32 and x_rows.is_contiguous() and x_rows.shape == (n, self.dims.t_hidden))
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_migrate(self._h, src._h, native.stream_handle(), int(src_slot0), int(dst_slot0), int(n), int(n_pos),
+                                                   int(n_codec_frames), native.ptr(x_rows)), "s2s_tts_migrate")
+        self._B = max(self._B, dst_slot0 + n)
+        self._keep_mig = x_rows
+
+    def read_x(self, slot0: int, n: int) -> torch.Tensor:
+        """Snapshot of the next talker input rows of the slots [slot0, slot0 + n) (taken before the slots are parked)."""
+        out = torch.empty((n, self.dims.t_hidden), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_read_x(self._h, native.stream_handle(), int(slot0), int(n), native.ptr(out)), "s2s_tts_read_x")
+        return out
 
     def release(self, slot0: int, n: int) -> None:
         with torch.cuda.device(self.device):

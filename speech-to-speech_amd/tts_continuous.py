@@ -34,6 +34,16 @@ import torch
 ROW_BUCKETS = (32, 64, 128, 192, 256, 384, 512)      # frame-loop row counts with a captured graph
 
 
+def _stream_wait(ev) -> None:
+    """Order the current stream behind `ev` (recorded on another lane's stream); host stand-ins without a GPU are waited for directly."""
+    if ev is None:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().wait_event(ev)
+    else:
+        ev.synchronize()
+
+
 @dataclass
 class TTSJob:
     """What the scheduler needs from a request (the pool's _TTSRequest has the same fields)."""
@@ -50,6 +60,19 @@ class _Cohort:
 
     slot0: int
     jobs: list
+
+
+@dataclass
+class _Graduates:
+    """Sessions whose first chunk a NurseryTTS has delivered, waiting to be adopted by the wide loop: a contiguous run of nursery slots."""
+
+    jobs: list
+    slot0: int                      # nursery slots [slot0, slot0 + len(jobs))
+    frames: int                     # frames generated (= decoded) so far
+    n_pos: int                      # talker positions to carry over (longest prompt of the run + frames)
+    t_first: float
+    event: Any                      # recorded on the nursery's stream behind the run's last launch
+    x: Any = None                   # snapshot of the run's next talker input rows (the nursery loop goes on over the parked slots)
 
 
 @dataclass
@@ -291,7 +314,8 @@ class ContinuousTTS:
                 if ended:
                     ended_slots.append(c.slot0 + i)
                 else:
-                    self.rows_live[c.slot0 + i] = _Row(job, c.slot0 + i, n, t_first)
+                    self._continue(job, c.slot0 + i, n, t_first)
+        self._first_chunks_done()
         self.cohorts = []
         # a finished session's slot is free at once (contiguous runs released with one call)
         ended_slots.sort()
@@ -306,6 +330,43 @@ class ContinuousTTS:
             for s in ended_slots[i : j + 1]:
                 self.rows_live.pop(s, None)
             i = j + 1
+
+    def _continue(self, job, slot: int, frames: int, t_first: float) -> None:
+        """A session that goes on after its first chunk: from now on an independent row of this loop (NurseryTTS hands it on instead)."""
+        self.rows_live[slot] = _Row(job, slot, frames, t_first)
+
+    def _first_chunks_done(self) -> None:
+        pass
+
+    # ---- adoption of sessions whose first chunk ran in a nursery loop ---------------------------------
+    def adopt(self, grads: Sequence[_Graduates], nursery: "NurseryTTS") -> list:
+        """Move graduated sessions into free slots of THIS loop (s2s_tts_migrate on this stream, behind the nursery's event); returns what
+        did not fit.  The nursery gets its slots back together with an event that marks the end of the copies."""
+        left = []
+        for g in grads:
+            jobs, src = list(g.jobs), g.slot0
+            waited = False
+            while jobs and self.free:
+                s, k = self._take(len(jobs))
+                if not waited:
+                    _stream_wait(g.event)
+                    waited = True
+                off = src - g.slot0
+                if g.x is not None and getattr(g.x, "is_cuda", False):
+                    g.x.record_stream(torch.cuda.current_stream())      # (allocated on the nursery's stream, read on this one)
+                xs = None if g.x is None else g.x[off : off + k]
+                self.eng.migrate_from(nursery.eng, src, s, k, g.n_pos, g.frames, xs.contiguous() if hasattr(xs, "contiguous") else xs)
+                ev = torch.cuda.Event()
+                ev.record()
+                for i, job in enumerate(jobs[:k]):
+                    self.rows_live[s + i] = _Row(job, s + i, g.frames, g.t_first)
+                nursery.give_back(src, k, ev)
+                jobs, src = jobs[k:], src + k
+                self.stats["admitted"] += k
+            if jobs:
+                left.append(_Graduates(jobs, src, g.frames, g.n_pos, g.t_first, g.event, None if g.x is None else g.x[src - g.slot0 :]))
+        self.stats["max_live"] = max(self.stats["max_live"], self.live)
+        return left
 
     FRAME_S = 0.08                   # one codec frame = 80 ms of audio (12.5 Hz)
     HUNGRY_FRAMES = 32               # a session whose consumer has not reported audible audio yet is served eagerly for this many frames
@@ -338,3 +399,67 @@ class ContinuousTTS:
         self.rows_live = {}
         self.free = [(0, self.cap)]
         return jobs
+
+
+class NurseryTTS(ContinuousTTS):
+    """The small, EAGER frame loop that produces every session's first chunk (time-to-first-audio), on its own engine replica / stream /
+    thread.  Sessions are admitted, run `chunk_size` frames at the smallest row count that holds them, get their first chunk decoded and
+    delivered - and are then handed to the wide, paced ContinuousTTS (`graduates`), which adopts them with s2s_tts_migrate.  A slot is
+    reusable once the wide loop has returned it (`give_back`: the copies out of it have completed)."""
+
+    def __init__(self, engine, chunk_size: int = 8, max_cohorts: int = 8):
+        super().__init__(engine, chunk_size, max_cohorts)
+        self.graduates: list[_Graduates] = []
+        self._run: list[tuple[Any, int, float]] = []          # (job, slot, t_first) of the round being delivered
+        self._returned: list[tuple[int, int, Any]] = []
+        self._ret_lock = threading.Lock()
+
+    @property
+    def live(self) -> int:
+        return sum(len(c.jobs) for c in self.cohorts)
+
+    def give_back(self, slot0: int, n: int, event: Any) -> None:
+        """Called by the adopting loop's thread: slots [slot0, slot0 + n) have been copied out (complete when `event` fires)."""
+        with self._ret_lock:
+            self._returned.append((slot0, n, event))
+
+    def reclaim(self) -> None:
+        """Nursery thread: make returned slots admissible again (their next prefill is ordered behind the copies by the event)."""
+        with self._ret_lock:
+            ret, self._returned = self._returned, []
+        for slot0, n, ev in ret:
+            _stream_wait(ev)
+            self.eng.release(slot0, n)
+            self._give(slot0, n)
+
+    def _continue(self, job, slot: int, frames: int, t_first: float) -> None:
+        self._run.append((job, slot, t_first))
+
+    def _first_chunks_done(self) -> None:
+        """Group the survivors of this round into contiguous slot runs and publish them behind ONE event."""
+        if not self._run:
+            return
+        self._run.sort(key=lambda t: t[1])
+        runs, i = [], 0
+        while i < len(self._run):
+            j = i
+            while j + 1 < len(self._run) and self._run[j + 1][1] == self._run[j][1] + 1:
+                j += 1
+            jobs = [t[0] for t in self._run[i : j + 1]]
+            lens = [int(getattr(getattr(job.prompt, "embeds", None), "shape", (self.eng.max_prompt,))[0]) for job in jobs]
+            s0 = self._run[i][1]
+            # snapshot the next input rows, THEN park the slots: this loop's later rounds step over them (a parked slot keeps its cache rows,
+            # counters, codes and codec state; only its row of x is recomputed by every frame)
+            x = self.eng.read_x(s0, len(jobs)) if hasattr(self.eng, "read_x") else None
+            self.eng.release(s0, len(jobs))
+            runs.append((jobs, s0, min(max(lens), self.eng.max_prompt) + self.chunk, self._run[i][2], x))
+            i = j + 1
+        ev = torch.cuda.Event()
+        ev.record()
+        for jobs, s0, n_pos, t_first, x in runs:
+            self.graduates.append(_Graduates(jobs, s0, self.chunk, n_pos, t_first, ev, x))
+        self._run = []
+
+    def take_graduates(self) -> list:
+        out, self.graduates = self.graduates, []
+        return out

@@ -604,3 +604,84 @@ def test_smart_turn_tick_batcher_serves_concurrent_sessions_with_one_batch():
     an.close()
     with pytest.raises(RuntimeError, match="closed"):
         an.predict(np.zeros(100, np.float32))
+
+
+def test_session_pool_nursery_lane_hands_sessions_to_the_wide_loop(monkeypatch):
+    """SessionPool(tts_nursery_slots > 0) on stub engines: a session's first chunk comes from the small eager loop (the nursery replica), its
+    later chunks from the wide loop after s2s_tts_migrate - with the state the session had RIGHT AFTER its first chunk (the nursery goes on
+    stepping over parked slots); every session gets all its chunks and one end; nursery slots are given back and reused."""
+    import threading
+    import time
+    import types
+
+    import torch
+
+    from speech_to_speech_amd import tts_continuous as TC
+    from speech_to_speech_amd.session_pool import SessionPool
+
+    class Eng(_StubTTSEngine):
+        def __init__(self, name="main", cap=8):
+            super().__init__()
+            self.name, self.max_batch = name, cap
+            self.parked = set()
+
+        def replica(self, max_batch=None):
+            self.nursery = Eng("nursery", max_batch or self.max_batch)
+            return self.nursery
+
+        def step(self, rows, n):
+            time.sleep(0.01)
+            self.log.append(("step", rows, n))
+            for s, st in self.slots.items():
+                if s in self.parked:
+                    st["x"] = "garbage"          # a parked slot's input row is recomputed by later frames
+                    continue
+                lim = st["budget"] if st["eos"] is None else min(st["budget"], st["eos"])
+                st["frames"] = min(st["frames"] + n, lim)
+                st["x"] = ("x", st["utt"], st["frames"])
+
+        def release(self, s0, n):
+            self.log.append(("release", s0, n))
+            for s in range(s0, s0 + n):
+                if s in self.slots and s not in self.parked and self.name == "nursery" and self.slots[s]["frames"] < self.slots[s]["budget"]:
+                    self.parked.add(s)           # first release of a live slot: parked for the hand-over
+                else:
+                    self.parked.discard(s)
+                    self.slots.pop(s, None)
+
+        def read_x(self, s0, n):
+            return [self.slots[s0 + i]["x"] for i in range(n)]
+
+        def migrate_from(self, src, s0, d0, n, n_pos, n_frames, x_rows=None):
+            self.log.append(("migrate", s0, d0, n, n_frames))
+            for i in range(n):
+                st = dict(src.slots[s0 + i])
+                assert x_rows[i] == ("x", st["utt"], st["frames"]), "the snapshot must be the row right after the first chunk"
+                assert d0 + i not in self.slots
+                self.slots[d0 + i] = st
+
+    monkeypatch.setattr(torch.cuda, "Event", _StubEvent)
+    monkeypatch.setattr(TC.ContinuousTTS, "_host", lambda self, key, shape, dtype: torch.empty(tuple(shape), dtype=dtype))
+    eng = Eng("main", 8)
+    pool = SessionPool("cpu-test-nursery", max_batch=8, batch_window_ms=0.0, tts_chunk_size=4, tts_lanes=1, tts_nursery_slots=2, tts_lead_s=float("inf"))
+    pool._engines["tts"] = eng
+    try:
+        prompt = types.SimpleNamespace(eos_at=None)
+        streams = [pool.synthesize(prompt, b)[0] for b in (16, 8, 4, 12, 16)]
+        got = [[] for _ in streams]
+        ths = [threading.Thread(target=lambda i=i: got[i].extend(list(streams[i]))) for i in range(len(streams))]
+        [t.start() for t in ths]
+        [t.join(timeout=30) for t in ths]
+        assert not any(t.is_alive() for t in ths)
+        assert [len(g) for g in got] == [4, 2, 1, 3, 4]                          # every chunk of every budget
+        nur = eng.nursery
+        assert all(k[0] != "admit" for k in eng.log) and sum(k[2] for k in nur.log if k[0] == "admit") == 5      # admission happens in the nursery only
+        migrated = sum(k[3] for k in eng.log if k[0] == "migrate")
+        assert migrated == 4                                                     # the 4-frame reply ended inside its first chunk and never moved
+        assert all(k[1] <= 2 for k in nur.log if k[0] == "step")                 # the nursery's rows stay within its two slots
+        deadline = time.time() + 5
+        while (nur.slots or eng.slots) and time.time() < deadline:
+            time.sleep(0.01)
+        assert not nur.slots and not eng.slots                                   # every slot of both loops was given back
+    finally:
+        pool.shutdown(close_engines=False)

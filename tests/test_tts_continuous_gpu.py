@@ -12,7 +12,7 @@ import torch
 from oracle import qwen3_tts as OT
 from speech_to_speech_amd.synth_weights import Qwen3TTSDims, qwen3_tts_state_dict
 from speech_to_speech_amd.tts import TTSEngine, TTSPrompt
-from speech_to_speech_amd.tts_continuous import ContinuousTTS, TTSJob
+from speech_to_speech_amd.tts_continuous import ContinuousTTS, NurseryTTS, TTSJob
 
 pytestmark = pytest.mark.gpu
 
@@ -202,3 +202,53 @@ def test_bf16_engine_is_consistent_across_row_buckets_and_slots():
     flips = {k: v for k, v in tops.items() if len(v) > 1}
     assert not flips, f"top-1 differs between buckets / from the oracle at clear-margin picks: {flips}"
     eng.close()
+
+
+def test_first_chunk_in_a_nursery_loop_then_migration_is_exact(world):
+    """A session's first chunk from a small eager loop (NurseryTTS on an engine replica), its continuation from the wide loop after
+    s2s_tts_migrate: codes bit-exact vs the oracle run of the session alone, audio equal to its solo stream - although the nursery keeps
+    stepping over the parked slots before they are taken over (later admissions), and the wide loop adopts into a slot range that is not
+    the nursery's."""
+    dims, sd, prompts, budgets, pad, ref_codes = world
+    main = TTSEngine(dims, sd, dtype=torch.float32, max_batch=8, max_prompt=16, max_frames=16, max_codec_frames=8, pad_embed=pad)
+    neng = main.replica(max_batch=4)
+    cb, nb = ContinuousTTS(main, chunk_size=CHUNK), NurseryTTS(neng, chunk_size=CHUNK)
+    cb.record_codes = nb.record_codes = True
+    assert cb._take(3) == (0, 3)                      # the wide loop's slots 0 .. 2 stay out of play: adopted rows land at 3 ..
+    jobs = [TTSJob(TTSPrompt(p.numpy()), b, min_frames=b) for p, b in zip(prompts, budgets)]
+    audio, ended = {}, {}
+    # nursery round 1: sessions 0, 1 get their first chunk and are parked
+    assert nb.admit(jobs[0:2]) == []
+    _collect(nb.step(), audio, ended)
+    g1 = nb.take_graduates()
+    assert sum(len(g.jobs) for g in g1) == 2 and nb.live == 0
+    # nursery round 2 BEFORE the hand-over: sessions 2, 3 run in the other two slots while 0, 1 sit parked (their input rows are recomputed
+    # as garbage by these frames - the snapshot is what gets migrated)
+    assert nb.admit(jobs[2:4]) == []
+    _collect(nb.step(), audio, ended)
+    g2 = nb.take_graduates()
+    assert cb.adopt(g1, nb) == [] and sorted(cb.rows_live) == [3, 4]
+    _collect(cb.step(), audio, ended)                  # wide round: 0, 1 continue
+    assert cb.adopt(g2, nb) == []
+    nb.reclaim()
+    assert nb.free_slots == 4
+    # 5 (budget 3: ends inside its first chunk, never migrates), 4 and 6 through reused nursery slots
+    assert nb.admit(jobs[4:7]) == []
+    _collect(nb.step(), audio, ended)
+    assert ended.get(id(jobs[5]))
+    left = cb.adopt(nb.take_graduates(), nb)
+    while cb.live or left:
+        _collect(cb.step(), audio, ended)
+        left = cb.adopt(left, nb)
+    assert all(ended.get(id(j)) for j in jobs)
+    for i, j in enumerate(jobs):
+        got = np.concatenate(j.codes)[: budgets[i]]
+        assert np.array_equal(got, ref_codes[i]), f"session {i}: codes differ from the oracle run of that session alone"
+    for i, j in enumerate(jobs):
+        solo = [c[0] for c in main.stream([j.prompt], [budgets[i]], chunk_size=CHUNK, min_frames=budgets[i]) if c[0] is not None]
+        a, b = np.concatenate(audio[id(j)]), np.concatenate(solo)
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        d = np.abs(a.astype(int) - b.astype(int))
+        assert d.max() <= 2, f"session {i}: audio differs from its solo stream (max diff {d.max()})"
+    neng.close()
+    main.close()
