@@ -1,16 +1,18 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r4j; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r4m; mkdir -p $O
+timeout 300 python -m pytest tests/test_tts_continuous_gpu.py tests/test_pipeline_gpu.py tests/test_logmel_gpu.py -q -x -s 2>&1 | grep -v amdgpu.ids | tail -12
 run() { tag=$1; shift; timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --probe-only --boundary-seconds 20 "$@" > $O/$tag.json 2> $O/$tag.err; python - <<PY
 import json
 try:
-    d = json.load(open("gpurun_out/r4j/$tag.json"))
+    d = json.load(open("gpurun_out/r4m/$tag.json"))
     for r in d["boundary"]["probes"]:
         p = r["pool"]
         print("$tag", r["sessions"], "done", r["turns_completed"], "/", r["turns_arrived"], "p50", r["p50_ttfa_ms"], "p95", r["p95_ttfa_ms"], "lag", r["max_playback_lag_ms"], "stt", r.get("p50_stt_ms"), r.get("p95_stt_ms"),
-              "stt_b", p["stt_batches"], "busy", p["stt_busy_s"], "tts_rounds", p["tts_rounds"], "round_s", p["tts_round_s"], p["tts_row_rounds"])
+              "stt_b", p["stt_batches"], "busy", p["stt_busy_s"], "tts_rounds", p["tts_rounds"], "round_s", p["tts_round_s"], p["tts_row_rounds"], "nursery", p.get("tts_nursery_rounds"), p.get("tts_nursery_s"))
+    if d["boundary"].get("error"): print("ERR", d["boundary"]["error"])
 except Exception as e:
     print("$tag ERR", e)
 PY
-tail -2 $O/$tag.err | grep -v amdgpu.ids
+tail -3 $O/$tag.err | grep -v amdgpu.ids
 }
-run S2 --probe-sessions 1000,1100 --tts-lead-s 0.5 --tts-admit-wait-s 0.25 --stt-stages 2
-run S1 --probe-sessions 1000,1100 --tts-lead-s 0.5 --tts-admit-wait-s 0.25 --stt-stages 1
+run N64 --probe-sessions 1100,1300 --tts-nursery-slots 64
+run N32 --probe-sessions 1300 --tts-nursery-slots 32 --tts-lead-s 0.4
