@@ -107,13 +107,14 @@ def parse(argv=None):
                     "(at once when the lane is idle or a round is due): rounds are fuller, TTFA grows by at most this")
     ap.add_argument("--probe-only", action="store_true", help="A/B runs: skip the single-session and warm-up probes (use with --probe-sessions and a short timed region)")
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
-    ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
+    ap.add_argument("--stt-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
     ap.add_argument("--tts-lead-s", type=float, default=0.5, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
     ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
     ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
                     "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
-    ap.add_argument("--tts-nursery-slots", type=int, default=0, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
+    ap.add_argument("--tts-nursery-slots", type=int, default=32, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
+    ap.add_argument("--tts-nursery-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the nursery loop")
     ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
@@ -346,7 +347,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0):
+                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0, nursery_priority=0):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -368,7 +369,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
 
     B = int(getattr(stt_engine, "max_batch", tts_engine.max_batch))      # STT batches; the TTS lane's rows are the TTS engine's slots
     pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus, stt_max_batch=stt_max_batch,
-                       tts_admit_wait_s=admit_wait_s, stt_stages=stt_stages, tts_nursery_slots=nursery_slots)
+                       tts_admit_wait_s=admit_wait_s, stt_stages=stt_stages, tts_nursery_slots=nursery_slots, tts_nursery_priority=nursery_priority)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
@@ -788,7 +789,7 @@ def main():
             def probe(n, window=args.boundary_seconds, seed=0):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch,
-                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows), nursery_slots=args.tts_nursery_slots)
+                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows), nursery_slots=args.tts_nursery_slots, nursery_priority=args.tts_nursery_priority)
 
             single = None if args.probe_only else probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
@@ -822,7 +823,10 @@ def main():
             total = sum_over_ranks(mine)         # gloo, host scalar: the sum of the ranks' sustained session counts
             boundary = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, STT batches of up to "
                                 f"{args.stt_max_batch or MB} sessions, {lanes} TTS lane(s) x {TMB} slots, " + ("turn-batches" if args.turn_batches else
-                                f"continuous batching at chunk boundaries, paced: a round runs when a session's audio lead < {args.tts_lead_s:g} s or a request has waited {args.tts_admit_wait_s * 1e3:g} ms")
+                                (f"first chunks in an eager {args.tts_nursery_slots}-slot nursery loop (high-priority stream), continuation after s2s_tts_migrate in the wide loop, whose rounds run when a session's audio lead < {args.tts_lead_s:g} s"
+                                 if args.tts_nursery_slots > 0 else
+                                 f"continuous batching at chunk boundaries, paced: a round runs when a session's audio lead < {args.tts_lead_s:g} s or a request has waited {args.tts_admit_wait_s * 1e3:g} ms")
+                                + (", STT worker on a high-priority stream" if args.stt_priority < 0 else ""))
                                 + f") -> C ABI; uniform-phase staggered turn arrivals, {args.boundary_seconds:g} s window per probe",
                         "ttfa_bound_ms": args.ttfa_bound_ms,
                         "sustained_sessions": None if best is None else total,

@@ -102,7 +102,7 @@ class SessionPool:
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
                  tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
-                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1, tts_nursery_slots: int = 0):
+                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1, tts_nursery_slots: int = 0, tts_nursery_priority: int = 0):
         self.device = device
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
@@ -124,6 +124,7 @@ class SessionPool:
         # stream); the session is then moved (s2s_tts_migrate) into the wide loop, whose rounds are paced by audio lead alone - so the wide
         # loop's pace no longer sits in anybody's time-to-first-audio.  0: one loop does both (admission wait `tts_admit_wait_s`).
         self.tts_nursery_slots = max(0, int(tts_nursery_slots))
+        self.tts_nursery_priority = int(tts_nursery_priority)      # HIP stream priority of the nursery loop (-1 = high: it sits in every session's first audio)
         self._stt_reps: dict[str, list] = {}          # model -> engines of the pipeline (the pool's engine + replicas)
         self._stt_free: dict[str, "queue.Queue[int]"] = {}
         self._stt_dq: "queue.Queue[Any]" = queue.Queue()
@@ -684,7 +685,7 @@ class SessionPool:
 
         def nursery_loop():
             nonlocal nb
-            ctx = self._lane_stream_ctx(0)
+            ctx = self._lane_stream_ctx(self.tts_nursery_priority)
             ctx.__enter__()
             backlog: list = [first] if first is not None else []
             try:
