@@ -584,6 +584,12 @@ class SessionPool:
         stop = False
         while True:
             try:
+                if self._stopping:       # shutdown: live sessions are failed NOW (their engine may be handed to another pool right after)
+                    err = RuntimeError("SessionPool is shut down")
+                    for job in cb.abort() + backlog:
+                        job.chunks.put(err)
+                    self._sync_current_stream()
+                    return
                 self._lane_live[lane] = cb.live + len(backlog)
                 T = self.tts_fill_first
                 lower_full = T <= 0 or all(self._lane_live.get(j, 0) >= T for j in range(lane))
@@ -707,6 +713,12 @@ class SessionPool:
             nursery_ready.set()
             while True:
                 try:
+                    if self._stopping:
+                        err = RuntimeError("SessionPool is shut down")
+                        for job in nb.abort() + backlog:
+                            job.chunks.put(err)
+                        self._sync_current_stream()
+                        break
                     nb.reclaim()
                     self._lane_live[lane] = cb.live + nb.live + len(backlog)
                     if not nb.cohorts and not backlog:
@@ -767,6 +779,18 @@ class SessionPool:
         pending: list = []
         while True:
             try:
+                if self._stopping:
+                    nt.join(timeout=10)
+                    while True:
+                        try:
+                            pending.append(grad_q.get_nowait())
+                        except queue.Empty:
+                            break
+                    err = RuntimeError("SessionPool is shut down")
+                    for job in cb.abort() + [j for g in pending for j in g.jobs]:
+                        job.chunks.put(err)
+                    self._sync_current_stream()
+                    return
                 while True:
                     try:
                         pending.append(grad_q.get_nowait())

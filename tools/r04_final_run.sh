@@ -27,7 +27,7 @@ python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/bench_reduced.json $O/p
 # 4. other workloads
 timeout 200 python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline --max-probes 2 > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 200 python bench.py --workload c1 --steps 5 --warmup 2 --no-cpu-baseline --max-probes 2 > $O/bench_c1.json 2> $O/bench_c1.err
-timeout 200 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 300 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --probe-only --probe-sessions 300 --boundary-seconds 15 > $O/bench_c5.json 2> $O/bench_c5.err
 cp $(find $O/prof_serial -name "*kernel_stats.csv" | head -1) $O/c3_serial_kernel_stats.csv 2>/dev/null
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 python tools/prof_families.py $O/c3_serial_kernel_stats.csv 24 $O/bench_c3_serial.json    # 8 warm-up + 8 timed + 8 (one merged roofline-sample step) turn-batches
