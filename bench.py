@@ -113,7 +113,7 @@ def parse(argv=None):
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
     ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
                     "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
-    ap.add_argument("--tts-nursery-slots", type=int, default=32, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
+    ap.add_argument("--tts-nursery-slots", type=int, default=0, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
     ap.add_argument("--tts-nursery-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the nursery loop")
     ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
     ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
