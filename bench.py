@@ -107,7 +107,7 @@ def parse(argv=None):
                     "(at once when the lane is idle or a round is due): rounds are fuller, TTFA grows by at most this")
     ap.add_argument("--probe-only", action="store_true", help="A/B runs: skip the single-session and warm-up probes (use with --probe-sessions and a short timed region)")
     ap.add_argument("--probe-sessions", default="", help="comma-separated session counts: run exactly these open-loop probes instead of the search")
-    ap.add_argument("--stt-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
+    ap.add_argument("--stt-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the pool's STT worker in the open-loop probe")
     ap.add_argument("--tts-lead-s", type=float, default=0.5, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
     ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
@@ -819,6 +819,21 @@ def main():
                         break
                     held.pop()
                     best = held[-1] if held else None
+                # nothing held (a bistable schedule: see profiles/r04_open_loop_ab.txt): step down from the smallest probe tried, two more attempts,
+                # each with both arrival seeds, so that the line reports a sustained figure rather than falling back to the closed-loop one
+                n_low = min((int(r["sessions"]) for r in tried), default=0)
+                for _ in range(2):
+                    if best is not None or n_low < 16:
+                        break
+                    n_low = int(0.7 * n_low)
+                    pair = [probe(n_low, seed=sd) for sd in (0, 101)]
+                    for rr in pair:
+                        rr["sustained"] = (rr["turns_completed"] >= rr["turns_arrived"] and rr["p95_ttfa_ms"] is not None and rr["p95_ttfa_ms"] <= args.ttfa_bound_ms
+                                           and rr["max_playback_lag_ms"] <= 0.0)
+                        rr["repeat_of"] = n_low
+                    repeats.extend(pair)
+                    if all(rr["sustained"] for rr in pair):
+                        best = pair[0]
             mine = 0 if best is None else int(best["sessions"])
             total = sum_over_ranks(mine)         # gloo, host scalar: the sum of the ranks' sustained session counts
             boundary = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, STT batches of up to "
@@ -905,7 +920,7 @@ def main():
                  f"{turn_audio_s:g} s, uniform phases) whose turns all complete in real time with p95 time-to-first-audio <= {args.ttfa_bound_ms:g} ms, through the handlers "
                  "(`boundary`); `xrt` is the closed-loop throughput of the timed region") if sustained else
                 "concurrent real-time sessions, whole job (= sessions x seconds of turn audio [utterance in + reply out] / wall seconds per turn; closed loop, no open-loop probe ran)",
-        "value_source": "boundary.sustained_sessions" if sustained else "xrt",
+        "value_source": "boundary.sustained_sessions" if sustained else ("xrt (the open-loop search found no sustained session count: see boundary)" if boundary else "xrt"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{wl.upper()}: {stt_name} + {'Qwen3-TTS test-tiny' if wl == 'tiny' else 'Qwen3-TTS-1.7B'} dims (random-init weights at those dims), {B} concurrent "
