@@ -453,7 +453,10 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     arrivals = []
     if n_sessions == 1:       # an idle system: a few turns of one session, spaced far enough apart to never overlap
         lead_in = utt_s if partial_windows else 0.0      # (C5: the utterance itself takes place inside the probe)
-        ramp, arrivals = 0.0, [(lead_in + 0.3 + (4.0 + lead_in) * k, 0) for k in range(max(2, int(window_s // (4.0 + lead_in))))]
+        # (a paced lane streams a reply for its own duration: the next turn starts after it, as a real single user's would)
+        gap = (4.0 if not np.isfinite(lead_s) else max(4.0, n_frames * FRAME_S + 1.0)) + lead_in
+        ramp, arrivals = 0.0, [(lead_in + 0.3 + gap * k, 0) for k in range(max(2, int(window_s // gap)))]
+        window_s = max(window_s, arrivals[-1][0] + 1.0)
     else:
         phases = rng.uniform(0.0, turn_period, n_sessions)
         ramp = min(3.0, turn_period) + (utt_s if partial_windows else 0.0)      # (C5: the first utterances START at t0)
@@ -920,7 +923,7 @@ def main():
                  f"{turn_audio_s:g} s, uniform phases) whose turns all complete in real time with p95 time-to-first-audio <= {args.ttfa_bound_ms:g} ms, through the handlers "
                  "(`boundary`); `xrt` is the closed-loop throughput of the timed region") if sustained else
                 "concurrent real-time sessions, whole job (= sessions x seconds of turn audio [utterance in + reply out] / wall seconds per turn; closed loop, no open-loop probe ran)",
-        "value_source": "boundary.sustained_sessions" if sustained else ("xrt (the open-loop search found no sustained session count: see boundary)" if boundary else "xrt"),
+        "value_source": "boundary.sustained_sessions" if sustained else ("xrt (the open-loop search found no sustained session count: see boundary)" if (boundary or {}).get("probes") else "xrt"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{wl.upper()}: {stt_name} + {'Qwen3-TTS test-tiny' if wl == 'tiny' else 'Qwen3-TTS-1.7B'} dims (random-init weights at those dims), {B} concurrent "
