@@ -16,6 +16,8 @@ class MI355XWhisperSTTHandlerArguments:
     stt_torch_dtype: str = field(default="bfloat16", metadata={"help": "bfloat16 (serving) or float32 (exact-f32 parity policy)."})
     stt_max_batch: int = field(default=128, metadata={"help": "Sessions batched per engine pass on one GPU (engine limit 128)."})
     stt_batch_window_ms: float = field(default=4.0, metadata={"help": "How long the pool waits for more sessions before launching a batch."})
+    stt_batch_cap: int = field(default=0, metadata={"help": "Largest final-STT batch the pool forms (0 = the engine's max_batch).  Near saturation a cap of 16-32 bounds "
+                                                            "the batch time and lets a backlog drain (bench.py runs with 32)."})
     language: Optional[str] = field(default="en", metadata={"help": "Target language, or 'auto' for on-device language detection."})
     stt_gen_max_new_tokens: int = field(default=128)
     stt_gen_num_beams: int = field(default=1)
@@ -30,6 +32,7 @@ class MI355XParakeetSTTHandlerArguments:
     parakeet_tdt_compute_type: str = field(default="bfloat16")
     parakeet_tdt_max_batch: int = field(default=128)
     parakeet_tdt_batch_window_ms: float = field(default=4.0)
+    parakeet_tdt_batch_cap: int = field(default=0, metadata={"help": "Largest final-STT batch the pool forms (0 = the engine's max_batch)."})
     parakeet_tdt_max_seconds: float = field(default=30.0)
     language: Optional[str] = field(default="en")
 
@@ -49,6 +52,12 @@ class MI355XQwen3TTSHandlerArguments:
     qwen3_tts_batch_window_ms: float = field(default=4.0)
     qwen3_tts_lanes: int = field(default=3, metadata={"help": "TTS turn-batches in flight per GPU (engine replicas sharing the weights, one HIP stream each)."})
     qwen3_tts_codec_context_frames: int = field(default=25)
+    # pacing of the continuously batched frame loop (session_pool.py): the high-load configuration bench.py measures is
+    #   --qwen3_tts_lanes 1 --qwen3_tts_max_batch 512 --qwen3_tts_lead_s 0.5 --qwen3_tts_admit_wait_ms 250 --stt_batch_cap 32
+    qwen3_tts_lead_s: float = field(default=0.0, metadata={"help": "Continuation rounds run only when a session's delivered audio leads its playback by less than this "
+                                                                 "many seconds (0 = eager: synthesise as fast as the device allows)."})
+    qwen3_tts_admit_wait_ms: float = field(default=0.0, metadata={"help": "With pacing: a new request joins the running frame loop at the next due round or after "
+                                                                        "this wait, whichever comes first (0 = at the next chunk boundary)."})
     # on-device sampler (no counterpart in the reference's arguments: its backend samples internally); folded into gen_kwargs
     qwen3_tts_gen_do_sample: bool = field(default=False, metadata={"help": "Sample codec tokens on the device instead of greedy decoding."})
     qwen3_tts_gen_temperature: float = field(default=0.9)

@@ -126,12 +126,15 @@ def build_parakeet_engine(model_name: str, device: str, compute_type: str, max_b
 class MI355XParakeetSTTHandler(BaseSTTHandler):
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", compute_type: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, max_seconds: float = 30.0, enable_live_transcription: bool = False,
-              live_transcription_update_interval: float = 0.5, gen_kwargs: dict | None = None, pool: SessionPool | None = None, **_ignored: Any) -> None:
+              live_transcription_update_interval: float = 0.5, gen_kwargs: dict | None = None, pool: SessionPool | None = None, batch_cap: int = 0,
+              **_ignored: Any) -> None:
         self.language = language or "en"
         self.enable_live_transcription = enable_live_transcription
         kind, key, _ = parse_model_name(model_name) if pool is None or "parakeet" not in getattr(pool, "_engines", {}) else ("pool", None, None)
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
+        if int(batch_cap) > 0:
+            self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("parakeet", lambda: build_parakeet_engine(model_name, device, compute_type, max_batch, max_seconds))
         self._live_model = PooledParakeetModel(self.pool, self.tokenizer, best_effort=True)
         self._windows: dict[Any, SentenceWindow] = {}

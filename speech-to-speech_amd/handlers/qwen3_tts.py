@@ -135,13 +135,15 @@ class MI355XQwen3TTSHandler(BaseHandler):
               speaker: str | None = None, language: str | None = "auto", instruct: str | None = None, streaming_chunk_size: int = 8,
               max_new_tokens: int = DEFAULT_MAX_NEW_TOKENS, blocksize: int = 512, max_batch: int = 64, batch_window_ms: float = 4.0,
               codec_context_frames: int = 25, lanes: int = 3, cancel_scope: Any = None, speculative_turns: Any = None, gen_kwargs: dict | None = None,
-              pool: SessionPool | None = None, **_ignored: Any) -> None:
+              pool: SessionPool | None = None, lead_s: float = 0.0, admit_wait_ms: float = 0.0, **_ignored: Any) -> None:
         self.should_listen = should_listen          # owned by the reference runtime; never touched here
         self.cancel_scope, self.speculative_turns = cancel_scope, speculative_turns
         self.streaming_chunk_size, self.max_new_tokens, self.blocksize = int(streaming_chunk_size), int(max_new_tokens), int(blocksize)
         self.speaker, self.language, self.instruct = speaker, language, instruct
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms,
                                                   tts_chunk_size=self.streaming_chunk_size, tts_ctx_frames=codec_context_frames, tts_lanes=lanes)
+        if float(lead_s) > 0.0:             # paced frame loop (0 = eager, the pool's default)
+            self.pool.configure(tts_lead_s=float(lead_s), tts_admit_wait_s=float(admit_wait_ms) * 1e-3)
         self.pool.ensure_engine("tts", lambda: build_tts_engine(model_name, device, dtype, max_batch, self.max_new_tokens, codec_context_frames,
                                                                self.streaming_chunk_size))
         eng = self.pool.engine("tts")

@@ -46,13 +46,15 @@ def build_whisper_engine(model_name: str, device: str, torch_dtype: str, max_bat
 class MI355XWhisperSTTHandler(BaseSTTHandler):
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", torch_dtype: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, gen_kwargs: dict | None = None, vocab: WhisperVocab | None = None,
-              pool: SessionPool | None = None, **_ignored: Any) -> None:
+              pool: SessionPool | None = None, batch_cap: int = 0, **_ignored: Any) -> None:
         self.gen_kwargs = dict(gen_kwargs or {})
         self.start_language = language
         self.last_language = language if language != "auto" else None
         kind, key, _ = parse_model_name(model_name) if pool is None or "whisper" not in getattr(pool, "_engines", {}) else ("pool", None, None)
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
+        if int(batch_cap) > 0:
+            self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("whisper", lambda: build_whisper_engine(model_name, device, torch_dtype, max_batch))
         # special-token ids, suppress_tokens and begin_suppress_tokens come from the checkpoint's generation_config.json - what
         # the reference's model.generate() applies (generation_whisper.py:1774-1812); synthetic checkpoints get a vocabulary

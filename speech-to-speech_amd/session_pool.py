@@ -93,6 +93,19 @@ class SessionPool:
                         logger.warning("SessionPool(%s) already exists with %s=%s; ignoring %s=%s from a later handler", device, k, cur, k, v)
             return cls._pools[device]
 
+    def configure(self, *, tts_lead_s: float | None = None, tts_admit_wait_s: float | None = None, stt_max_batch: int | None = None) -> None:
+        """Scheduling knobs a handler may set after the pool exists (the lanes read them every round).  One pool per GPU: a later handler
+        asking for something else is told so, the first explicit setting stands."""
+        for name, val, unset in (("tts_lead_s", tts_lead_s, float("inf")), ("tts_admit_wait_s", tts_admit_wait_s, 0.0), ("stt_max_batch", stt_max_batch, 0)):
+            if val is None:
+                continue
+            val = type(unset)(val)
+            cur = getattr(self, name)
+            if cur == unset or cur == val:
+                setattr(self, name, val)
+            else:
+                logger.warning("SessionPool(%s) already runs with %s=%s; ignoring %s=%s from a later handler", self.device, name, cur, name, val)
+
     @classmethod
     def shutdown_all(cls) -> None:
         with cls._pools_lock:

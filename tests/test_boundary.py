@@ -284,6 +284,11 @@ def test_registry_entries_and_lazy_factories():
     tcfg = names["mi355x-qwen3"].normalize(names["mi355x-qwen3"].config_type(qwen3_tts_gen_do_sample=True, qwen3_tts_gen_top_k=20))
     assert tcfg["gen_kwargs"]["do_sample"] is True and tcfg["gen_kwargs"]["top_k"] == 20 and tcfg["gen_kwargs"]["temperature"] == 0.9
     assert "gen_do_sample" not in tcfg and tcfg["lanes"] == 3
+    # the scheduling knobs bench.py measures with are reachable from the CLI: pacing of the frame loop, the final-STT batch cap
+    assert tcfg["lead_s"] == 0.0 and tcfg["admit_wait_ms"] == 0.0 and cfg["batch_cap"] == 0           # defaults: eager, uncapped
+    hot = names["mi355x-qwen3"].normalize(names["mi355x-qwen3"].config_type(qwen3_tts_lanes=1, qwen3_tts_max_batch=512, qwen3_tts_lead_s=0.5, qwen3_tts_admit_wait_ms=250.0))
+    assert (hot["lanes"], hot["max_batch"], hot["lead_s"], hot["admit_wait_ms"]) == (1, 512, 0.5, 250.0)
+    assert names["mi355x-parakeet"].normalize(names["mi355x-parakeet"].config_type(parakeet_tdt_batch_cap=32))["batch_cap"] == 32
     # importing the registry must not import the handler modules or torch-heavy engines
     for m in [k for k in sys.modules if k.startswith("speech_to_speech_amd.handlers") or k.endswith(".whisper") or k.endswith(".tts")]:
         del sys.modules[m]

@@ -685,3 +685,23 @@ def test_session_pool_nursery_lane_hands_sessions_to_the_wide_loop(monkeypatch):
         assert not nur.slots and not eng.slots                                   # every slot of both loops was given back
     finally:
         pool.shutdown(close_engines=False)
+
+
+def test_pool_configure_first_explicit_setting_stands(caplog):
+    """SessionPool.configure: handlers set the pacing / batch-cap knobs after the pool exists (one pool per GPU, whichever handler is built first
+    creates it); the first explicit value stands and a later, different one is reported, not applied."""
+    from speech_to_speech_amd.session_pool import SessionPool
+
+    pool = SessionPool("cpu-test-configure", max_batch=4, tts_lanes=1)
+    try:
+        assert pool.tts_lead_s == float("inf") and pool.tts_admit_wait_s == 0.0 and pool.stt_max_batch == 0
+        pool.configure(tts_lead_s=0.5, tts_admit_wait_s=0.25)
+        pool.configure(stt_max_batch=32)
+        assert (pool.tts_lead_s, pool.tts_admit_wait_s, pool.stt_max_batch) == (0.5, 0.25, 32)
+        pool.configure(tts_lead_s=0.5, stt_max_batch=None)                 # same value / not given: nothing to report
+        with caplog.at_level("WARNING"):
+            pool.configure(tts_lead_s=2.0, stt_max_batch=16)
+        assert (pool.tts_lead_s, pool.stt_max_batch) == (0.5, 32)
+        assert sum("ignoring" in r.getMessage() for r in caplog.records) == 2
+    finally:
+        pool.shutdown()
