@@ -32,7 +32,7 @@ extern "C" {
 #define S2S_ERR_STATE (-3)
 #define S2S_ERR_UNSUPPORTED (-4)
 
-#define S2S_ABI_VERSION 2 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions */
+#define S2S_ABI_VERSION 3 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots */
 
 /* element types of device buffers */
 #define S2S_F32 0
@@ -260,6 +260,32 @@ int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t B, const in
                                   const uint8_t* prompt_fill_mask_dev, int32_t eos, int32_t max_new_tokens,
                                   int32_t min_steps, int32_t* out_ids_dev, int32_t* out_len_dev,
                                   float* last_logits_dev);
+
+/* Continuous batching of the Whisper token loop (ABI 3).  The reference decodes every request with its own model.generate() call
+ * (STT/whisper_stt_handler.py:243); a pool that batches requests per generate() call makes a transcript wait for the whole batch in
+ * front of it.  Here the rows of ONE running greedy loop are SLOTS: a session's encoder pass writes its cross K|V into a free slot's
+ * rows (s2s_whisper_encode_at, on any stream: the encoder's scratch and the loop's state are disjoint), the session is admitted into
+ * the loop at the next step boundary and leaves at ITS eos / token budget.  Results per session are those of
+ * s2s_whisper_decode_greedy on that session (same kernels, same per-row arithmetic).  An engine runs either this loop or
+ * s2s_whisper_decode_greedy at a time (they share the decoder's self-attention cache and step inputs).
+ *   slots_config: the loop's masks (uint8 [vocab] each, optional) and eos - once, while no slot is live.
+ *   encode_at:    s2s_whisper_encode for B sessions whose cross K|V go to slots slot0 .. slot0 + B - 1.
+ *   slots_admit:  slots slot0 .. slot0 + n - 1 start decoding: prompt_dev int32 [n][P] (P <= 8, -1 = fill with the masked argmax),
+ *                 max_new_dev int32 [n] per-session budgets, max_new_limit >= every budget (checked against max_target on the host).
+ *   slots_step:   n_steps greedy steps over rows 0 .. rows - 1 (one captured graph per row count); idle and finished rows stand still.
+ *   slots_collect: pack_dev int32 [rows][stride], stride = s2s_whisper_slots_pack_stride() = 2 + 8 + max_target:
+ *                 {finished (0 | 1 eos | 2 budget), n_ids, filled prompt tokens [8] (0 = as given), ids [max_target]}; the filled tokens
+ *                 and ids are written for finished rows only.
+ *   slots_release: the slots are idle again (their cache rows are rewritten from position 0 by the next admission). */
+int32_t s2s_whisper_slots_config(void* model, void* stream, const uint8_t* suppress_dev, const uint8_t* begin_suppress_dev,
+                                 const uint8_t* prompt_fill_mask_dev, int32_t eos);
+int32_t s2s_whisper_encode_at(void* model, void* stream, const void* feats_dev, int32_t B, int32_t slot0);
+int32_t s2s_whisper_slots_admit(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* prompt_dev, int32_t P,
+                                const int32_t* max_new_dev, int32_t max_new_limit);
+int32_t s2s_whisper_slots_step(void* model, void* stream, int32_t rows, int32_t n_steps);
+int32_t s2s_whisper_slots_collect(void* model, void* stream, int32_t rows, int32_t* pack_dev);
+int32_t s2s_whisper_slots_release(void* model, void* stream, int32_t slot0, int32_t n);
+int32_t s2s_whisper_slots_pack_stride(void* model);
 
 /* ------------------------------------------------------------------------- *
  * Parakeet-TDT (FastConformer encoder + TDT greedy decode) for one batch of sessions.

@@ -35,6 +35,7 @@ struct Tensor {
 
 constexpr int WH_SS_PARTS = 512;      // pair partials per row of a residual projection (2 x d / 16; 160 at d = 1280)
 constexpr int WH_SS_STRIDE = 128;     // row stride of the partial arrays (= the most sessions of a decode batch)
+constexpr int WH_SLOT_PMAX = 8;       // longest forced decoder prefix of a slot (<sot><lang><task><notimestamps> = 4)
 
 struct Whisper {
     s2s_whisper_config cfg;
@@ -65,6 +66,17 @@ struct Whisper {
     // rows ping-pong between ssA / ssB [WH_SS_PARTS][WH_SS_STRIDE]
     bool ln_fold = false;
     float *ssA = nullptr, *ssB = nullptr;
+    // continuous batching of the token loop (s2s_whisper_slots_*): the rows of ONE running greedy loop are slots which a session enters
+    // after its encoder pass (s2s_whisper_encode_at wrote its cross K|V into the slot's rows) and leaves at its eos / token budget.
+    // Per-slot scalars [max_batch] each: step (index of the token just consumed), P, max_new, active; prompts and model-filled prompt
+    // tokens [max_batch][WH_SLOT_PMAX]; generated ids [max_batch][tmax]; the loop's own masks and eos.  cur_ids / pos / out_len /
+    // finished are the arrays of the batch API: an engine runs in ONE of the two modes at a time.
+    int *slot_step = nullptr, *slot_P = nullptr, *slot_maxnew = nullptr, *slot_active = nullptr, *slot_prompt = nullptr, *slot_fill = nullptr,
+        *slot_out = nullptr;
+    unsigned char* smask = nullptr;     // [3][vocab]: suppress, begin-suppress, prompt-fill
+    int slot_eos = -1;
+    int slots_live = 0;                 // host-side count of admitted, not yet released slots
+    std::map<int, hipGraphExec_t> slot_graphs;
     std::vector<void*> owned;
 };
 
@@ -234,7 +246,7 @@ static int finalize(Whisper* m) {
 
 static inline void* at(void* p, size_t bytes) { return (char*)p + bytes; }
 
-static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
+static int encode(Whisper* m, hipStream_t st, const void* feats, int B, int slot0 = 0) {
     const auto& c = m->cfg;
     const int d = c.d_model, H = c.n_heads, D = d / H, dt = c.dtype, e = m->esz;
     const int M = B * ENC_T;
@@ -287,7 +299,7 @@ static int encode(Whisper* m, hipStream_t st, const void* feats, int B) {
     if ((rc = layernorm(st, m->x, PF(m, "enc.ln_post.g"), PF(m, "enc.ln_post.b"), m->enc_out, M, d, 1e-5f, dt))) return rc;
     // cross-attention K|V of every decoder layer, once per utterance
     for (int l = 0; l < c.dec_layers; ++l) {
-        void* ckv = at(m->cross, (size_t)l * m->max_batch * ENC_T * 2 * d * e);
+        void* ckv = at(m->cross, ((size_t)l * m->max_batch + slot0) * ENC_T * 2 * d * e);      // rows of slots slot0 .. slot0 + B - 1
         if ((rc = gemm(st, m->enc_out, d, P(m, lname("dec", l, "ckv.w")), PF(m, lname("dec", l, "ckv.b")), nullptr, ckv, 2 * d, M, 2 * d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
     }
     return S2S_OK;
@@ -532,6 +544,131 @@ static int step_graph(Whisper* m, int B, bool split_ok, hipGraphExec_t* out) {
     return S2S_OK;
 }
 
+// ---- continuous batching of the token loop ------------------------------------------------------------------------------------
+// End of a step in slot mode, one block per row: as whisper_pick_advance_kernel, but every row reads ITS step / prefix length / budget;
+// rows that are idle, or whose session has finished (eos or budget), stand still (their decoder pass re-writes the same cache row).
+__global__ __launch_bounds__(256) void whisper_slot_pick_kernel(const float* __restrict__ logits, int V, const unsigned char* __restrict__ mask_sup,
+                                                                const unsigned char* __restrict__ mask_begin,
+                                                                const unsigned char* __restrict__ mask_fill, int eos, int tmax, int* step_a,
+                                                                const int* __restrict__ P_a, const int* __restrict__ maxnew_a,
+                                                                const int* __restrict__ active_a, const int* __restrict__ prompt, int* fill,
+                                                                int* cur_ids, int* pos, int* out, int* out_len, int* finished) {
+    const int b = blockIdx.x;
+    if (!active_a[b] || finished[b]) return;      // (block-uniform; read before the barriers of the argmax below)
+    const int step = step_a[b], P = P_a[b], max_new = maxnew_a[b];
+    const bool in_prompt = step + 1 < P;
+    const int picked = block_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup, (!in_prompt && step == P - 1) ? mask_begin : nullptr);
+    if (threadIdx.x != 0) return;
+    int next;
+    if (in_prompt) {
+        next = prompt[b * WH_SLOT_PMAX + step + 1];
+        if (next < 0) {              // placeholder: the (masked) argmax, e.g. the language token; reported back through `fill`
+            next = picked;
+            fill[b * WH_SLOT_PMAX + step + 1] = next;
+        }
+    } else {
+        next = picked;
+        const int n = out_len[b];
+        if (next == eos) {
+            finished[b] = 1;
+        } else {
+            out[(long)b * tmax + n] = next;
+            out_len[b] = n + 1;
+            if (n + 1 >= max_new) finished[b] = 2;      // budget: exactly max_new picks, like the batch loop's P - 1 + max_new steps
+        }
+        if (finished[b]) return;     // the row stands still from here on
+    }
+    cur_ids[b] = next;
+    pos[b] = step + 1;
+    step_a[b] = step + 1;
+}
+
+__global__ void whisper_slot_admit_kernel(int slot0, int n, const int* __restrict__ prompts, int P, const int* __restrict__ maxnew, int* step_a, int* P_a,
+                                          int* maxnew_a, int* active_a, int* prompt, int* fill, int* cur_ids, int* pos, int* out_len, int* finished) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = slot0 + i;
+    for (int k = 0; k < WH_SLOT_PMAX; ++k) {
+        prompt[b * WH_SLOT_PMAX + k] = k < P ? prompts[i * P + k] : 0;
+        fill[b * WH_SLOT_PMAX + k] = 0;
+    }
+    step_a[b] = 0; P_a[b] = P; maxnew_a[b] = maxnew[i]; active_a[b] = 1;
+    cur_ids[b] = prompts[i * P]; pos[b] = 0; out_len[b] = 0; finished[b] = 0;
+}
+
+__global__ void whisper_slot_release_kernel(int slot0, int n, int* active_a, int* finished, int* pos, int* cur_ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    active_a[slot0 + i] = 0; finished[slot0 + i] = 0; pos[slot0 + i] = 0; cur_ids[slot0 + i] = 0;
+}
+
+// rows [0, rows): pack[b] = {finished, out_len, fill[0 .. PMAX), ids[0 .. tmax)} - ids / fill only for rows that have finished
+__global__ __launch_bounds__(256) void whisper_slot_collect_kernel(const int* __restrict__ active_a, const int* __restrict__ finished,
+                                                                   const int* __restrict__ out_len, const int* __restrict__ fill,
+                                                                   const int* __restrict__ out, int tmax, int* pack) {
+    const int b = blockIdx.x, stride = 2 + WH_SLOT_PMAX + tmax;
+    int* row = pack + (long)b * stride;
+    const int fin = active_a[b] ? finished[b] : 0, n = out_len[b];
+    if (threadIdx.x == 0) { row[0] = fin; row[1] = n; }
+    if (!fin) return;
+    for (int k = threadIdx.x; k < WH_SLOT_PMAX; k += blockDim.x) row[2 + k] = fill[b * WH_SLOT_PMAX + k];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) row[2 + WH_SLOT_PMAX + k] = out[(long)b * tmax + k];
+}
+
+static int slot_step_body(Whisper* m, hipStream_t st, int rows, bool split_ok) {
+    int rc = decode_step(m, st, rows, split_ok);
+    if (rc) return rc;
+    const int V = m->cfg.vocab;
+    whisper_slot_pick_kernel<<<rows, 256, 0, st>>>(m->logits, V, m->smask, m->smask + V, m->smask + 2 * (size_t)V, m->slot_eos, m->tmax, m->slot_step,
+                                                   m->slot_P, m->slot_maxnew, m->slot_active, m->slot_prompt, m->slot_fill, m->cur_ids, m->pos, m->slot_out,
+                                                   m->out_len, m->finished);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// one captured step per row count (every per-slot quantity lives in device memory; eos is baked in: slots_config drops the graphs)
+static int slot_graph(Whisper* m, int rows, bool split_ok, hipGraphExec_t* out) {
+    auto it = m->slot_graphs.find(rows);
+    if (it != m->slot_graphs.end()) {
+        *out = it->second;
+        return S2S_OK;
+    }
+    std::lock_guard<std::mutex> capture_lock(capture_mutex());
+    if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    S2S_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = slot_step_body(m, m->cap_stream, rows, split_ok);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    S2S_HIP_CHECK(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2S_HIP_CHECK(ie);
+    m->slot_graphs[rows] = exec;
+    *out = exec;
+    return S2S_OK;
+}
+
+static int slots_alloc(Whisper* m) {
+    if (m->slot_step) return S2S_OK;
+    std::lock_guard<std::mutex> no_capture(capture_mutex());     // (synchronous allocation / memset: never under another thread's capture)
+    const size_t B = m->max_batch, n_int = B * (4 + 2 * WH_SLOT_PMAX + (size_t)m->tmax);
+    int* ib = nullptr;
+    S2S_HIP_CHECK(hipMalloc((void**)&ib, sizeof(int) * n_int));
+    S2S_HIP_CHECK(hipMemset(ib, 0, sizeof(int) * n_int));
+    m->owned.push_back(ib);
+    m->slot_step = ib; m->slot_P = ib + B; m->slot_maxnew = ib + 2 * B; m->slot_active = ib + 3 * B;
+    m->slot_prompt = ib + 4 * B; m->slot_fill = m->slot_prompt + B * WH_SLOT_PMAX; m->slot_out = m->slot_fill + B * WH_SLOT_PMAX;
+    S2S_HIP_CHECK(hipMalloc((void**)&m->smask, 3 * (size_t)m->cfg.vocab));
+    S2S_HIP_CHECK(hipMemset(m->smask, 0, 3 * (size_t)m->cfg.vocab));
+    m->owned.push_back(m->smask);
+    return S2S_OK;
+}
+
 }  // namespace s2s
 
 using namespace s2s;
@@ -557,6 +694,7 @@ extern "C" int32_t s2s_whisper_destroy(void* model) {
     if (m->step_dev) (void)hipFree(m->step_dev);
     if (m->mask_sup) (void)hipFree(m->mask_sup);
     for (auto& kv : m->step_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : m->slot_graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : m->owned) (void)hipFree(p);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
@@ -609,6 +747,7 @@ extern "C" int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t 
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m && m->finalized, "whisper_decode: model not finalized");
     S2S_REQUIRE(B > 0 && B <= m->max_batch && prompt_dev && P >= 1 && out_ids_dev && out_len_dev, "whisper_decode: bad arguments");
+    S2S_REQUIRE(m->slots_live == 0, "whisper_decode: %d slot(s) of the continuous token loop are live on this engine (one mode at a time)", m->slots_live);
     S2S_REQUIRE(max_new_tokens >= 1 && P + max_new_tokens <= m->tmax, "whisper_decode: P + max_new_tokens = %d exceeds %d target positions", P + max_new_tokens, m->tmax);
     hipStream_t st = (hipStream_t)stream;
     const auto& c = m->cfg;
@@ -659,4 +798,95 @@ extern "C" int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t 
     S2S_HIP_CHECK(hipMemcpyAsync(out_ids_dev, m->out_ids, sizeof(int) * (size_t)B * row, hipMemcpyDeviceToDevice, st));
     S2S_HIP_CHECK(hipMemcpyAsync(out_len_dev, m->out_len, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
     return S2S_OK;
+}
+
+// ---- continuous batching of the token loop (see include/s2s_mi355x.h) ---------------------------------------------------------------
+extern "C" int32_t s2s_whisper_slots_config(void* model, void* stream, const uint8_t* suppress_dev, const uint8_t* begin_suppress_dev,
+                                            const uint8_t* prompt_fill_mask_dev, int32_t eos) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized, "whisper_slots_config: model not finalized");
+    S2S_REQUIRE(m->slots_live == 0, "whisper_slots_config: %d slot(s) are live", m->slots_live);
+    S2S_REQUIRE(eos >= 0 && eos < m->cfg.vocab, "whisper_slots_config: eos %d outside the vocabulary", eos);
+    int rc = slots_alloc(m);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = m->cfg.vocab;
+    auto set_mask = [&](unsigned char* dst, const uint8_t* src) -> hipError_t {
+        return src ? hipMemcpyAsync(dst, src, V, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, V, st);
+    };
+    S2S_HIP_CHECK(set_mask(m->smask, suppress_dev));
+    S2S_HIP_CHECK(set_mask(m->smask + V, begin_suppress_dev));
+    S2S_HIP_CHECK(set_mask(m->smask + 2 * V, prompt_fill_mask_dev));
+    if (eos != m->slot_eos) {       // eos is a kernel argument of the captured step: new graphs
+        for (auto& kv : m->slot_graphs) (void)hipGraphExecDestroy(kv.second);
+        m->slot_graphs.clear();
+        m->slot_eos = eos;
+    }
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_encode_at(void* model, void* stream, const void* feats_dev, int32_t B, int32_t slot0) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized, "whisper_encode_at: model not finalized");
+    S2S_REQUIRE(B > 0 && slot0 >= 0 && slot0 + B <= m->max_batch && feats_dev, "whisper_encode_at: slots %d .. %d outside 0 .. %d", slot0, slot0 + B, m->max_batch);
+    return encode(m, (hipStream_t)stream, feats_dev, B, slot0);
+}
+
+extern "C" int32_t s2s_whisper_slots_admit(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* prompt_dev, int32_t P,
+                                           const int32_t* max_new_dev, int32_t max_new_limit) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized && m->slot_step && m->slot_eos >= 0, "whisper_slots_admit: call s2s_whisper_slots_config first");
+    S2S_REQUIRE(n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch && prompt_dev && max_new_dev, "whisper_slots_admit: bad arguments");
+    S2S_REQUIRE(P >= 1 && P <= WH_SLOT_PMAX, "whisper_slots_admit: prefix of %d tokens (1 .. %d)", P, WH_SLOT_PMAX);
+    S2S_REQUIRE(max_new_limit >= 1 && P + max_new_limit <= m->tmax, "whisper_slots_admit: P + max_new_tokens = %d exceeds %d target positions", P + max_new_limit, m->tmax);
+    whisper_slot_admit_kernel<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(slot0, n, prompt_dev, P, max_new_dev, m->slot_step, m->slot_P, m->slot_maxnew, m->slot_active,
+                                                                         m->slot_prompt, m->slot_fill, m->cur_ids, m->pos, m->out_len, m->finished);
+    S2S_LAUNCH_CHECK();
+    m->slots_live += n;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_slots_step(void* model, void* stream, int32_t rows, int32_t n_steps) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized && m->slot_step && m->slot_eos >= 0, "whisper_slots_step: call s2s_whisper_slots_config first");
+    S2S_REQUIRE(rows > 0 && rows <= m->max_batch && n_steps >= 1, "whisper_slots_step: bad arguments (rows %d, steps %d)", rows, n_steps);
+    hipStream_t st = (hipStream_t)stream;
+    const bool split_ok = m->cfg.dtype == S2S_BF16;
+    hipGraphExec_t exec = nullptr;
+    bool graph_ok = graphs_enabled() && !prof_active();
+    if (graph_ok && slot_graph(m, rows, split_ok, &exec) != S2S_OK) {
+        (void)hipGetLastError();
+        graph_ok = false;
+    }
+    for (int s = 0; s < n_steps; ++s) {
+        if (graph_ok) {
+            S2S_HIP_CHECK(hipGraphLaunch(exec, st));
+        } else {
+            const int rc = slot_step_body(m, st, rows, split_ok);
+            if (rc) return rc;
+        }
+    }
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_slots_collect(void* model, void* stream, int32_t rows, int32_t* pack_dev) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized && m->slot_step && pack_dev && rows > 0 && rows <= m->max_batch, "whisper_slots_collect: bad arguments");
+    whisper_slot_collect_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(m->slot_active, m->finished, m->out_len, m->slot_fill, m->slot_out, m->tmax, pack_dev);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_slots_release(void* model, void* stream, int32_t slot0, int32_t n) {
+    Whisper* m = (Whisper*)model;
+    S2S_REQUIRE(m && m->finalized && m->slot_step && n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch, "whisper_slots_release: bad arguments");
+    whisper_slot_release_kernel<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(slot0, n, m->slot_active, m->finished, m->pos, m->cur_ids);
+    S2S_LAUNCH_CHECK();
+    m->slots_live = m->slots_live > n ? m->slots_live - n : 0;
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_whisper_slots_pack_stride(void* model) {
+    Whisper* m = (Whisper*)model;
+    return m && m->finalized ? 2 + WH_SLOT_PMAX + m->tmax : 0;
 }

@@ -126,6 +126,13 @@ _SIGNATURES = {
     "s2s_resample_24k16k_int16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_resample_poly_int16": [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32],
     "s2s_whisper_decode_greedy": [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "s2s_whisper_slots_config": [_vp, _vp, _vp, _vp, _vp, _i32],
+    "s2s_whisper_encode_at": [_vp, _vp, _vp, _i32, _i32],
+    "s2s_whisper_slots_admit": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32],
+    "s2s_whisper_slots_step": [_vp, _vp, _i32, _i32],
+    "s2s_whisper_slots_collect": [_vp, _vp, _i32, _vp],
+    "s2s_whisper_slots_release": [_vp, _vp, _i32, _i32],
+    "s2s_whisper_slots_pack_stride": [_vp],
 }
 # development / measurement hooks (include/s2s_mi355x_dev.h): bench.py's kernel timers, tools/, the parity sweeps of tests/
 _DEV_SIGNATURES = {

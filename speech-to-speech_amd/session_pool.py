@@ -115,8 +115,16 @@ class SessionPool:
 
     def __init__(self, device: str, max_batch: int = 64, batch_window_ms: float = 4.0, tts_chunk_size: int = 8, tts_ctx_frames: int = 25,
                  tts_lanes: int = 3, continuous: bool = True, stt_priority: int = 0, stt_workers: int = 1, tts_lead_s: float = float("inf"), tts_fill_first: int = 0, tts_lane_cus: int = 8, stt_max_batch: int = 0,
-                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1, tts_nursery_slots: int = 0, tts_nursery_priority: int = 0):
+                 tts_admit_wait_s: float = 0.0, stt_stages: int = 1, tts_nursery_slots: int = 0, tts_nursery_priority: int = 0, stt_slots: int = 0,
+                 stt_slot_steps: int = 4):
         self.device = device
+        # > 0: engines that offer it (Whisper: slots_step, stt_continuous.py) run their token loop continuously - requests join after their
+        # encoder pass (second stream) and leave at their own eos instead of being served batch by batch.  Written at the end of round 4
+        # without GPU time left to measure it: off by default.
+        self.stt_slots = max(0, int(stt_slots))
+        self.stt_slot_steps = max(1, int(stt_slot_steps))
+        self._stt_sq: dict[str, "queue.Queue[Any]"] = {}
+        self._stt_sthreads: dict[str, threading.Thread] = {}
         self.stt_priority = int(stt_priority)    # HIP stream priority of the STT worker (-1 = high: STT sits in front of every session's first audio)
         # optional pacing of the continuous lanes: a round of continuation chunks runs only when some session's delivered audio leads its
         # playback by less than this (a round with a NEW cohort - time-to-first-audio - always runs at once).  Default inf = eager rounds:
@@ -283,8 +291,12 @@ class SessionPool:
             self._tts_q.put(_STOP)
         self._wake.set()
         self._thread.join(timeout=10)
-        for t in self._stt_extra + self._lanes + ([self._stt_dthread] if self._stt_dthread is not None else []):
+        for t in self._stt_extra + self._lanes + ([self._stt_dthread] if self._stt_dthread is not None else []) + list(self._stt_sthreads.values()):
             t.join(timeout=10)
+        for sq in self._stt_sq.values():
+            for it in self._drain(sq, 1 << 20):
+                if isinstance(it, _STTRequest) and not it.future.done():
+                    it.future.set_exception(RuntimeError("SessionPool is shut down"))
         while True:
             try:
                 item = self._stt_dq.get_nowait()
@@ -356,6 +368,9 @@ class SessionPool:
                     reqs.append(it)
             for model in sorted({r.model for r in reqs}):
                 mine = [r for r in reqs if r.model == model]
+                if self.stt_slots > 0 and hasattr(self._engines.get(model), "slots_step"):
+                    self._stt_slots_submit(mine, model)
+                    continue
                 if self.stt_stages > 1 and model not in self._stt_reps:
                     self._stt_pipeline_build(model)      # (an engine registered directly, e.g. by bench.py: first use)
                 if self._stt_reps.get(model):
@@ -364,6 +379,88 @@ class SessionPool:
                     self._run_stt(mine, model)
             if self._stopping and self._stt_q.empty():
                 return
+
+    # ---- continuous token loop (slots) ------------------------------------------------------------
+    def _stt_slots_submit(self, reqs: list[_STTRequest], model: str) -> None:
+        if model not in self._stt_sq:
+            self._stt_sq[model] = queue.Queue()
+            t = threading.Thread(target=self._run_stt_slots, args=(model,), name=f"s2s-pool-{self.device}-sttloop-{model}", daemon=True)
+            self._stt_sthreads[model] = t
+            t.start()
+        for r in reqs:
+            self._stt_sq[model].put(r)
+
+    def _run_stt_slots(self, model: str) -> None:
+        """The running token loop of one STT engine (own thread, its stream for the loop + a side stream for the encoder passes)."""
+        from .stt_continuous import ContinuousSTT
+
+        ctx = self._lane_stream_ctx(self.stt_priority)
+        ctx.__enter__()
+        eng = self._engines[model]
+        hooks: dict[str, Any] = {}
+        try:
+            import torch
+
+            dev = torch.device(self.device)
+            if dev.type == "cuda" and torch.cuda.is_available():
+                side = torch.cuda.Stream(device=dev, priority=self.stt_priority)
+
+                def make_event():
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    return ev
+
+                hooks = {"enc_stream": lambda: torch.cuda.stream(side), "make_event": make_event,
+                         "wait_event": lambda ev: torch.cuda.current_stream().wait_event(ev)}
+        except Exception:  # noqa: BLE001
+            hooks = {}
+        cs = ContinuousSTT(eng, steps_per_round=self.stt_slot_steps, max_group=self.stt_max_batch or 16, **hooks)
+        q = self._stt_sq[model]
+        backlog: list[_STTRequest] = []
+        t_busy = None
+        while True:
+            try:
+                if cs.idle and not backlog:
+                    if t_busy is not None:
+                        with self._stats_lock:
+                            self.stats["stt_busy_s"] += time.perf_counter() - t_busy
+                        t_busy = None
+                    try:
+                        backlog.append(q.get(timeout=0.05))
+                    except queue.Empty:
+                        if self._stopping:
+                            return
+                        continue
+                    if self.batch_window_s > 0:
+                        time.sleep(self.batch_window_s)
+                    t_busy = time.perf_counter()
+                backlog += self._drain(q, 1 << 20)
+                if self._stopping:
+                    raise RuntimeError("SessionPool is shut down")
+                if backlog and cs.can_encode():
+                    take, rest = backlog[: cs.max_group], backlog[cs.max_group :]
+                    left = cs.encode(take)
+                    for j, err in cs.rejected:
+                        if not j.future.done():
+                            j.future.set_exception(err)
+                    n_in = len(take) - len(left) - len(cs.rejected)
+                    if n_in > 0:
+                        with self._stats_lock:
+                            self.stats["stt_batches"] += 1
+                            self.stats["stt_requests"] += n_in
+                            self.stats["max_stt_batch"] = max(self.stats["max_stt_batch"], n_in)
+                    backlog = left + rest
+                for job, res in cs.step():
+                    job.future.set_result(res)
+            except BaseException as e:  # noqa: BLE001
+                if not self._stopping:
+                    logger.error("%s token loop failed: %s", model, e, exc_info=True)
+                for j in cs.abort() + backlog:
+                    if not j.future.done():
+                        j.future.set_exception(e)
+                backlog = []
+                if self._stopping:
+                    return
 
     # ---- two-stage STT ---------------------------------------------------------------------------
     def _stt_pipeline_build(self, model: str) -> None:

@@ -276,6 +276,66 @@ class WhisperEngine:
             out.append({"ids": ids[i][:n], "language": vocab.id_to_lang(filled[i][1]) if vocab.multilingual else "en"})
         return out
 
+    # ---- continuous batching of the token loop (csrc/whisper.cpp s2s_whisper_slots_*; scheduler: stt_continuous.py) ----------------
+    SLOT_PMAX = 8
+
+    def slots_config(self, vocab) -> None:
+        """The running loop's vocabulary: suppress / begin-suppress / language-fill masks and eos (once, while no slot is live)."""
+        vocab.validate(self.dims.vocab)
+        sup, bsup = self._mask(vocab.suppress), self._mask(vocab.begin_suppress)
+        fill = self._mask(list(vocab.lang_to_id.values()) or None, invert=True)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_slots_config(self._h, native.stream_handle(), native.ptr(sup), native.ptr(bsup), native.ptr(fill),
+                                                            int(vocab.eot)), "s2s_whisper_slots_config")
+        self._slot_vocab = vocab
+        self._slot_stride = int(self._lib.s2s_whisper_slots_pack_stride(self._h))
+        if getattr(self, "_slot_pack", None) is None:
+            self._slot_pack = torch.zeros((self.max_batch, self._slot_stride), dtype=torch.int32, device=self.device)
+            self._slot_pack_host = torch.zeros((self.max_batch, self._slot_stride), dtype=torch.int32, pin_memory=True)
+
+    def slots_encode(self, audios: Sequence[np.ndarray], slot0: int) -> torch.Tensor:
+        """Log-mel + encoder of len(audios) sessions on the CURRENT stream; their cross K|V land in slots slot0 ...  Returns the feature
+        tensor (keep it referenced until the stream has passed this point)."""
+        feats = self.features(audios)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_encode_at(self._h, native.stream_handle(), native.ptr(feats), len(audios), int(slot0)), "s2s_whisper_encode_at")
+        return feats
+
+    def slots_admit(self, slot0: int, prompts: Sequence[Sequence[int]], max_new: Sequence[int]) -> None:
+        n, P = len(prompts), len(prompts[0])
+        assert all(len(p) == P for p in prompts) and len(max_new) == n and 1 <= P <= self.SLOT_PMAX
+        pr = torch.tensor(prompts, dtype=torch.int32).to(self.device, non_blocking=True)
+        mn = torch.tensor([int(v) for v in max_new], dtype=torch.int32).to(self.device, non_blocking=True)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_slots_admit(self._h, native.stream_handle(), int(slot0), n, native.ptr(pr), P, native.ptr(mn),
+                                                           int(max(max_new))), "s2s_whisper_slots_admit")
+        self._slot_keep = (pr, mn)          # (alive until the next admission: the kernel has long read them by then)
+
+    def slots_step(self, rows: int, n_steps: int) -> None:
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_slots_step(self._h, native.stream_handle(), int(rows), int(n_steps)), "s2s_whisper_slots_step")
+
+    def slots_collect(self, rows: int) -> np.ndarray:
+        """-> int32 [rows][2 + 8 + max_target] on the host (synchronises the current stream): finished flag (0 | 1 eos | 2 budget), number of
+        ids, the prompt tokens the model filled in, the ids - the last two valid for finished rows."""
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_slots_collect(self._h, native.stream_handle(), int(rows), native.ptr(self._slot_pack)), "s2s_whisper_slots_collect")
+            self._slot_pack_host[:rows].copy_(self._slot_pack[:rows], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return self._slot_pack_host[:rows].numpy()
+
+    def slots_release(self, slot0: int, n: int) -> None:
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_whisper_slots_release(self._h, native.stream_handle(), int(slot0), int(n)), "s2s_whisper_slots_release")
+
+    def slot_result(self, row: np.ndarray, prompt: Sequence[int], max_new: int) -> dict:
+        """One finished row of `slots_collect` -> the dict `transcribe_batch` returns for that request."""
+        vocab = self._slot_vocab
+        n = int(row[1])
+        ids = row[2 + self.SLOT_PMAX : 2 + self.SLOT_PMAX + n].tolist()[: int(max_new)]
+        filled = [int(row[2 + i]) if prompt[i] < 0 else int(prompt[i]) for i in range(len(prompt))]
+        return {"ids": ids, "language": vocab.id_to_lang(filled[1]) if vocab.multilingual else "en"}
+
     def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
         """SessionPool entry point: one dict per request {"ids": [...], "language": code | None}.
         options per request: language (code | "auto" | None), max_new_tokens, vocab (text.WhisperVocab)."""

@@ -705,3 +705,156 @@ def test_pool_configure_first_explicit_setting_stands(caplog):
         assert sum("ignoring" in r.getMessage() for r in caplog.records) == 2
     finally:
         pool.shutdown()
+
+
+class _StubSlotWhisper:
+    """Host double of WhisperEngine's slot API (speech-to-speech_amd/whisper.py slots_*): a session 'decodes' the token ids
+    100 * tag + k, k = 0 .. n - 1 (tag and n ride in its audio array), one per step after its P - 1 prompt steps; eos after n."""
+
+    def __init__(self, max_batch=8, max_target=64):
+        from types import SimpleNamespace
+
+        self.max_batch, self.dims = max_batch, SimpleNamespace(max_target=max_target, vocab=1000)
+        self.slots = {}                  # slot -> dict(tag, n, P, max_new, step, ids, fin, active)
+        self.encoded = {}                # slot -> (tag, n): cross K|V written, not admitted yet
+        self.calls, self.configured = [], None
+
+    def slots_config(self, vocab):
+        assert not self.slots
+        self.configured = vocab
+
+    def slots_encode(self, audios, slot0):
+        self.calls.append(("encode", slot0, len(audios)))
+        for i, a in enumerate(audios):
+            assert slot0 + i not in self.slots, "encoder pass into a live slot"
+            self.encoded[slot0 + i] = (int(a[0]), int(a[1]))
+        return object()
+
+    def slots_admit(self, slot0, prompts, max_new):
+        self.calls.append(("admit", slot0, len(prompts)))
+        for i, (p, m) in enumerate(zip(prompts, max_new)):
+            tag, n = self.encoded.pop(slot0 + i)
+            self.slots[slot0 + i] = dict(tag=tag, n=n, P=len(p), max_new=m, step=0, ids=[], fin=0, prompt=list(p))
+
+    def slots_step(self, rows, n_steps):
+        self.calls.append(("step", rows, n_steps))
+        assert all(s < rows for s in self.slots), "a live slot outside the row bucket"
+        for _ in range(n_steps):
+            for s in self.slots.values():
+                if s["fin"]:
+                    continue
+                if s["step"] + 1 >= s["P"]:              # a generated pick
+                    k = len(s["ids"])
+                    if k >= s["n"]:
+                        s["fin"] = 1
+                        continue
+                    s["ids"].append(100 * s["tag"] + k)
+                    if k + 1 >= s["max_new"]:
+                        s["fin"] = 2
+                        continue
+                s["step"] += 1
+
+    def slots_collect(self, rows):
+        pack = np.zeros((rows, 2 + 8 + self.dims.max_target), dtype=np.int32)
+        for slot, s in self.slots.items():
+            pack[slot, 0], pack[slot, 1] = s["fin"], len(s["ids"])
+            if s["fin"]:
+                pack[slot, 3] = 7 if s["prompt"][1] < 0 else 0          # the 'detected language' of a placeholder prompt
+                pack[slot, 10 : 10 + len(s["ids"])] = s["ids"]
+        return pack
+
+    def slots_release(self, slot0, n):
+        self.calls.append(("release", slot0, n))
+        for s in range(slot0, slot0 + n):
+            self.slots.pop(s, None)
+
+    def slot_result(self, row, prompt, max_new):
+        n = int(row[1])
+        return {"ids": row[10 : 10 + n].tolist()[:max_new], "language": "xx" if prompt[1] < 0 and row[3] == 7 else "en"}
+
+
+class _StubVocabW:
+    eot = 999
+
+    def prompt(self, language, task="transcribe"):
+        return [1, -1 if language in (None, "auto") else 2, 3, 4]
+
+    def __eq__(self, other):
+        return isinstance(other, _StubVocabW)
+
+
+def _slot_job(tag, n, **opt):
+    from types import SimpleNamespace
+
+    return SimpleNamespace(audio=np.array([tag, n], dtype=np.float32), options={"vocab": _StubVocabW(), "language": "en", "max_new_tokens": 16, **opt}, tag=tag)
+
+
+def test_continuous_stt_sessions_join_after_their_encoder_pass_and_leave_at_their_own_eos():
+    """stt_continuous.ContinuousSTT on a stub engine: slots are taken lowest-first, ONE encoder group is in flight at a time and joins the
+    loop only once its event has completed, every session gets ITS ids whatever shared the loop, finishes at its own length (eos or budget),
+    its slot is reused, and requests the loop cannot serve fail alone."""
+    from speech_to_speech_amd.stt_continuous import ContinuousSTT
+
+    eng = _StubSlotWhisper(max_batch=8)
+    ready = {"flag": False}
+
+    class Ev:
+        def query(self):
+            return ready["flag"]
+
+    waited = []
+    cs = ContinuousSTT(eng, steps_per_round=2, max_group=3, make_event=Ev, wait_event=waited.append)
+    jobs = [_slot_job(1, 5), _slot_job(2, 1), _slot_job(3, 9, max_new_tokens=4), _slot_job(4, 2)]
+    left = cs.encode(jobs)                                   # group cap 3: the fourth job comes back
+    assert [j.tag for j in left] == [4] and eng.calls == [("encode", 0, 3)] and not cs.can_encode()
+    cs.step()                                                # nothing live yet: the round waits for the group's event (wait_event) and admits it
+    assert eng.calls[1] == ("admit", 0, 3) and len(waited) == 1 and cs.live == 3
+    # second group while the first decodes: its encoder event is NOT complete, so it stays outside the loop
+    ready["flag"] = False
+    assert cs.can_encode() and cs.encode(left + [_slot_job(5, 3, language="auto"), _slot_job(6, 1, max_new_tokens=100)]) == []
+    assert ("encode", 3, 2) in eng.calls and cs.rejected and cs.rejected[0][0].tag == 6       # 4 + 100 > 64 target positions: fails alone
+    out = {}
+    for _ in range(3):
+        for j, res in cs.step():
+            out[j.tag] = res
+    assert cs.group is not None and 4 not in eng.slots       # still waiting outside
+    assert out[2] == {"ids": [200], "language": "en"} and out[3] == {"ids": [300, 301, 302, 303], "language": "en"}      # eos after 1; budget 4 of 9
+    ready["flag"] = True
+    for _ in range(8):
+        for j, res in cs.step():
+            out[j.tag] = res
+    assert out[1]["ids"] == [100, 101, 102, 103, 104] and out[4]["ids"] == [400, 401] and out[5] == {"ids": [500, 501, 502], "language": "xx"}
+    assert cs.idle and cs.free == [(0, 8)] and not eng.slots
+    assert all(c[1] <= 8 for c in eng.calls if c[0] == "step") and cs.stats["admitted"] == 5 and cs.stats["groups"] == 2
+    # a request with another vocabulary is refused while the loop serves this one
+    other = _slot_job(7, 1)
+    other.options["vocab"] = object()
+    assert cs.encode([other]) == [] and cs.rejected[0][0] is other and cs.group is None
+
+
+def test_session_pool_serves_whisper_finals_through_the_slot_loop():
+    """SessionPool(stt_slots > 0): finals of concurrent handler threads go through the running token loop; each gets its own result and the
+    pool shuts down cleanly with the loop idle."""
+    import threading
+
+    from speech_to_speech_amd.session_pool import SessionPool
+
+    eng = _StubSlotWhisper(max_batch=8)
+    eng.close = lambda: None
+    pool = SessionPool("cpu-test-stt-slots", max_batch=8, batch_window_ms=1.0, tts_lanes=1, stt_slots=8, stt_slot_steps=2, stt_max_batch=4)
+    pool._engines["whisper"] = eng
+    res = {}
+
+    def one(tag, n):
+        res[tag] = pool.transcribe("whisper", np.array([tag, n], dtype=np.float32), vocab=_StubVocabW(), language="en", max_new_tokens=16)
+
+    try:
+        ts = [threading.Thread(target=one, args=(t, 1 + t % 5)) for t in range(1, 11)]
+        [t.start() for t in ts]
+        [t.join(timeout=30) for t in ts]
+        assert all(not t.is_alive() for t in ts)
+        for t in range(1, 11):
+            assert res[t]["ids"] == [100 * t + k for k in range(1 + t % 5)]
+        assert pool.stats["stt_requests"] == 10 and pool.stats["max_stt_batch"] <= 4
+    finally:
+        pool.shutdown()
