@@ -729,6 +729,7 @@ extern "C" int32_t s2s_whisper_encode(void* model, void* stream, const void* fea
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m && m->finalized, "whisper_encode: model not finalized");
     S2S_REQUIRE(B > 0 && B <= m->max_batch && feats_dev, "whisper_encode: bad batch %d", B);
+    S2S_REQUIRE(m->slots_live == 0, "whisper_encode: %d slot(s) of the continuous token loop are live on this engine (one mode at a time; use s2s_whisper_encode_at)", m->slots_live);
     return encode(m, (hipStream_t)stream, feats_dev, B);
 }
 
