@@ -113,6 +113,8 @@ def parse(argv=None):
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
     ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
                     "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
+    ap.add_argument("--stt-slots", type=int, default=0, help="> 0: the pool's Whisper token loop runs continuously with this many slots (SessionPool stt_slots; unmeasured, off)")
+    ap.add_argument("--stt-slot-steps", type=int, default=4, help="greedy steps per round of the continuous token loop")
     ap.add_argument("--tts-nursery-slots", type=int, default=0, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
     ap.add_argument("--tts-nursery-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the nursery loop")
     ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
@@ -347,7 +349,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0, nursery_priority=0):
+                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0, nursery_priority=0, stt_slots=0, stt_slot_steps=4):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -369,7 +371,8 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
 
     B = int(getattr(stt_engine, "max_batch", tts_engine.max_batch))      # STT batches; the TTS lane's rows are the TTS engine's slots
     pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus, stt_max_batch=stt_max_batch,
-                       tts_admit_wait_s=admit_wait_s, stt_stages=stt_stages, tts_nursery_slots=nursery_slots, tts_nursery_priority=nursery_priority)
+                       tts_admit_wait_s=admit_wait_s, stt_stages=stt_stages, tts_nursery_slots=nursery_slots, tts_nursery_priority=nursery_priority,
+                       stt_slots=stt_slots, stt_slot_steps=stt_slot_steps)
     pool._engines[stt_model] = stt_engine
     pool._engines["tts"] = tts_engine
     tts_engine.text_frontend = front
@@ -792,7 +795,8 @@ def main():
             def probe(n, window=args.boundary_seconds, seed=0):
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch,
-                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows), nursery_slots=args.tts_nursery_slots, nursery_priority=args.tts_nursery_priority)
+                                      admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows), nursery_slots=args.tts_nursery_slots, nursery_priority=args.tts_nursery_priority,
+                                      stt_slots=args.stt_slots, stt_slot_steps=args.stt_slot_steps)
 
             single = None if args.probe_only else probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
