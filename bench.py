@@ -94,7 +94,7 @@ def parse(argv=None):
     ap.add_argument("--stt-only", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run STT and TTS of every step back to back on one stream")
     ap.add_argument("--tts-lanes", type=int, default=None, help="TTS turn-batches in flight at once (engine replicas sharing the weights; thread + HIP stream each)")
-    ap.add_argument("--tts-slots", type=int, default=None, help="rows (slots) of the TTS engine's frame loop (default: 512 for c3 - the wide loop of csrc/gemm_decw.hip -, else --sessions)")
+    ap.add_argument("--tts-slots", type=int, default=None, help="rows (slots) of the TTS engine's frame loop (default: 512 for c3 / c5 - the wide loop of csrc/gemm_decw.hip -, else --sessions)")
     ap.add_argument("--lane-priority", type=int, default=0, choices=[0, -1], help="HIP stream priority of the TTS lanes (-1 = high: their short latency-bound "
                     "kernels are dispatched ahead of the encoder's workgroups; experimental, default 0)")
     ap.add_argument("--tts-merge", type=int, default=None, help="STT turn-batches merged into ONE TTS run on a lane (default 4 for c3: 4 x 64 sessions = 256 rows per decode kernel; "
@@ -607,7 +607,7 @@ def main():
     # of the queued sessions per pass (measured on C3: 549 sustained sessions with batches of up to 128 vs 416 with 64)
     MB = min(128, max(B, args.pool_max_batch or (128 if wl == "c3" else B)))      # STT engine rows (whisper.cpp: <= 128)
     merge = max(1, int(args.tts_merge if args.tts_merge is not None else (4 if wl == "c3" and not args.serial else 1)))
-    TMB = max(MB, merge * B, int(args.tts_slots or (512 if wl == "c3" else B)))        # TTS engine slots (tts.cpp: <= 512)
+    TMB = max(MB, merge * B, int(args.tts_slots or (512 if wl in ("c3", "c5") else B)))        # TTS engine slots (tts.cpp: <= 512); a PACED reply holds its slot for its whole duration
     if TMB > 512 or B > 128:
         raise SystemExit(f"--tts-merge {merge} x --sessions {B} / --tts-slots exceed the engines' limits (TTS 512 slots, STT 128 rows)")
     audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
