@@ -45,6 +45,17 @@ int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
 int32_t s2s_graph_bench_begin(void** out_stream);
 int32_t s2s_graph_bench_end(int32_t warm, int32_t reps, double* us_per_replay);
 
+/* S2S_GUARD (environment, read once): development allocator mode for cornering stray device accesses.
+ *   1: every workspace sub-buffer of the engines is followed by a 64 KiB gap filled with 0xA5; s2s_guard_check() copies the gaps back,
+ *      writes one line per gap a kernel stored into ("<owner> buffer <i>: n byte(s) written behind its end, offsets +a .. +b") into
+ *      `report`, re-poisons it and returns the number of corrupted gaps (0 = clean, < 0 = HIP error).
+ *   2: additionally every guarded allocation is a HIP virtual-memory mapping that ENDS at an unmapped page: a load or store past the
+ *      end of an arena faults at once, and the table printed to stderr at allocation time ("[s2s guard] owner lo .. hi") attributes
+ *      the faulting address.
+ * s2s_guard_check synchronises the device: call it between launches (tests/conftest.py does, after every GPU test, when S2S_GUARD is set). */
+int32_t s2s_guard_mode(void);
+int32_t s2s_guard_check(char* report, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/s2s_mi355x.h"
 #include "../../include/s2s_mi355x_dev.h"
@@ -82,6 +84,44 @@ bool prof_active();
 bool graphs_enabled();
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- S2S_GUARD: development allocator mode (corner the unexplained "Memory access fault") -------------------
+//   S2S_GUARD=1  every workspace sub-buffer is followed by a poisoned gap (0xA5); s2s_guard_check() reports the gaps a kernel wrote
+//                into - a store past the end of a buffer that stays inside the arena never faults, it corrupts a neighbour.
+//   S2S_GUARD=2  additionally every guarded allocation ends at an UNMAPPED page (HIP virtual memory management): a load or store
+//                past the end faults at once, at an address the table printed at allocation time attributes to its owner.
+// Off (unset / 0): plain hipMalloc, no gaps - the product path is byte-for-byte what it was.
+int guard_mode();
+size_t guard_gap();                                                           // bytes of poison behind every sub-buffer (0 when off)
+int guard_alloc(char** out, size_t bytes, const char* owner);                 // hipMalloc, or (mode 2) a mapping that ends at an unmapped page
+void guard_free(void* p);
+int guard_add_gap(char* p, size_t len, const char* owner, int index);         // poison + register [p, p + len)
+
+// carve-up of one workspace arena (whisper.cpp / parakeet.cpp / tts.cpp): offsets of 256-byte aligned sub-buffers
+struct ArenaPlan {
+    size_t off = 0;
+    std::vector<std::pair<size_t, size_t>> gaps;      // guard mode: (offset, length) from the exact end of a sub-buffer to the next one
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        if (const size_t g = guard_gap()) {
+            off += g;
+            gaps.emplace_back(o + bytes, off - (o + bytes));
+        }
+        return o;
+    }
+    // allocate the arena (zero-filled); guard mode poisons and registers the gaps
+    int commit(char** arena, const char* owner) {
+        int rc = guard_alloc(arena, off, owner);
+        if (rc) return rc;
+        S2S_HIP_CHECK(hipMemset(*arena, 0, off));
+        int idx = 0;
+        for (const auto& g : gaps) {
+            if ((rc = guard_add_gap(*arena + g.first, g.second, owner, idx++))) return rc;
+        }
+        return S2S_OK;
+    }
+};
 
 // ---- device helpers --------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {

@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 
+#include <map>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -206,4 +207,143 @@ extern "C" int32_t s2s_device_count(void) {
         return 0;
     }
     return n;
+}
+
+// ---- S2S_GUARD: poisoned gaps + unmapped tail pages (development; see common.h) ---------------------------------------------------
+namespace s2s {
+namespace {
+struct GuardGap {
+    char* p;
+    size_t len;
+    std::string owner;
+    int index;
+};
+struct GuardMap {       // one mode-2 allocation: reserved range [va, va + reserved), mapped [va, va + mapped), user pointer inside
+    char* va;
+    size_t reserved, mapped;
+    hipMemGenericAllocationHandle_t handle;
+};
+std::mutex g_guard_mu;
+std::vector<GuardGap> g_guard_gaps;
+std::map<void*, GuardMap> g_guard_maps;
+constexpr unsigned char GUARD_POISON = 0xA5;
+}  // namespace
+
+int guard_mode() {
+    static const int mode = [] {
+        const char* e = getenv("S2S_GUARD");
+        return e ? atoi(e) : 0;
+    }();
+    return mode;
+}
+
+size_t guard_gap() { return guard_mode() > 0 ? (size_t)64 << 10 : 0; }
+
+int guard_alloc(char** out, size_t bytes, const char* owner) {
+    *out = nullptr;
+    if (guard_mode() < 2) {
+        S2S_HIP_CHECK(hipMalloc((void**)out, bytes));
+        if (guard_mode() == 1) fprintf(stderr, "[s2s guard] %-10s %p .. %p (%zu bytes)\n", owner, (void*)*out, (void*)(*out + bytes), bytes);
+        return S2S_OK;
+    }
+    int dev = 0;
+    S2S_HIP_CHECK(hipGetDevice(&dev));
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    S2S_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    if (gran < 4096) gran = 4096;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    const size_t mapped = (need + gran - 1) / gran * gran;
+    GuardMap g{};
+    g.mapped = mapped;
+    g.reserved = mapped + gran;                         // one granule behind the mapping stays reserved and UNMAPPED
+    void* va = nullptr;
+    S2S_HIP_CHECK(hipMemAddressReserve(&va, g.reserved, gran, nullptr, 0));
+    g.va = (char*)va;
+    S2S_HIP_CHECK(hipMemCreate(&g.handle, mapped, &prop, 0));
+    S2S_HIP_CHECK(hipMemMap(va, mapped, 0, g.handle, 0));
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    S2S_HIP_CHECK(hipMemSetAccess(va, mapped, &acc, 1));
+    *out = g.va + (mapped - need);                      // right-aligned: the allocation ENDS where the mapping ends
+    fprintf(stderr, "[s2s guard] %-10s %p .. %p (%zu bytes), unmapped from %p\n", owner, (void*)*out, (void*)(*out + need), bytes, (void*)(g.va + mapped));
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard_maps[*out] = g;
+    return S2S_OK;
+}
+
+void guard_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        // gaps that live inside this allocation go with it (an arena's gaps, or the single gap behind a stand-alone buffer)
+        auto it = g_guard_maps.find(p);
+        const char* lo = (const char*)p;
+        const char* hi = it != g_guard_maps.end() ? it->second.va + it->second.mapped : nullptr;
+        if (!hi) {
+            size_t sz = 0;
+            hipDeviceptr_t base = nullptr;
+            if (hipMemGetAddressRange(&base, &sz, (hipDeviceptr_t)p) == hipSuccess) hi = (const char*)base + sz;
+            else (void)hipGetLastError();
+        }
+        if (hi) g_guard_gaps.erase(std::remove_if(g_guard_gaps.begin(), g_guard_gaps.end(), [&](const GuardGap& g) { return g.p >= lo && g.p < hi; }), g_guard_gaps.end());
+        if (it != g_guard_maps.end()) {
+            const GuardMap g = it->second;
+            g_guard_maps.erase(it);
+            (void)hipMemUnmap(g.va, g.mapped);
+            (void)hipMemRelease(g.handle);
+            (void)hipMemAddressFree(g.va, g.reserved);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+int guard_add_gap(char* p, size_t len, const char* owner, int index) {
+    if (!guard_mode() || !len) return S2S_OK;
+    S2S_HIP_CHECK(hipMemset(p, GUARD_POISON, len));
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard_gaps.push_back(GuardGap{p, len, owner, index});
+    return S2S_OK;
+}
+}  // namespace s2s
+
+extern "C" int32_t s2s_guard_mode(void) { return s2s::guard_mode(); }
+
+// Checks every poisoned gap (synchronous copies: call it between launches, never while a stream is being captured); writes one line per
+// corrupted gap into `report` and re-poisons it.  Returns the number of corrupted gaps, or < 0 on a HIP error.
+extern "C" int32_t s2s_guard_check(char* report, int32_t cap) {
+    using namespace s2s;
+    if (report && cap > 0) report[0] = 0;
+    if (!guard_mode()) return 0;
+    std::lock_guard<std::mutex> no_capture(capture_mutex());
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    S2S_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<unsigned char> host;
+    int bad = 0;
+    size_t used = 0;
+    for (const GuardGap& g : g_guard_gaps) {
+        host.resize(g.len);
+        S2S_HIP_CHECK(hipMemcpy(host.data(), g.p, g.len, hipMemcpyDeviceToHost));
+        size_t first = g.len, n_bad = 0, last = 0;
+        for (size_t i = 0; i < g.len; ++i)
+            if (host[i] != GUARD_POISON) {
+                if (first == g.len) first = i;
+                last = i;
+                ++n_bad;
+            }
+        if (!n_bad) continue;
+        ++bad;
+        if (report && used + 1 < (size_t)cap) {
+            const int w = snprintf(report + used, (size_t)cap - used, "%s buffer %d: %zu byte(s) written behind its end, offsets +%zu .. +%zu (gap %p, %zu bytes)\n",
+                                   g.owner.c_str(), g.index, n_bad, first, last, (void*)g.p, g.len);
+            if (w > 0) used = std::min((size_t)cap - 1, used + (size_t)w);
+        }
+        S2S_HIP_CHECK(hipMemset(g.p, GUARD_POISON, g.len));
+    }
+    return bad;
 }

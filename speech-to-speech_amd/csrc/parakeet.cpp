@@ -99,10 +99,7 @@ static int check_weights(const Parakeet* m) {
 
 static inline int half_up(int n) { return (n - 1) / 2 + 1; }
 
-struct Plan {
-    size_t off = 0;
-    size_t take(size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; }
-};
+using Plan = ArenaPlan;      // (common.h: the shared carve-up, with poisoned gaps under S2S_GUARD)
 
 static int finalize(Parakeet* m) {
     int rc = check_weights(m);
@@ -144,8 +141,7 @@ static int finalize(Parakeet* m) {
     o[k++] = a.take(3 * B * (size_t)m->max_steps_alloc * 4);   // 25 outputs
     o[k++] = a.take(64 * sizeof(void*));       // 26 pointer tables
     m->arena_bytes = a.off;
-    S2S_HIP_CHECK(hipMalloc(&m->arena, m->arena_bytes));
-    S2S_HIP_CHECK(hipMemset(m->arena, 0, m->arena_bytes));
+    if ((rc = a.commit(&m->arena, "parakeet"))) return rc;
     char* b0 = m->arena;
     m->s1 = b0 + o[0]; m->s2a = b0 + o[1]; m->s2b = b0 + o[2]; m->s3a = b0 + o[3]; m->s3b = b0 + o[4];
     m->x = (float*)(b0 + o[5]); m->h = b0 + o[6]; m->qkv = b0 + o[7]; m->qv = b0 + o[8]; m->vt = b0 + o[9];
@@ -346,7 +342,7 @@ extern "C" int32_t s2s_parakeet_create(const s2s_parakeet_config* cfg, int32_t m
 extern "C" int32_t s2s_parakeet_destroy(void* model) {
     if (!model) return S2S_OK;
     Parakeet* m = (Parakeet*)model;
-    if (m->arena) (void)hipFree(m->arena);
+    guard_free(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
     delete m;
     return S2S_OK;

@@ -160,10 +160,7 @@ static int check_stack(const Tts* m, const Stack& s) {
     return S2S_OK;
 }
 
-struct Plan {
-    size_t off = 0;
-    size_t take(size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; }
-};
+using Plan = ArenaPlan;      // (common.h: the shared carve-up, with poisoned gaps under S2S_GUARD)
 
 // rows of a stage for a streamed CONTINUATION chunk of F frames: every frame contributes its full upsampling product (the first chunk
 // of a stream is shorter: each causal transposed conv trims its first output group) - this is what the activation buffers must hold
@@ -280,8 +277,7 @@ static int finalize(Tts* m) {
     T(B * act_elems * e);                      // 24 cb
     T(B * act_elems * e);                      // 25 cc
     m->arena_bytes = a.off;
-    S2S_HIP_CHECK(hipMalloc(&m->arena, m->arena_bytes));
-    S2S_HIP_CHECK(hipMemset(m->arena, 0, m->arena_bytes));
+    if ((rc = a.commit(&m->arena, "tts"))) return rc;
     char* b0 = m->arena;
     m->h = b0 + o[0]; m->qkv = b0 + o[1]; m->att = b0 + o[2]; m->gu = b0 + o[3]; m->act = b0 + o[4];
     m->x = (float*)(b0 + o[5]); m->xp = (float*)(b0 + o[6]); m->hn = (float*)(b0 + o[7]); m->hn_t = b0 + o[8];
@@ -319,9 +315,10 @@ static int finalize(Tts* m) {
         for (int i = 0; i < c.n_dec_blocks; ++i)
             for (int j = 0; j < 4; ++j) m->cstate_c.push_back((int)(Dd >> (i + 1)));
         for (int i = 0; i < n_slots; ++i) {
-            void* p = nullptr;
-            S2S_HIP_CHECK(hipMalloc(&p, B * LPAD * cmax * e));
-            S2S_HIP_CHECK(hipMemset(p, 0, B * LPAD * cmax * e));
+            ArenaPlan hp;                      // (one buffer per plan: under S2S_GUARD each history block gets its own poisoned gap / unmapped tail)
+            hp.take(B * LPAD * cmax * e);
+            char* p = nullptr;
+            if ((rc = hp.commit(&p, "tts.hist"))) return rc;
             m->cstate.push_back(p);
         }
         m->pos_c = ints + 8 * B + 8;
@@ -333,13 +330,15 @@ static int finalize(Tts* m) {
         // norm-free decode path: RMSNorm weights folded into the columns of the consuming projections (own copies; the
         // prefill path keeps the checkpoint's matrices)
         m->xb_width = (int)std::max(std::max(E, P), (long)c.c_hidden);
-        S2S_HIP_CHECK(hipMalloc(&m->xb, (size_t)DEC_ROWS * m->xb_width * e));
-        S2S_HIP_CHECK(hipMalloc((void**)&m->ssA, sizeof(float) * SS_PARTS * DEC_ROWS));
-        S2S_HIP_CHECK(hipMalloc((void**)&m->ssB, sizeof(float) * SS_PARTS * DEC_ROWS));
-        S2S_HIP_CHECK(hipMalloc(&m->dec_ws, DEC_WS_BYTES));
-        S2S_HIP_CHECK(hipMemset(m->dec_ws, 0, DEC_WS_BYTES));
-        m->owned.push_back(m->xb); m->owned.push_back(m->ssA); m->owned.push_back(m->ssB); m->owned.push_back(m->dec_ws);
-        S2S_HIP_CHECK(hipMemset(m->xb, 0, (size_t)DEC_ROWS * m->xb_width * e));   // padding rows of fragment tiles must stay finite
+        {   // one small arena (zero-filled: padding rows of fragment tiles must stay finite; the K-slice tickets start at zero)
+            ArenaPlan dp;
+            const size_t o_xb = dp.take((size_t)DEC_ROWS * m->xb_width * e), o_a = dp.take(sizeof(float) * SS_PARTS * DEC_ROWS),
+                         o_b = dp.take(sizeof(float) * SS_PARTS * DEC_ROWS), o_ws = dp.take(DEC_WS_BYTES);
+            char* base = nullptr;
+            if ((rc = dp.commit(&base, "tts.dec"))) return rc;
+            m->xb = base + o_xb; m->ssA = (float*)(base + o_a); m->ssB = (float*)(base + o_b); m->dec_ws = base + o_ws;
+            m->owned.push_back(base);
+        }
         // The fragment-major copies ("<name>.f": s2s_op_to_frag of the projection, RMSNorm weight folded into qkv / gate-up / the
         // predictor heads) are made once by the host side and shared by every engine replica on the GPU; the norm-free decode
         // path is on only when all of them were registered.
@@ -674,11 +673,11 @@ extern "C" int32_t s2s_tts_create(const s2s_tts_config* cfg, int32_t max_batch, 
 extern "C" int32_t s2s_tts_destroy(void* model) {
     if (!model) return S2S_OK;
     Tts* m = (Tts*)model;
-    if (m->arena) (void)hipFree(m->arena);
+    guard_free(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
     if (m->pos_p) (void)hipFree(m->pos_p);
-    for (void* p : m->owned) (void)hipFree(p);
-    for (void* p : m->cstate) (void)hipFree(p);
+    for (void* p : m->owned) guard_free(p);
+    for (void* p : m->cstate) guard_free(p);
     for (auto& kv : m->frame_graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipGraphExec_t e : m->retired_graphs) (void)hipGraphExecDestroy(e);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);

@@ -140,15 +140,6 @@ static int check_weights(const Whisper* m) {
 static const void* P(const Whisper* m, const std::string& name) { return find(m, name)->ptr; }
 static const float* PF(const Whisper* m, const std::string& name) { return (const float*)find(m, name)->ptr; }
 
-struct ArenaPlan {
-    size_t off = 0;
-    size_t take(size_t bytes) {
-        const size_t o = off;
-        off += (bytes + 255) & ~(size_t)255;
-        return o;
-    }
-};
-
 static int finalize(Whisper* m) {
     int rc = check_weights(m);
     if (rc) return rc;
@@ -178,8 +169,7 @@ static int finalize(Whisper* m) {
     const size_t o_logits = a.take(B * (size_t)c.vocab * 4);
     const size_t o_ints = a.take((size_t)(B * (8 + m->tmax)) * 4);
     m->arena_bytes = a.off;
-    S2S_HIP_CHECK(hipMalloc(&m->arena, m->arena_bytes));
-    S2S_HIP_CHECK(hipMemset(m->arena, 0, m->arena_bytes));
+    if ((rc = a.commit(&m->arena, "whisper"))) return rc;
     char* base = m->arena;
     m->y1 = base + o_y1; m->x = (float*)(base + o_x); m->h = base + o_h; m->qkv = base + o_qkv;
     m->vt = base + o_vt; m->att = base + o_att; m->ffn = base + o_ffn; m->enc_out = base + o_enc;
@@ -689,7 +679,7 @@ extern "C" int32_t s2s_whisper_create(const s2s_whisper_config* cfg, int32_t max
 extern "C" int32_t s2s_whisper_destroy(void* model) {
     if (!model) return S2S_OK;
     Whisper* m = (Whisper*)model;
-    if (m->arena) (void)hipFree(m->arena);
+    guard_free(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
     if (m->step_dev) (void)hipFree(m->step_dev);
     if (m->mask_sup) (void)hipFree(m->mask_sup);

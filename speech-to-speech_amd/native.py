@@ -144,6 +144,8 @@ _DEV_SIGNATURES = {
     "s2s_graph_bench_begin": [C.POINTER(_vp)],
     "s2s_graph_bench_end": [_i32, _i32, C.POINTER(C.c_double)],
     "s2s_op_gemm_decw_tune": [_i32, _i32, _i32],
+    "s2s_guard_mode": [],
+    "s2s_guard_check": [C.c_char_p, _i32],
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
              "s2s_parakeet_workspace_bytes": C.c_int64, "s2s_tts_workspace_bytes": C.c_int64,
@@ -174,6 +176,16 @@ def load():
             fn.restype = _RESTYPES.get(name, _i32)
         _lib = lib
         return lib
+
+
+def guard_check() -> tuple[int, str]:
+    """S2S_GUARD development mode (include/s2s_mi355x_dev.h): -> (number of poisoned gaps a kernel wrote into, report text)."""
+    lib = load()
+    buf = C.create_string_buffer(16384)
+    n = int(lib.s2s_guard_check(buf, len(buf)))
+    if n < 0:
+        check(n, "s2s_guard_check")
+    return n, buf.value.decode(errors="replace")
 
 
 def declared_symbols(header: str | None = None) -> list[str]:

@@ -33,3 +33,16 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _guard_check(request):
+    """S2S_GUARD=1|2 (development allocator mode, include/s2s_mi355x_dev.h): after every GPU test the poisoned gaps behind the engines'
+    workspace buffers are verified - a kernel that stored past the end of a buffer fails the test that ran it, with the owner named."""
+    yield
+    if os.environ.get("S2S_GUARD", "0") in ("", "0") or "gpu" not in request.keywords or not _has_gpu():
+        return
+    from speech_to_speech_amd import native
+
+    n, report = native.guard_check()
+    assert n == 0, "S2S_GUARD: stores behind the end of a workspace buffer:\n" + report
