@@ -278,6 +278,10 @@ int guard_alloc(char** out, size_t bytes, const char* owner) {
 
 void guard_free(void* p) {
     if (!p) return;
+    if (!guard_mode()) {         // the product path: plain hipFree, nothing else
+        (void)hipFree(p);
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(g_guard_mu);
         // gaps that live inside this allocation go with it (an arena's gaps, or the single gap behind a stand-alone buffer)
