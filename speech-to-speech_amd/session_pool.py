@@ -146,6 +146,8 @@ class SessionPool:
         # loop's pace no longer sits in anybody's time-to-first-audio.  0: one loop does both (admission wait `tts_admit_wait_s`).
         self.tts_nursery_slots = max(0, int(tts_nursery_slots))
         self.tts_nursery_priority = int(tts_nursery_priority)      # HIP stream priority of the nursery loop (-1 = high: it sits in every session's first audio)
+        self.stt_workers = max(1, int(stt_workers))
+        self._stt_extra_reps: dict[str, dict[int, Any]] = {}      # model -> {extra worker k: its replica, built with the engine}
         self._stt_reps: dict[str, list] = {}          # model -> engines of the pipeline (the pool's engine + replicas)
         self._stt_free: dict[str, "queue.Queue[int]"] = {}
         self._stt_dq: "queue.Queue[Any]" = queue.Queue()
@@ -360,6 +362,7 @@ class SessionPool:
                     try:
                         self._engines[name] = factory()
                         self._stt_pipeline_build(name)   # (replicas are built HERE, with the engine - never while serving)
+                        self._stt_extra_build(name)
                         self._sync_current_stream()      # uploads / conversions of the build are complete before any lane uses the weights
                         fut.set_result(True)
                     except BaseException as e:  # noqa: BLE001
@@ -561,6 +564,21 @@ class SessionPool:
             finally:
                 self._stt_free[model].put(idx)
 
+    def _stt_extra_build(self, model: str) -> None:
+        """Replicas of the extra STT workers are built with the engine (replica finalize allocates and uses the legacy stream; the
+        first features() call pins memory - neither belongs into serving time).  Engines registered directly are replicated lazily."""
+        eng = self._engines.get(model)
+        if self.stt_workers <= 1 or eng is None or not hasattr(eng, "replica") or not hasattr(eng, "transcribe_batch"):
+            return
+        reps = self._stt_extra_reps.setdefault(model, {})
+        for k in range(1, self.stt_workers):
+            if k not in reps:
+                try:
+                    reps[k] = eng.replica()
+                    self._lane_replicas.append(reps[k])
+                except BaseException as e:  # noqa: BLE001
+                    logger.error("STT worker %d: could not build its %s replica with the engine (%s); it will try on first use", k, model, e)
+
     def _run_stt_extra(self, k: int) -> None:
         """STT worker k > 0: same batching as the first worker, on replicas that share the engines' weights.  Engine builds, and requests for
         engines that cannot be replicated, stay with the first worker."""
@@ -583,8 +601,12 @@ class SessionPool:
             model = first.model
             try:
                 if model not in replicas:
-                    replicas[model] = self._engines[model].replica()
-                    self._lane_replicas.append(replicas[model])
+                    pre = self._stt_extra_reps.get(model, {}).get(k)
+                    if pre is not None:
+                        replicas[model] = pre
+                    else:
+                        replicas[model] = self._engines[model].replica()
+                        self._lane_replicas.append(replicas[model])
             except BaseException as e:  # noqa: BLE001
                 logger.error("STT worker %d could not build its %s replica: %s", k, model, e, exc_info=True)
                 self._stt_q.put(first)
