@@ -304,8 +304,8 @@ class WhisperEngine:
     def slots_admit(self, slot0: int, prompts: Sequence[Sequence[int]], max_new: Sequence[int]) -> None:
         n, P = len(prompts), len(prompts[0])
         assert all(len(p) == P for p in prompts) and len(max_new) == n and 1 <= P <= self.SLOT_PMAX
-        pr = torch.tensor(prompts, dtype=torch.int32).to(self.device, non_blocking=True)
-        mn = torch.tensor([int(v) for v in max_new], dtype=torch.int32).to(self.device, non_blocking=True)
+        pr = torch.tensor(prompts, dtype=torch.int32).to(self.device)
+        mn = torch.tensor([int(v) for v in max_new], dtype=torch.int32).to(self.device)
         with torch.cuda.device(self.device):
             native.check(self._lib.s2s_whisper_slots_admit(self._h, native.stream_handle(), int(slot0), n, native.ptr(pr), P, native.ptr(mn),
                                                            int(max(max_new))), "s2s_whisper_slots_admit")
