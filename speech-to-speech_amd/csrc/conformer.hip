@@ -157,8 +157,9 @@ __global__ void add_rowvec_kernel(const T* __restrict__ in, long ld_in, const fl
 // A[b][:] = relu(encp[b][min(frame, T-1)][:] + dec[b][:])
 template <typename T>
 __global__ void tdt_joint_in_kernel(const float* __restrict__ encp, const float* __restrict__ dec, const int* __restrict__ frame,
-                                    T* __restrict__ A, int Tn, int Hd) {
+                                    T* __restrict__ A, int Tn, int Hd, const int* __restrict__ dyn) {
     const int b = blockIdx.x;
+    if (dyn) Tn = dyn[0];        // captured step (parakeet.cpp tdt_step_graph): the utterance's frame count lives in device memory
     const int f = min(frame[b], Tn - 1);
     for (int i = threadIdx.x; i < Hd; i += blockDim.x)
         Elem<T>::st(A + (long)b * Hd + i, fmaxf(encp[((long)b * Tn + f) * Hd + i] + dec[(long)b * Hd + i], 0.f));
@@ -167,7 +168,9 @@ __global__ void tdt_joint_in_kernel(const float* __restrict__ encp, const float*
 // token = argmax(logits[:V]), duration = argmax(logits[V:V+ND]); blank & dur 0 -> 1; frame += dur
 __global__ __launch_bounds__(256) void tdt_select_kernel(const float* __restrict__ logits, int ld, int V, int ND, int blank,
                                                          const int* __restrict__ enc_len, TdtState s, int* __restrict__ out_tok,
-                                                         int* __restrict__ out_dur, int* __restrict__ out_frame, int max_steps) {
+                                                         int* __restrict__ out_dur, int* __restrict__ out_frame, int max_steps,
+                                                         const int* __restrict__ dyn) {
+    if (dyn) max_steps = dyn[1];
     __shared__ float sv[4];
     __shared__ int si[4];
     const int b = blockIdx.x;
@@ -303,15 +306,15 @@ int add_rowvec(hipStream_t st, const void* in, long ld_in, const float* vec, voi
     return S2S_OK;
 }
 
-int tdt_joint_in(hipStream_t st, const float* encp, const float* dec, const int* frame, void* A, int B, int Tn, int Hd, int dtype) {
-    S2S_DT(TT, (tdt_joint_in_kernel<TT><<<B, 256, 0, st>>>(encp, dec, frame, (TT*)A, Tn, Hd)));
+int tdt_joint_in(hipStream_t st, const float* encp, const float* dec, const int* frame, void* A, int B, int Tn, int Hd, int dtype, const int* dyn) {
+    S2S_DT(TT, (tdt_joint_in_kernel<TT><<<B, 256, 0, st>>>(encp, dec, frame, (TT*)A, Tn, Hd, dyn)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
 
 int tdt_select(hipStream_t st, const float* logits, int ld, int V, int ND, int blank, const int* enc_len, const TdtState& s,
-               int* out_tok, int* out_dur, int* out_frame, int max_steps, int B) {
-    tdt_select_kernel<<<B, 256, 0, st>>>(logits, ld, V, ND, blank, enc_len, s, out_tok, out_dur, out_frame, max_steps);
+               int* out_tok, int* out_dur, int* out_frame, int max_steps, int B, const int* dyn) {
+    tdt_select_kernel<<<B, 256, 0, st>>>(logits, ld, V, ND, blank, enc_len, s, out_tok, out_dur, out_frame, max_steps, dyn);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

@@ -175,9 +175,9 @@ int sub_lengths(hipStream_t st, const int* len0, int halvings, int* out, int B);
 int glu_dwconv(hipStream_t st, const void* y, const float* w, const float* b, void* out, const int* len, int B, int Tn, int d,
                int ksize, int dtype);
 int add_rowvec(hipStream_t st, const void* in, long ld_in, const float* vec, void* out, long rows, int cols, int dtype);
-int tdt_joint_in(hipStream_t st, const float* encp, const float* dec, const int* frame, void* A, int B, int Tn, int Hd, int dtype);
+int tdt_joint_in(hipStream_t st, const float* encp, const float* dec, const int* frame, void* A, int B, int Tn, int Hd, int dtype, const int* dyn = nullptr);
 int tdt_select(hipStream_t st, const float* logits, int ld, int V, int ND, int blank, const int* enc_len, const TdtState& s,
-               int* out_tok, int* out_dur, int* out_frame, int max_steps, int B);
+               int* out_tok, int* out_dur, int* out_frame, int max_steps, int B, const int* dyn = nullptr);
 int lstm_in(hipStream_t st, const void* emb, const int* tok, const float* xin, const float* h, void* X, int B, int Hd, int dtype);
 int lstm_cell(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd);
 int tdt_commit(hipStream_t st, float* const* dst, const float* const* src, int n_arrays, const int* adv, int force, int B, int Hd);

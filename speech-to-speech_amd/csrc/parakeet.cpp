@@ -44,6 +44,11 @@ struct Parakeet {
     float** d_dst; const float** d_src;   // device pointer tables for the commit kernel
     int max_steps_alloc;
     int* host_flag = nullptr;
+    // S2S_TDT_GRAPH=1 (round 4, unmeasured, off by default): one captured TDT step per batch size; the utterance's frame count and the
+    // step budget are read from tdt_dyn {T, max_steps} in device memory, so the graph does not depend on the utterance
+    int* tdt_dyn = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, hipGraphExec_t> tdt_graphs;
 };
 
 static const PTensor* pfind(const Parakeet* m, const std::string& n) {
@@ -157,6 +162,7 @@ static int finalize(Parakeet* m) {
     int* ints = (int*)(b0 + o[24]);
     m->frame = ints; m->finished = ints + B; m->tok = ints + 2 * B; m->adv = ints + 3 * B; m->n_steps = ints + 4 * B;
     m->n_active = ints + 5 * B;
+    m->tdt_dyn = ints + 5 * B + 4;
     int* outs = (int*)(b0 + o[25]);
     m->o_tok = outs; m->o_dur = outs + B * m->max_steps_alloc; m->o_frame = outs + 2 * B * m->max_steps_alloc;
     // pointer tables for the commit kernel: dst = {h_l, c_l ..., dec}, src = {hnew_l, cnew_l ..., dec_new}
@@ -282,6 +288,61 @@ __global__ void fill_int_kernel(int* p, int v, int n) {
     if (i < n) p[i] = v;
 }
 
+__global__ void tdt_set_dyn_kernel(int* dyn, int T, int max_steps) {
+    dyn[0] = T;
+    dyn[1] = max_steps;
+}
+
+// one TDT step: joint network on the current frame, token / duration pick, prediction network on the pick, commit where it advanced.
+// dyn != null: the captured variant (frame count / step budget from device memory, the active counter reset by a kernel)
+static int tdt_step_body(Parakeet* m, hipStream_t st, int B, int T, int max_steps, const TdtState& s, const int* dyn) {
+    const auto& c = m->cfg;
+    const int Hd = c.dec_hidden, dt = c.dtype, V = c.vocab, ND = c.n_durations, NA = 2 * c.dec_layers + 1;
+    int rc;
+    if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt, dyn))) return rc;
+    if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+    if (dyn) {
+        fill_int_kernel<<<1, 64, 0, st>>>(m->n_active, 0, 1);
+        S2S_LAUNCH_CHECK();
+    } else {
+        S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
+    }
+    if ((rc = tdt_select(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B, dyn))) return rc;
+    if ((rc = prednet(m, st, B))) return rc;
+    return tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd);
+}
+
+static bool tdt_graph_enabled() {
+    static const bool on = getenv("S2S_TDT_GRAPH") != nullptr && atoi(getenv("S2S_TDT_GRAPH")) != 0;
+    return on;
+}
+
+static int tdt_step_graph(Parakeet* m, int B, const TdtState& s, hipGraphExec_t* out) {
+    auto it = m->tdt_graphs.find(B);
+    if (it != m->tdt_graphs.end()) {
+        *out = it->second;
+        return S2S_OK;
+    }
+    std::lock_guard<std::mutex> capture_lock(capture_mutex());
+    if (!m->cap_stream) S2S_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    S2S_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = tdt_step_body(m, m->cap_stream, B, /*T=*/1, /*max_steps=*/1, s, m->tdt_dyn);      // (T / max_steps come from tdt_dyn)
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    S2S_HIP_CHECK(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2S_HIP_CHECK(ie);
+    m->tdt_graphs[B] = exec;
+    *out = exec;
+    return S2S_OK;
+}
+
 static int tdt_greedy(Parakeet* m, hipStream_t st, int max_steps, int* out_tok, int* out_dur, int* out_frame, int* out_n) {
     const auto& c = m->cfg;
     const int B = m->cur_B, T = m->cur_T, Hd = c.dec_hidden, dt = c.dtype, V = c.vocab, ND = c.n_durations;
@@ -297,7 +358,28 @@ static int tdt_greedy(Parakeet* m, hipStream_t st, int max_steps, int* out_tok, 
     if ((rc = prednet(m, st, B))) return rc;
     if ((rc = tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, /*force=*/1, B, Hd))) return rc;
     TdtState s{m->frame, m->finished, m->tok, m->adv, m->n_steps, m->n_active};
+    hipGraphExec_t exec = nullptr;
+    bool graph_ok = tdt_graph_enabled() && graphs_enabled() && !prof_active();
+    if (graph_ok) {
+        tdt_set_dyn_kernel<<<1, 1, 0, st>>>(m->tdt_dyn, T, max_steps);
+        S2S_LAUNCH_CHECK();
+        if (tdt_step_graph(m, B, s, &exec) != S2S_OK) {      // refused / invalidated capture: this call runs as stream launches
+            (void)hipGetLastError();
+            graph_ok = false;
+        }
+    }
     for (int step = 0; step < max_steps; ++step) {
+        if (graph_ok) {
+            // the whole step is one replay; the prediction network and the commit after the LAST executed pick are harmless (they only
+            // touch rows that advanced, and nothing reads the state after the loop)
+            S2S_HIP_CHECK(hipGraphLaunch(exec, st));
+            if ((step & 15) == 15 || step + 1 == max_steps) {
+                S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+                S2S_HIP_CHECK(hipStreamSynchronize(st));
+                if (*m->host_flag == 0) break;
+            }
+            continue;
+        }
         if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt))) return rc;
         if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
         S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
@@ -344,6 +426,8 @@ extern "C" int32_t s2s_parakeet_destroy(void* model) {
     Parakeet* m = (Parakeet*)model;
     guard_free(m->arena);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
+    for (auto& kv : m->tdt_graphs) (void)hipGraphExecDestroy(kv.second);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return S2S_OK;
 }

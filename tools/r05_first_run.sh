@@ -25,5 +25,18 @@ for f in sorted(glob.glob("$O/ab_*.json")):
         print(f.split("/")[-1], r["sessions"], "done", r["turns_completed"], "/", r["turns_arrived"], "ttfa", r["p50_ttfa_ms"], r["p95_ttfa_ms"], "lag", r["max_playback_lag_ms"],
               "stt", r.get("p50_stt_ms"), r.get("p95_stt_ms"), r["pool"])
 PY
+# 3b. the captured TDT step (S2S_TDT_GRAPH=1): parity, then C2 with and without it
+S2S_TDT_GRAPH=1 timeout 300 python -m pytest tests/test_parakeet_gpu.py tests/test_full_depth_gpu.py -x -q -m gpu > $O/tests_tdt_graph.log 2>&1; tail -3 $O/tests_tdt_graph.log
+timeout 150 python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline --max-probes 2 > $O/c2_plain.json 2> $O/c2_plain.err
+S2S_TDT_GRAPH=1 timeout 150 python bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline --max-probes 2 > $O/c2_tdt_graph.json 2> $O/c2_tdt_graph.err
+python - <<PY
+import json
+for n in ("c2_plain", "c2_tdt_graph"):
+    try:
+        d = json.load(open("$O/" + n + ".json")); s = (d.get("boundary") or {}).get("single_session") or {}
+        print(n, "xrt", d["xrt"], "ms/step", d["ms_per_step"], "single TTFA", s.get("p50_ttfa_ms"), "stt", s.get("p50_stt_ms"))
+    except Exception as e:
+        print(n, "ERR", e)
+PY
 # 4. the suite under the poisoned-gap allocator (S2S_GUARD=1); mode 2 and the bench starts: tools/guard_run.sh
 S2S_GUARD=1 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests_guard1.log 2>&1; tail -3 $O/tests_guard1.log
