@@ -4,6 +4,9 @@ NOT part of the test suite: the kernel was written at the end of round 2 without
     python tools/proto/tile4_check.py            parity vs float64 on ragged and encoder shapes, then timing with the switch ON
     S2S_TILE4=2 python tools/proto/tile4_check.py    the 8-wave variant (wave tile 128 x 64, two waves per SIMD)
     S2S_TILE4_OFF=1 python tools/proto/tile4_check.py    same shapes on the current gemm_tile3 path (the A/B reference)
+    S2S_TILE4_PIPE=1 | 2 python tools/proto/tile4_check.py    the software-pipelined main loops written at the end of round 4 (UNMEASURED):
+                                                 1 = next group's A fragments read under the current group's MFMAs, 2 = + the next slab's first
+                                                 operands read under the last MFMA group (two slabs of look-ahead instead of three)
 
 Parity bar: f32 accumulation order only (<= 2e-4 of the row magnitude) plus one bf16 rounding (2^-8) for bf16 outputs.
 """

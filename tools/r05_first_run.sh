@@ -38,5 +38,7 @@ for n in ("c2_plain", "c2_tdt_graph"):
     except Exception as e:
         print(n, "ERR", e)
 PY
+# 3c. software-pipelined 256x256 tile GEMM main loops (S2S_TILE4_PIPE): parity + timing per variant, same box
+for v in 0 1 2; do S2S_TILE4_PIPE=$v timeout 200 python tools/proto/tile4_check.py > $O/tile4_pipe$v.log 2>&1; echo "== S2S_TILE4_PIPE=$v"; tail -12 $O/tile4_pipe$v.log; done
 # 4. the suite under the poisoned-gap allocator (S2S_GUARD=1); mode 2 and the bench starts: tools/guard_run.sh
 S2S_GUARD=1 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests_guard1.log 2>&1; tail -3 $O/tests_guard1.log
