@@ -1036,6 +1036,305 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
     pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
 }
 
+// ---- 256x256 tile, 64-wide K tiles, two staggered wave groups ("8-phase" schedule of cdna_hip_programming.md section 5) --------------
+// Round 5.  gemm_tile4's loop is lock-step: every wave reads its fragments, then every wave multiplies, one barrier per 32-wide slab, so
+// the matrix pipe idles through every LDS latency (0.20 - 0.25 of the MFMA peak in situ for three rounds).  Here the 8 waves form two
+// groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that run the SAME instruction stream one barrier apart: while one group
+// multiplies a 64x32 quadrant of its 128x64 wave tile (16 MFMAs under s_setprio 1) the other group issues its LDS fragment reads and the
+// direct global->LDS loads of a later K tile, then the roles swap at the next barrier.  A K tile (64 wide) is FOUR phases:
+//     phase 0: read B0 (4 x ds_read_b128) + A0 (8)   multiply acc[a0][b0]      stage half B1 of tile t + 1
+//     phase 1: read B1 (4)                           multiply acc[a0][b1]      stage half A1 of tile t + 1
+//     phase 2: read A1 (8)                           multiply acc[a1][b1]      stage half B0 of tile t + 2
+//     phase 3: -                                     multiply acc[a1][b0]      stage half A0 of tile t + 2
+// LDS = 2 buffers x 4 half-tiles x 16 KiB (128 rows x 128 bytes).  The half-tiles are laid out so that EVERY wave is done with a half
+// after one phase: A half `ah` holds, for both wave rows, the 64 tile rows of quadrant row ah (LDS row r <-> tile row
+// (r >> 6) * 128 + ah * 64 + (r & 63)), W half `bh` the 32 columns of quadrant column bh of all four wave columns (LDS row r <-> tile
+// column (r >> 5) * 64 + bh * 32 + (r & 31)); the permutation lives in the per-thread SOURCE addresses, the LDS image of a
+// global_load_lds is lane-linear as always.  One half-tile (2 loads per thread) is staged per phase, five to six phases ahead of its
+// first read:
+//   * WAR: a half read in phase g is restaged in phase g + 2 at the earliest - the other group runs one barrier behind, so its reads
+//     of phase g are only known complete (its lgkmcnt(0)) once THIS group has passed two more barriers;
+//   * RAW: `s_waitcnt vmcnt(8)` after the phase's own issue leaves the four youngest half-tiles in flight, i.e. everything issued
+//     up to four phases ago has landed for this wave before the phase's first barrier; a read in the NEXT phase sits behind that
+//     barrier for both groups (the lagging group passes it one barrier later still).  Needed: issue phase + 5 <= read phase (table).
+// Loads past the end of K re-read the last K tile (never consumed) so that the counted wait is the same instruction all along; rows
+// past M / N are clamped to the last valid row (their products are never stored).
+// 128-byte LDS rows: 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7) - the 16 lanes of every ds_read_b128 lane group
+// (MI355X_MICROARCH.md, LDS table) then cover the 16 distinct 16-byte slots of a 256-byte bank window.
+// VAR bit 0: no stagger (lock-step A/B arm); bit 1: no s_setprio.
+constexpr int T5_M = 256, T5_N = 256, T5_BK = 64, T5_HALF = 128 * 128, T5_BUF = 4 * T5_HALF, T5_LDS = 2 * T5_BUF;
+
+// the epilogue of the 256x256 kernels: wave tile 128 x 64 at (wm, wn), 8 passes of 16 rows staged through LDS (pitch 68 floats:
+// conflict-free fragment writes) and read back row-wise so that every lane moves 16 contiguous bytes of one output row.  The residual
+// values of a pass are fetched before its first store (the residual may alias C).
+template <typename CT>
+__device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned char* lds, const float* __restrict__ bias, const float* residual,
+                                                 CT* C, long ldc, int M, int N, int act, const RowMap& rm, int m0, int n0, int wm, int wn,
+                                                 int lane, int wave) {
+    constexpr int WNF = 4, WCOLS = 64;
+    constexpr int VEC = 16 / (int)sizeof(CT);   // 8 (bf16) / 4 (f32)
+    constexpr int PITCH = WCOLS + 4;
+    constexpr int LPR = WCOLS / VEC;            // lanes per output row of the wave tile
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int NIT = 16 / RPI;               // instructions per 16-row pass
+    const int l15 = lane & 15, lg = lane >> 4;
+    const bool grouped = rm.G < M;
+    const int cc = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc;
+    const bool full = n + VEC <= N;
+    float* stg = reinterpret_cast<float*>(lds) + wave * (16 * PITCH);
+    float bv[WNF];
+#pragma unroll
+    for (int j = 0; j < WNF; ++j) {
+        const int nc = n0 + wn + j * 16 + l15;
+        bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
+    }
+    auto row_off = [&](int m, long& coff, long& roff) {
+        if (grouped) {
+            const int mb = m / rm.G, mr = m - mb * rm.G;
+            coff = (long)mb * rm.c_bs + (long)mr * ldc;
+            roff = (long)mb * rm.r_bs + (long)mr * rm.ldr;
+        } else {
+            coff = (long)m * ldc;
+            roff = (long)m * rm.ldr;
+        }
+    };
+    auto pass = [&](auto ic) {                  // (compile-time pass index: a runtime one would send the accumulators to scratch)
+        constexpr int i = decltype(ic)::value;
+        float rres[NIT][VEC];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) rres[it][e] = 0.f;
+            const int m = m0 + wm + i * 16 + it * RPI + lane / LPR;
+            if (residual == nullptr || m >= M || n >= N) continue;
+            long coff, roff;
+            row_off(m, coff, roff);
+            const float* rp = residual + roff + n;
+            if (full && ((uintptr_t)rp & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rp + q * 4);
+                    rres[it][q * 4 + 0] = r4.x; rres[it][q * 4 + 1] = r4.y; rres[it][q * 4 + 2] = r4.z; rres[it][q * 4 + 3] = r4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) rres[it][e] = rp[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WNF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int prow = it * RPI + lane / LPR;      // row inside the staged pass
+            const int m = m0 + wm + i * 16 + prow;
+            if (m >= M || n >= N) continue;
+            long coff, roff;
+            row_off(m, coff, roff);
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + prow * PITCH + cc + q * 4);
+                v[q * 4 + 0] = t4.x + rres[it][q * 4 + 0]; v[q * 4 + 1] = t4.y + rres[it][q * 4 + 1];
+                v[q * 4 + 2] = t4.z + rres[it][q * 4 + 2]; v[q * 4 + 3] = t4.w + rres[it][q * 4 + 3];
+            }
+            CT* dp = C + coff + n;
+            if (full && ((uintptr_t)dp & 15) == 0) {
+                if constexpr (sizeof(CT) == 4) {
+                    *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2_hw(v[2 * q], v[2 * q + 1]);
+                    *reinterpret_cast<u32x4_t*>(dp) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (n + e < N) Elem<CT>::st(dp + e, v[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();      // the next pass overwrites the staging rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
+    pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
+}
+
+template <typename CT, int VAR>
+__global__ __launch_bounds__(512) void gemm_tile5_kernel(
+    const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
+    using T = __hip_bfloat16;
+    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds5[];
+    {
+        const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
+        A += z1 * rm.a_z1 + z2 * rm.a_z2;
+        W += z1 * rm.w_z1 + z2 * rm.w_z2;
+        C += z1 * rm.c_z1 + z2 * rm.c_z2;
+        if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
+    }
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(wg, tiles_m, (int)gridDim.x / tiles_m, tm, tn);
+    const int m0 = tm * T5_M, n0 = tn * T5_N;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;    // wave tile: rows wr * 128 .., columns wc * 64 ..; group = wr
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: a half-tile = 128 LDS rows x 8 chunks of 16 bytes = 1024 chunks, 2 per thread; chunk c -> (row c >> 3, slot c & 7),
+    // LDS byte c * 16 inside the half; the SOURCE chunk of slot p is p ^ ((row >> 1) & 7) of the mapped tile row / column.
+    const T* pa[2][2];
+    const T* pw[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 512 + tid, r = c >> 3;
+            const int lch = (c & 7) ^ ((r >> 1) & 7);
+            const int m = min(m0 + (r >> 6) * 128 + hh * 64 + (r & 63), M - 1);
+            const T* rowp = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+            pa[hh][i] = rowp + lch * 8;
+            const int n = min(n0 + (r >> 5) * 64 + hh * 32 + (r & 31), N - 1);
+            pw[hh][i] = W + (long)n * rm.ldw + lch * 8;
+        }
+    const int wave_base = wave * 1024;
+    // half index inside a buffer: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order they are consumed in)
+    auto stage_half = [&](int buf, int h, const T* (&p)[2], int adv) {
+        unsigned char* base = lds5 + buf * T5_BUF + h * T5_HALF + wave_base;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p[i],
+                                             (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+            p[i] += adv;
+        }
+    };
+    // fragment byte offsets inside a half-tile: row * 128 + (((kh * 4 + lg) ^ (row >> 1 & 7)) << 4), row & 15 = l15 for every fragment
+    const int sw = (lg ^ (l15 >> 1)) << 4;
+    const int offa0 = T5_HALF + (wr * 64 + l15) * 128 + sw, offa1 = offa0 ^ 64;      // A0 of buffer 0, k-half 0 / 1
+    const int offb0 = (wc * 32 + l15) * 128 + sw, offb1 = offb0 ^ 64;                // B0 of buffer 0
+    bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+    auto read_a = [&](int buf, int ah) {
+        const unsigned char* s = lds5 + buf * T5_BUF + ah * (2 * T5_HALF);
+#pragma unroll
+        for (int ff = 0; ff < 4; ++ff) {
+            fa[ff][0] = *reinterpret_cast<const bf16x8_t*>(s + offa0 + ff * 2048);
+            fa[ff][1] = *reinterpret_cast<const bf16x8_t*>(s + offa1 + ff * 2048);
+        }
+    };
+    auto read_b = [&](int buf, int bh, bf16x8_t (&fb)[2][2]) {
+        const unsigned char* s = lds5 + buf * T5_BUF + bh * (2 * T5_HALF);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            fb[c][0] = *reinterpret_cast<const bf16x8_t*>(s + offb0 + c * 2048);
+            fb[c][1] = *reinterpret_cast<const bf16x8_t*>(s + offb1 + c * 2048);
+        }
+    };
+    // one quadrant: 64 rows (ah) x 32 columns (bh) x K = 64: 16 MFMAs, two of them per accumulator, eight apart
+#define S2S_T5_QUAD(AH, BH, FB)                                                                                           \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                  \
+        _Pragma("unroll") for (int ff = 0; ff < 4; ++ff)                                                                  \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                     \
+            acc[(AH) * 4 + ff][(BH) * 2 + c] =                                                                            \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ff][kh], FB[c][kh], acc[(AH) * 4 + ff][(BH) * 2 + c], 0, 0, 0); \
+    } while (0)
+    // end of a phase's load segment: everything staged up to four phases ago has landed for this wave; meet the other group; own
+    // fragment reads complete.  End of the multiply segment: meet again.
+#define S2S_T5_LOADS_DONE()                                  \
+    do {                                                     \
+        S2S_WAIT_VMCNT(8);                                   \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   \
+    } while (0)
+#define S2S_T5_MFMAS_DONE()                                  \
+    do {                                                     \
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);   \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        __builtin_amdgcn_s_barrier();                        \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+
+    const int nk = K / T5_BK;
+    // prologue: tile 0 complete, B0 / A0 of tile 1 (units 0 .. 5 of the staging sequence; phase g of the loop issues unit g + 6)
+    stage_half(0, 0, pw[0], 1 < nk ? T5_BK : 0);
+    stage_half(0, 1, pa[0], 1 < nk ? T5_BK : 0);
+    stage_half(0, 2, pw[1], 1 < nk ? T5_BK : 0);
+    stage_half(0, 3, pa[1], 1 < nk ? T5_BK : 0);
+    stage_half(1, 0, pw[0], 2 < nk ? T5_BK : 0);
+    stage_half(1, 1, pa[0], 2 < nk ? T5_BK : 0);
+    S2S_WAIT_VMCNT(8);                           // B0 / A0 of tile 0 have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (STAGGER) {
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto ktile = [&](auto bufc, int t) {
+        constexpr int b = decltype(bufc)::value;
+        const int adv1 = t + 2 < nk ? T5_BK : 0, adv2 = t + 3 < nk ? T5_BK : 0;
+        // phase 0
+        read_b(b, 0, fb0);
+        read_a(b, 0);
+        stage_half(b ^ 1, 2, pw[1], adv1);
+        S2S_T5_LOADS_DONE();
+        S2S_T5_QUAD(0, 0, fb0);
+        S2S_T5_MFMAS_DONE();
+        // phase 1
+        read_b(b, 1, fb1);
+        stage_half(b ^ 1, 3, pa[1], adv1);
+        S2S_T5_LOADS_DONE();
+        S2S_T5_QUAD(0, 1, fb1);
+        S2S_T5_MFMAS_DONE();
+        // phase 2
+        read_a(b, 1);
+        stage_half(b, 0, pw[0], adv2);
+        S2S_T5_LOADS_DONE();
+        S2S_T5_QUAD(1, 1, fb1);
+        S2S_T5_MFMAS_DONE();
+        // phase 3
+        stage_half(b, 1, pa[0], adv2);
+        S2S_T5_LOADS_DONE();
+        S2S_T5_QUAD(1, 0, fb0);
+        S2S_T5_MFMAS_DONE();
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nk) ktile(std::integral_constant<int, 0>{}, t);
+#undef S2S_T5_QUAD
+#undef S2S_T5_LOADS_DONE
+#undef S2S_T5_MFMAS_DONE
+    if constexpr (STAGGER) {
+        if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0 waits for group 1's last phase
+    }
+    S2S_WAIT_VMCNT(0);                           // the loads past the end of K still target the ring
+    __builtin_amdgcn_s_barrier();
+    tile256_epilogue<CT>(acc, lds5, bias, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
+}
+
 // ---- skinny (decode) GEMM --------------------------------------------------
 // M <= 64 rows (one per live session): pure weight streaming.  One workgroup of 8 waves owns a 16-column slab of
 // W over the WHOLE of K; the 8 waves split K, so every weight element is read exactly once, straight from HBM into
@@ -1237,6 +1536,30 @@ static bool tile4_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
            (long)cdiv(M, T4_M) * cdiv(N, T4_N) * nz >= 192;
 }
 
+// S2S_TILE5 = 1: the staggered 8-phase 256x256 kernel (round 5) takes the shapes tile4 serves (K a multiple of 64), = 2: every shape it can
+// run (parity tests: small / ragged shapes too); S2S_TILE5_VAR picks the
+// A/B arm (bit 0: lock-step, bit 1: no s_setprio)
+static int tile5_mode() {
+    static const int mode = [] {
+        const char* e = getenv("S2S_TILE5");
+        return e ? atoi(e) : 0;
+    }();
+    return mode;
+}
+static int tile5_var() {
+    static const int v = [] {
+        const char* e = getenv("S2S_TILE5_VAR");
+        return e ? atoi(e) & 3 : 0;
+    }();
+    return v;
+}
+template <typename T>
+static bool tile5_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
+    if (tile5_mode() <= 0 || sizeof(T) != 2 || ext || g.tap_len != 0 || K % T5_BK != 0) return false;
+    if (tile5_mode() >= 2) return M > 128;      // parity runs: every shape the kernel can take (the decode kernels keep M <= 128)
+    return K >= 2 * T5_BK && M >= 2048 && N >= 512 && (long)cdiv(M, T5_M) * cdiv(N, T5_N) * nz >= 192;
+}
+
 static bool tile3_disabled() {
     static const bool off = getenv("S2S_NO_TILE3") != nullptr;   // A/B switch for tools/bench_ops.py
     return off;
@@ -1311,6 +1634,31 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SK_MT
 #undef S2S_SK
 #undef S2S_SK1
+    } else if (tile5_ok<T>(g, M, N, K, nz, ext)) {
+        if constexpr (sizeof(T) == 2) {
+            const int tiles_m = cdiv(M, T5_M), tiles_n = cdiv(N, T5_N);
+            static bool attr5[64] = {};
+            int dev = 0;
+            S2S_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr5[dev]) {
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                if (dev >= 0 && dev < 64) attr5[dev] = true;
+            }
+            ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
+                           ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+            const int var5 = tile5_var();
+            if (var5 == 1)
+                launch_k(gemm_tile5_kernel<CT, 1>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
+                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            else if (var5 == 2)
+                launch_k(gemm_tile5_kernel<CT, 2>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
+                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            else
+                launch_k(gemm_tile5_kernel<CT, 0>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
+                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+        }
     } else if (tile4_ok<T>(g, M, N, K, nz, ext)) {
         if constexpr (sizeof(T) == 2) {
             const int tiles_m = cdiv(M, T4_M), tiles_n = cdiv(N, T4_N);
