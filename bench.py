@@ -174,10 +174,6 @@ def cpu_baseline_c1(iterations: int = 3, first_chunk_frames: int = CHUNK_FRAMES)
 
     node_cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
-    # (round 3 probed 4 .. 256 threads and kept the fastest: the figure then moved with the box's pick - 0.34 at 4 threads, 0.09 at 64.
-    # A FIXED count makes runs comparable across boxes: 32 threads, or every core of a smaller host)
-    cores = min(32, node_cores)
-    torch.set_num_threads(cores)
     wd = WhisperDims.tiny_en()
     wsd = _rand_whisper_sd(wd, g)
     audio = synth_audio(80000, 0)
@@ -195,7 +191,7 @@ def cpu_baseline_c1(iterations: int = 3, first_chunk_frames: int = CHUNK_FRAMES)
         OW.greedy_decode(wsd, enc, wd.n_heads, wd.dec_layers, [[1, 2]], eos=-1, max_new_tokens=32)
         return time.perf_counter() - t0
 
-    def tts_first_chunk(n):
+    def tts_frames(n):
         t1 = time.perf_counter()
         codes, _ = OT.talker_generate(tsd, td.talker_cfg(), td.predictor_cfg(), prompt, td.n_groups, n, td.codec_eos, pad_embed=pad, min_frames=n)
         t_gen = time.perf_counter() - t1
@@ -204,30 +200,41 @@ def cpu_baseline_c1(iterations: int = 3, first_chunk_frames: int = CHUNK_FRAMES)
         return t_gen, time.perf_counter() - t2
 
     with torch.no_grad():
-        stt_leg()                                        # warm-up (untimed) ...
-        t_gen1, _ = tts_first_chunk(1)                   # ... which also gives prefill + ONE frame, to separate the prefill from the per-frame cost
+        # Thread sweep (a fixed count is not the best CPU configuration - 4 threads measured 0.34 x real time against 0.09 at 64 in round
+        # 3): a short probe of both legs (STT leg + prefill and 2 frames) at each count of a FIXED set, every result recorded, the fastest kept.
+        sweep = {}
+        for c in [c for c in (4, 8, 16, 32, 64) if c <= node_cores] or [node_cores]:
+            torch.set_num_threads(c)
+            if not sweep:
+                stt_leg()                                # first touch of the weights (untimed)
+            a = stt_leg()
+            b, _ = tts_frames(2)
+            sweep[c] = round(a + b, 3)
+        cores = min(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
+        stt_leg()                                        # warm-up at the chosen count (untimed)
         stt, gen, cod = [], [], []
-        for _ in range(max(1, int(iterations))):
+        for _ in range(max(1, int(iterations))):         # the time-to-first-audio path
             stt.append(stt_leg())
-            a, b = tts_first_chunk(F)
+            a, b = tts_frames(F)
             gen.append(a)
             cod.append(b)
+        t_gen_full, t_codec_full = tts_frames(frames_full)      # the WHOLE reply, executed once: nothing priced
     ttfa = np.array(stt) + np.array(gen) + np.array(cod)
     t_stt, t_gen, t_codec = float(np.mean(stt)), float(np.mean(gen)), float(np.mean(cod))
-    per_frame = max(t_gen - t_gen1, 0.0) / max(F - 1, 1)
-    prefill = max(t_gen1 - per_frame, 0.0)
-    t_tts = prefill + per_frame * frames_full + t_codec * frames_full / F
+    t_tts = t_gen_full + t_codec_full
     total = t_stt + t_tts
     turn_audio = 5.0 + frames_full * FRAME_S
     return {"value": round(turn_audio / total, 3), "unit": "concurrent real-time sessions (C1 turn: 5 s utterance in + 5.04 s reply out / CPU seconds of its STT + TTS legs)",
             "cores": cores, "kind": "port", "node_cores": node_cores, "iterations": len(stt), "warmup": 1,
+            "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "baseline_threads": cores,
             "ttfa_ms": {"mean": round(float(ttfa.mean()) * 1e3, 1), "min": round(float(ttfa.min()) * 1e3, 1), "std": round(float(ttfa.std()) * 1e3, 1)},
             "stt_ms": {"mean": round(t_stt * 1e3, 1), "min": round(float(np.min(stt)) * 1e3, 1)},
-            "sample": f"CPU oracle (PyTorch fp32), not ggml / CTranslate2 (neither is installed): config C1 = one 5 s utterance; 1 warm-up + {len(stt)} iterations of the "
-                      f"time-to-first-audio path at FULL depth - STT leg Whisper tiny.en dims ({t_stt:.2f} s: log-mel + encoder + 32 greedy tokens), Qwen3-TTS-1.7B dims: talker "
-                      f"prefill of 70 rows + first {F} frames with all {td.t_layers} talker layers and the 15-group code predictor ({t_gen:.2f} s; {per_frame:.3f} s per frame, "
-                      f"prefill {prefill:.2f} s), codec decoder of that chunk ({t_codec:.2f} s).  Throughput: the remaining {frames_full - F} frames of the 5.04 s reply are priced "
-                      f"at the measured per-frame cost (identical work per frame) -> {t_tts:.1f} s TTS, {total:.1f} s per turn"}
+            "sample": f"CPU oracle (PyTorch fp32), not ggml / CTranslate2 (neither is installed): config C1 = one 5 s utterance at FULL depth.  Threads: the fastest of "
+                      f"{sorted(sweep)} on a short probe of both legs (seconds per probe: {sweep}) -> {cores}.  Time to first audio: 1 warm-up + {len(stt)} iterations of STT leg "
+                      f"(Whisper tiny.en dims, {t_stt:.2f} s: log-mel + encoder + 32 greedy tokens) + Qwen3-TTS-1.7B dims talker prefill of 70 rows and the first {F} frames "
+                      f"(all {td.t_layers} talker layers, 15-group code predictor; {t_gen:.2f} s) + codec decoder of that chunk ({t_codec:.2f} s).  Throughput: the whole "
+                      f"{frames_full}-frame (5.04 s) reply EXECUTED once - {t_gen_full:.1f} s frame loop + {t_codec_full:.1f} s codec decoder -> {total:.1f} s per turn"}
 
 
 def _rand_whisper_sd(dims, g):

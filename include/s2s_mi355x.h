@@ -269,14 +269,19 @@ int32_t s2s_whisper_decode_greedy(void* model, void* stream, int32_t B, const in
  * s2s_whisper_decode_greedy on that session (same kernels, same per-row arithmetic).  An engine runs either this loop or
  * s2s_whisper_decode_greedy at a time (they share the decoder's self-attention cache and step inputs).
  *   slots_config: the loop's masks (uint8 [vocab] each, optional) and eos - once, while no slot is live.
- *   encode_at:    s2s_whisper_encode for B sessions whose cross K|V go to slots slot0 .. slot0 + B - 1.
- *   slots_admit:  slots slot0 .. slot0 + n - 1 start decoding: prompt_dev int32 [n][P] (P <= 8, -1 = fill with the masked argmax),
- *                 max_new_dev int32 [n] per-session budgets, max_new_limit >= every budget (checked against max_target on the host).
+ * The library keeps a per-slot state (idle -> reserved by encode_at -> live after slots_admit -> idle after slots_release) and CHECKS the
+ * scheduler against it: every call below fails with S2S_ERR_ARG instead of overwriting a session's rows or desynchronising the count.
+ *   encode_at:    s2s_whisper_encode for B sessions whose cross K|V go to slots slot0 .. slot0 + B - 1; the slots must be idle and
+ *                 are RESERVED from here on (s2s_whisper_encode / _decode_greedy refuse while any slot is reserved or live).
+ *   slots_admit:  slots slot0 .. slot0 + n - 1 (reserved or idle, never live) start decoding: prompt_dev int32 [n][P] (P <= 8, -1 = fill
+ *                 with the masked argmax), max_new_dev int32 [n] per-session budgets, clamped on the device to 1 .. max_new_limit
+ *                 (P + max_new_limit is checked against max_target on the host).
  *   slots_step:   n_steps greedy steps over rows 0 .. rows - 1 (one captured graph per row count); idle and finished rows stand still.
  *   slots_collect: pack_dev int32 [rows][stride], stride = s2s_whisper_slots_pack_stride() = 2 + 8 + max_target:
  *                 {finished (0 | 1 eos | 2 budget), n_ids, filled prompt tokens [8] (0 = as given), ids [max_target]}; the filled tokens
  *                 and ids are written for finished rows only.
- *   slots_release: the slots are idle again (their cache rows are rewritten from position 0 by the next admission). */
+ *   slots_release: reserved / live slots become idle again (their cache rows are rewritten from position 0 by the next admission);
+ *                 releasing an idle slot is an error, except for the whole range (slot0 = 0, n = max_batch: drop everything). */
 int32_t s2s_whisper_slots_config(void* model, void* stream, const uint8_t* suppress_dev, const uint8_t* begin_suppress_dev,
                                  const uint8_t* prompt_fill_mask_dev, int32_t eos);
 int32_t s2s_whisper_encode_at(void* model, void* stream, const void* feats_dev, int32_t B, int32_t slot0);

@@ -39,6 +39,10 @@ int32_t s2s_op_gemm_dec_tune(int32_t enable, int32_t splitk, int32_t nt);
 int32_t s2s_op_gemm_decw_tune(int32_t enable, int32_t splitk, int32_t min_m);
 /* development: per-workgroup phase timestamps of the column-block / row-block decode kernels (8 x u64 per workgroup, 100 MHz), null = off */
 int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
+/* development: per-tile phase timestamps of the 256x256 staggered tile GEMM (csrc/gemm.hip gemm_tile5_kernel): 6 x u64 per tile of every
+ * following launch - {start, prologue landed, main loop done, epilogue issued} on the 100 MHz counter, HW_ID, XCC_ID - null = off
+ * (tools/tile5_phases.py) */
+int32_t s2s_op_gemm_tile_debug(void* dbg_dev);
 
 /* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
  * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */

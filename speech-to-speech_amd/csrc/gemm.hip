@@ -1170,12 +1170,17 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
     pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
 }
 
+// Persistent launch (PERSIST): gridDim.x = min(tiles, compute units) workgroups, each walks the logical tile ids blockIdx.x,
+// blockIdx.x + gridDim.x, ...  gridDim.x is a multiple of 8, so a workgroup's tiles keep the XCD the one-tile-per-workgroup launch
+// gives them (xcd_remap / tile_coords unchanged): what goes away is the workgroup launch between two tiles of a compute unit.
+// dbg (development, s2s_op_gemm_tile_debug): 6 x u64 per tile - {start, prologue landed, main loop done, epilogue issued, HW_ID, XCC_ID},
+// times on the 100 MHz counter - for tools/tile5_phases.py.
 template <typename CT, int VAR>
 __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, int tiles_total, RowMap rm, unsigned long long* dbg) {
     using T = __hip_bfloat16;
-    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0;
+    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0, PERSIST = (VAR & 4) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds5[];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
@@ -1184,14 +1189,17 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
         C += z1 * rm.c_z1 + z2 * rm.c_z2;
         if (residual) residual += z1 * rm.c_z1 + z2 * rm.c_z2;
     }
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(wg, tiles_m, (int)gridDim.x / tiles_m, tm, tn);
-    const int m0 = tm * T5_M, n0 = tn * T5_N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int wr = wave >> 2, wc = wave & 3;    // wave tile: rows wr * 128 .., columns wc * 64 ..; group = wr
+  for (int vt = blockIdx.x; vt < tiles_total; vt += gridDim.x) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (dbg) ts0 = __builtin_amdgcn_s_memrealtime();
+    const int wg = xcd_remap(vt, tiles_total);
+    int tm, tn;
+    tile_coords(wg, tiles_m, tiles_total / tiles_m, tm, tn);
+    const int m0 = tm * T5_M, n0 = tn * T5_N;
 
     f32x4_t acc[8][4];
 #pragma unroll
@@ -1286,6 +1294,7 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     S2S_WAIT_VMCNT(8);                           // B0 / A0 of tile 0 have landed
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if (dbg) ts1 = __builtin_amdgcn_s_memrealtime();
     if constexpr (STAGGER) {
         if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
     }
@@ -1332,7 +1341,16 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     }
     S2S_WAIT_VMCNT(0);                           // the loads past the end of K still target the ring
     __builtin_amdgcn_s_barrier();
+    if (dbg) ts2 = __builtin_amdgcn_s_memrealtime();
     tile256_epilogue<CT>(acc, lds5, bias, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
+    if (dbg && tid == 0) {
+        unsigned long long* d = dbg + ((long)blockIdx.y * tiles_total + vt) * 6;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memrealtime();
+        d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: wave / simd / pipe / cu / sh / se
+        d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+    }
+    if constexpr (PERSIST) __builtin_amdgcn_s_barrier();   // the next tile's prologue overwrites the epilogue's staging rows
+  }
 }
 
 // ---- skinny (decode) GEMM --------------------------------------------------
@@ -1549,10 +1567,26 @@ static int tile5_mode() {
 static int tile5_var() {
     static const int v = [] {
         const char* e = getenv("S2S_TILE5_VAR");
-        return e ? atoi(e) & 3 : 0;
+        return e ? atoi(e) & 7 : 0;
     }();
     return v;
 }
+// persistent arm (S2S_TILE5_VAR=4): workgroups per launch = compute units (a multiple of 8: one XCD per workgroup for all its tiles)
+static int tile5_persist_wgs() {
+    static const int n = [] {
+        if (const char* e = getenv("S2S_TILE5_WGS")) return max(8, atoi(e) / 8 * 8);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return max(8, cus / 8 * 8);
+    }();
+    return n;
+}
+static unsigned long long*& tile5_dbg() {
+    static unsigned long long* p = nullptr;
+    return p;
+}
+void tile5_set_debug(unsigned long long* dbg) { tile5_dbg() = dbg; }
+
 template <typename T>
 static bool tile5_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
     if (tile5_mode() <= 0 || sizeof(T) != 2 || ext || g.tap_len != 0 || K % T5_BK != 0) return false;
@@ -1644,20 +1678,22 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 if (dev >= 0 && dev < 64) attr5[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                            ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
             const int var5 = tile5_var();
-            if (var5 == 1)
-                launch_k(gemm_tile5_kernel<CT, 1>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
-            else if (var5 == 2)
-                launch_k(gemm_tile5_kernel<CT, 2>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
-            else
-                launch_k(gemm_tile5_kernel<CT, 0>, dim3(tiles_m * tiles_n, nz), dim3(512), T5_LDS, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            const int tiles = tiles_m * tiles_n;
+            unsigned long long* dbg = tile5_dbg();
+#define S2S_T5_LAUNCH(V, GRID)                                                                                            \
+    launch_k(gemm_tile5_kernel<CT, V>, dim3(GRID, nz), dim3(512), T5_LDS, st, (const T*)g.A, g.lda, (const T*)g.W, g.bias, \
+             g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, tiles, rm, dbg)
+            if (var5 == 1) S2S_T5_LAUNCH(1, tiles);
+            else if (var5 == 2) S2S_T5_LAUNCH(2, tiles);
+            else if (var5 == 4) S2S_T5_LAUNCH(4, min(tiles, tile5_persist_wgs()));
+            else S2S_T5_LAUNCH(0, tiles);
+#undef S2S_T5_LAUNCH
         }
     } else if (tile4_ok<T>(g, M, N, K, nz, ext)) {
         if constexpr (sizeof(T) == 2) {
@@ -1816,4 +1852,10 @@ extern "C" int32_t s2s_op_conv1d_causal_tm(void* stream, const void* x, const vo
     g.ab_dtype = ab_dtype; g.c_dtype = c_dtype; g.act = act;
     if (ksize > 1) { g.tap_len = Cin; g.tap_stride = (long)dilation * Cin; }
     return s2s::gemm_ex((hipStream_t)stream, g);
+}
+
+/* Development hook (include/s2s_mi355x_dev.h): phase timestamps of every following gemm_tile5_kernel launch, 6 x u64 per tile, or null. */
+extern "C" int32_t s2s_op_gemm_tile_debug(void* dbg_dev) {
+    s2s::tile5_set_debug(reinterpret_cast<unsigned long long*>(dbg_dev));
+    return S2S_OK;
 }

@@ -490,7 +490,7 @@ WideTune& wtune() {
         WideTune x;
         if (const char* e = getenv("S2S_DECW")) x.enable = atoi(e);
         if (const char* e = getenv("S2S_DECW_SPLITK")) x.splitk = atoi(e);
-        if (const char* e = getenv("S2S_DECW_MIN_M")) x.min_m = atoi(e);
+        if (const char* e = getenv("S2S_DECW_MIN_M")) x.min_m = atoi(e) < 65 ? 65 : atoi(e);     // gemm_dec() only offers this kernel M > 64: one predicate for the launch and for dec_out_parts()
         return x;
     }();
     return t;
@@ -549,7 +549,7 @@ void decw_set_tune(int enable, int splitk, int min_m) {
     WideTune& t = wtune();
     t.enable = enable;
     t.splitk = splitk;
-    if (min_m > 0) t.min_m = min_m;
+    if (min_m > 0) t.min_m = min_m < 65 ? 65 : min_m;       // (same clamp as the environment switch)
 }
 
 void decw_set_debug(unsigned long long* dbg) { wtune().dbg = dbg; }

@@ -75,7 +75,9 @@ struct Whisper {
         *slot_out = nullptr;
     unsigned char* smask = nullptr;     // [3][vocab]: suppress, begin-suppress, prompt-fill
     int slot_eos = -1;
-    int slots_live = 0;                 // host-side count of admitted, not yet released slots
+    int slots_live = 0;                 // host-side count of reserved + admitted slots (always == number of non-zero bytes of slot_live_map)
+    std::vector<unsigned char> slot_live_map;   // per slot: 0 idle, 1 reserved (s2s_whisper_encode_at wrote its cross K|V), 2 admitted to the token loop
+                                                // - the scheduler's contract is checked, not trusted
     std::map<int, hipGraphExec_t> slot_graphs;
     std::vector<void*> owned;
 };
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256) void whisper_slot_pick_kernel(const float* __r
     step_a[b] = step + 1;
 }
 
-__global__ void whisper_slot_admit_kernel(int slot0, int n, const int* __restrict__ prompts, int P, const int* __restrict__ maxnew, int* step_a, int* P_a,
+__global__ void whisper_slot_admit_kernel(int slot0, int n, const int* __restrict__ prompts, int P, const int* __restrict__ maxnew, int maxnew_limit, int* step_a, int* P_a,
                                           int* maxnew_a, int* active_a, int* prompt, int* fill, int* cur_ids, int* pos, int* out_len, int* finished) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -582,7 +584,8 @@ __global__ void whisper_slot_admit_kernel(int slot0, int n, const int* __restric
         prompt[b * WH_SLOT_PMAX + k] = k < P ? prompts[i * P + k] : 0;
         fill[b * WH_SLOT_PMAX + k] = 0;
     }
-    step_a[b] = 0; P_a[b] = P; maxnew_a[b] = maxnew[i]; active_a[b] = 1;
+    const int mn = maxnew[i];
+    step_a[b] = 0; P_a[b] = P; maxnew_a[b] = mn < 1 ? 1 : (mn > maxnew_limit ? maxnew_limit : mn); active_a[b] = 1;   // the row's out buffer holds tmax ids: never past the checked limit
     cur_ids[b] = prompts[i * P]; pos[b] = 0; out_len[b] = 0; finished[b] = 0;
 }
 
@@ -820,7 +823,15 @@ extern "C" int32_t s2s_whisper_encode_at(void* model, void* stream, const void* 
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m && m->finalized, "whisper_encode_at: model not finalized");
     S2S_REQUIRE(B > 0 && slot0 >= 0 && slot0 + B <= m->max_batch && feats_dev, "whisper_encode_at: slots %d .. %d outside 0 .. %d", slot0, slot0 + B, m->max_batch);
-    return encode(m, (hipStream_t)stream, feats_dev, B, slot0);
+    if (m->slot_live_map.empty()) m->slot_live_map.assign(m->max_batch, 0);
+    for (int i = 0; i < B; ++i)
+        S2S_REQUIRE(!m->slot_live_map[slot0 + i], "whisper_encode_at: slot %d is %s (its cross K|V belongs to another session)", slot0 + i,
+                    m->slot_live_map[slot0 + i] == 2 ? "live in the token loop" : "reserved by an earlier encoder pass");
+    const int rc = encode(m, (hipStream_t)stream, feats_dev, B, slot0);
+    if (rc) return rc;
+    for (int i = 0; i < B; ++i) m->slot_live_map[slot0 + i] = 1;      // reserved: the batch API (one mode at a time) refuses from here on
+    m->slots_live += B;
+    return S2S_OK;
 }
 
 extern "C" int32_t s2s_whisper_slots_admit(void* model, void* stream, int32_t slot0, int32_t n, const int32_t* prompt_dev, int32_t P,
@@ -830,10 +841,15 @@ extern "C" int32_t s2s_whisper_slots_admit(void* model, void* stream, int32_t sl
     S2S_REQUIRE(n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch && prompt_dev && max_new_dev, "whisper_slots_admit: bad arguments");
     S2S_REQUIRE(P >= 1 && P <= WH_SLOT_PMAX, "whisper_slots_admit: prefix of %d tokens (1 .. %d)", P, WH_SLOT_PMAX);
     S2S_REQUIRE(max_new_limit >= 1 && P + max_new_limit <= m->tmax, "whisper_slots_admit: P + max_new_tokens = %d exceeds %d target positions", P + max_new_limit, m->tmax);
-    whisper_slot_admit_kernel<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(slot0, n, prompt_dev, P, max_new_dev, m->slot_step, m->slot_P, m->slot_maxnew, m->slot_active,
+    if (m->slot_live_map.empty()) m->slot_live_map.assign(m->max_batch, 0);
+    for (int i = 0; i < n; ++i) S2S_REQUIRE(m->slot_live_map[slot0 + i] != 2, "whisper_slots_admit: slot %d is already live (double admit)", slot0 + i);
+    whisper_slot_admit_kernel<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(slot0, n, prompt_dev, P, max_new_dev, max_new_limit, m->slot_step, m->slot_P, m->slot_maxnew, m->slot_active,
                                                                          m->slot_prompt, m->slot_fill, m->cur_ids, m->pos, m->out_len, m->finished);
     S2S_LAUNCH_CHECK();
-    m->slots_live += n;
+    for (int i = 0; i < n; ++i) {
+        m->slots_live += m->slot_live_map[slot0 + i] == 0;      // (admission without s2s_whisper_encode_at: cross K|V written by other means)
+        m->slot_live_map[slot0 + i] = 2;
+    }
     return S2S_OK;
 }
 
@@ -871,9 +887,16 @@ extern "C" int32_t s2s_whisper_slots_collect(void* model, void* stream, int32_t 
 extern "C" int32_t s2s_whisper_slots_release(void* model, void* stream, int32_t slot0, int32_t n) {
     Whisper* m = (Whisper*)model;
     S2S_REQUIRE(m && m->finalized && m->slot_step && n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch, "whisper_slots_release: bad arguments");
+    if (m->slot_live_map.empty()) m->slot_live_map.assign(m->max_batch, 0);
+    const bool reset = slot0 == 0 && n == m->max_batch;          // the whole range = "drop everything" (scheduler abort): idle slots allowed
+    for (int i = 0; i < n && !reset; ++i)
+        S2S_REQUIRE(m->slot_live_map[slot0 + i], "whisper_slots_release: slot %d is neither reserved nor live (double release)", slot0 + i);
     whisper_slot_release_kernel<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(slot0, n, m->slot_active, m->finished, m->pos, m->cur_ids);
     S2S_LAUNCH_CHECK();
-    m->slots_live = m->slots_live > n ? m->slots_live - n : 0;
+    for (int i = 0; i < n; ++i) {
+        m->slots_live -= m->slot_live_map[slot0 + i] != 0;
+        m->slot_live_map[slot0 + i] = 0;
+    }
     return S2S_OK;
 }
 

@@ -15,6 +15,45 @@ from ..session_pool import SessionPool
 from ..text import load_tokenizer
 
 logger = logging.getLogger(__name__)
+# the 25 languages of Parakeet-TDT v3 (reference STT/parakeet_tdt_handler.py:41-67)
+SUPPORTED_LANGUAGES = ["en", "de", "fr", "es", "it", "pt", "nl", "pl", "ru", "uk", "cs", "sk", "hu", "ro", "bg", "hr", "sl", "sr", "da", "no", "sv", "fi", "et",
+                       "lv", "lt"]
+LINGUA_CODE_MAP = {"no": "nb"}          # lingua calls Norwegian "nb" (:70)
+MIN_LANGUAGE_ID_CHARS = 20              # shorter transcripts keep the previous language (:392-394)
+
+
+def lingua_language_detector() -> Any:
+    """text -> ISO 639-1 code | None over SUPPORTED_LANGUAGES with lingua-py, built (and its models preloaded) once per process like the
+    reference's module-level detector (:72-88); None when lingua is not installed - the handler then keeps `last_language`, which is
+    what the reference does without lingua (:386-388)."""
+    try:
+        from lingua import Language, LanguageDetectorBuilder
+    except ImportError:
+        return None
+    by_iso = {lang.iso_code_639_1.name.lower(): lang for lang in Language.all() if lang.iso_code_639_1 is not None}
+    langs = [by_iso[LINGUA_CODE_MAP.get(c, c)] for c in SUPPORTED_LANGUAGES if LINGUA_CODE_MAP.get(c, c) in by_iso]
+    det = LanguageDetectorBuilder.from_languages(*langs).with_preloaded_language_models().build()
+    back = {v: k for k, v in LINGUA_CODE_MAP.items()}
+
+    def detect(text: str):
+        found = det.detect_language_of(text)
+        if found is None:
+            return None
+        code = found.iso_code_639_1.name.lower()
+        return back.get(code, code)
+
+    return detect
+
+
+_detector_cache: list = []
+
+
+def default_language_detector() -> Any:
+    if not _detector_cache:
+        _detector_cache.append(lingua_language_detector())
+    return _detector_cache[0]
+
+
 PROGRESSIVE_WINDOW_S = 15.0      # STT/smart_progressive_streaming.py:44 max_window_size
 SENTENCE_BUFFER_S = 2.0          # :45 sentence_buffer
 SENTENCE_FINAL = (".", "?", "!", "\u3002", "\uff1f", "\uff01")
@@ -127,22 +166,57 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", compute_type: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, max_seconds: float = 30.0, enable_live_transcription: bool = False,
               live_transcription_update_interval: float = 0.5, gen_kwargs: dict | None = None, pool: SessionPool | None = None, batch_cap: int = 0,
-              **_ignored: Any) -> None:
-        self.language = language or "en"
+              language_detector: Any = "lingua", **_ignored: Any) -> None:
+        # language state exactly as the reference keeps it (STT/parakeet_tdt_handler.py:150-156): a fixed start language is reported as is,
+        # "auto" / None -> language ID on the transcript text, falling back to the last language seen
+        self.start_language = language
+        self.last_language = language if language and language != "auto" else "en"
+        self.language = self.last_language           # (kept: round-4 callers read it)
         self.enable_live_transcription = enable_live_transcription
+        self.processing_final = False
+        # text -> code hook: "lingua" = lingua-py when installed (the reference's detector), a callable = the caller's own, None = off
+        self.language_detector = default_language_detector() if language_detector == "lingua" else language_detector
         kind, key, _ = parse_model_name(model_name) if pool is None or "parakeet" not in getattr(pool, "_engines", {}) else ("pool", None, None)
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
+        self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
+        if self._owns_pool:
+            self.pool.attach(self)
         if int(batch_cap) > 0:
             self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("parakeet", lambda: build_parakeet_engine(model_name, device, compute_type, max_batch, max_seconds))
         self._live_model = PooledParakeetModel(self.pool, self.tokenizer, best_effort=True)
         self._windows: dict[Any, SentenceWindow] = {}
 
+    def _detect_language_from_text(self, text: str) -> str | None:
+        """Reference `_detect_language_from_text` (:379-403): no detector or fewer than 20 characters -> None (language ID on a short
+        utterance is noise); otherwise the detector's code."""
+        det = getattr(self, "language_detector", None)
+        if det is None or not text or len(text.strip()) < MIN_LANGUAGE_ID_CHARS:
+            return None
+        try:
+            return det(text)
+        except Exception as e:  # noqa: BLE001
+            logger.debug("language ID failed: %s", e)
+            return None
+
+    def _language_for(self, text: str) -> str:
+        """Language of a final transcript (:588-596 + :348-352): the fixed start language; else the detected one when it is supported
+        (and it becomes `last_language`); else `last_language`."""
+        start = getattr(self, "start_language", None)
+        last = getattr(self, "last_language", None) or getattr(self, "language", None) or "en"
+        code = start if start and start != "auto" else (self._detect_language_from_text(text) or last)
+        if code in SUPPORTED_LANGUAGES:
+            self.last_language = code
+            return code
+        return last
+
     def process(self, vad_audio: Any) -> Iterator[Any]:
         audio = vad_audio.audio
         windows = self.__dict__.setdefault("_windows", {})
         if vad_audio.mode == "progressive":
+            if getattr(self, "processing_final", False):
+                return     # a final of this unit is in flight: its progressive items are stale (:259-262)
             win = windows.get(vad_audio.turn_id)
             if win is None:
                 windows.clear()              # one live turn per pipeline unit
@@ -156,12 +230,37 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
                 fixed, active = upd
                 yield PartialTranscription(text=(fixed + " " + active).strip(), turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision)
             return
-        windows.pop(vad_audio.turn_id, None)
+        self.processing_final = True
         try:
-            res = self.pool.transcribe("parakeet", audio)
-            text = self.tokenizer.decode(res["ids"]).strip()
-        except Exception as e:  # noqa: BLE001
-            logger.error("Parakeet inference failed: %s", e)
-            text = ""
-        yield Transcription(text=text, language_code=self.language, turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision,
+            windows.pop(vad_audio.turn_id, None)
+            try:
+                res = self.pool.transcribe("parakeet", audio)
+                text = self.tokenizer.decode(res["ids"]).strip()
+                language_code = self._language_for(text)
+            except Exception as e:  # noqa: BLE001
+                logger.error("Parakeet inference failed: %s", e)
+                text, language_code = "", getattr(self, "last_language", None) or getattr(self, "language", "en")
+        finally:
+            self.processing_final = False
+        yield Transcription(text=text, language_code=language_code, turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision,
                             speech_stopped_at_s=vad_audio.created_at_s)
+
+    def on_session_end(self) -> None:
+        """Per-session state back to its start values (reference :642-648): reported language, live-partial windows, the final-in-flight
+        flag, and the completed-final bookkeeping of BaseSTTHandler."""
+        super().on_session_end()
+        start = getattr(self, "start_language", None)
+        self.last_language = start if start and start != "auto" else "en"
+        self.processing_final = False
+        self.__dict__.setdefault("_windows", {}).clear()
+        logger.debug("MI355X Parakeet session state reset")
+
+    def cleanup(self) -> None:
+        """Reference :636-640 deletes its model; here the model belongs to the device's SessionPool: the handler lets go of it, and the pool
+        closes its engines when the last handler that obtained it through `for_device` is gone."""
+        logger.info("Cleaning up %s", self.__class__.__name__)
+        self.__dict__.setdefault("_windows", {}).clear()
+        pool, self.pool = getattr(self, "pool", None), None
+        self._live_model = None
+        if pool is not None and getattr(self, "_owns_pool", False):
+            pool.detach(self)

@@ -5,12 +5,17 @@ pool.  Kept from the reference contract (tests/test_qwen3_tts_handler_backend.py
     tail zero-padded;
   * the cancel generation captured at the start of the utterance is checked between chunks;
   * the frame budget estimator (words / chars / CJK chars / punctuation -> seconds -> 12.5 Hz * 1.35 margin,
-    >= 360, multiple of the chunk size, <= cap) and the coalescing of already-queued TTSInputs of the same response."""
+    >= 360, multiple of the chunk size, <= cap) and the coalescing of already-queued TTSInputs of the same response;
+  * the three generation modes and their dispatch (:841-858): voice clone when a reference is set (`ref_spk` [+ `ref_rvq`, `ref_text`],
+    `xvec_only`), else custom voice (speaker [+ instruct]) or voice design (instruct) by the checkpoint's model type, else the
+    reference's "Base model requires a voice-clone reference" error; the per-session voice override (:506-553) and
+    `on_session_end()` / `cleanup()` (:1005-1034)."""
 
 from __future__ import annotations
 
 import logging
 import math
+import os
 import re
 import unicodedata
 from time import perf_counter
@@ -23,7 +28,7 @@ from ..boundary import (AUDIO_RESPONSE_DONE, PIPELINE_END, SESSION_END, Assistan
                         is_control_message)
 from ..checkpoints import TTS_DIMS, load_safetensors_dir, parse_model_name
 from ..session_pool import SessionPool
-from ..text import ByteTextFrontend
+from ..text import ByteTextFrontend, PromptTooLong
 from ..tts import AudioBlocker, TTSPrompt
 
 logger = logging.getLogger(__name__)
@@ -74,6 +79,43 @@ def resolve_voice(layout: Any, speaker: Optional[str], language: Optional[str]) 
     return spk_key, lang_key
 
 
+def infer_model_type(model_name: Any) -> str:
+    """`_infer_model_type_from_name` of the reference (:402-414): 'voicedesign' / 'customvoice' / 'base' in the model name, else 'base'."""
+    name = str(model_name or "").lower()
+    for needle, kind in (("voicedesign", "voice_design"), ("customvoice", "custom_voice"), ("base", "base")):
+        if needle in name:
+            return kind
+    return "base"
+
+
+def load_speaker_embedding(path: Any, width: int) -> np.ndarray:
+    """A precomputed speaker embedding (`qwen3_tts_ref_spk`): `.npy` (float vector) or raw little-endian float32 - `width` values, the
+    talker's row width (the x-vector AFTER the speaker encoder's projection).  The reference hands the path to qwentts.cpp, whose .spk
+    container is not documented offline: a file of any other size is refused, never reinterpreted."""
+    p = os.fspath(path)
+    v = np.load(p).astype(np.float32).reshape(-1) if p.endswith(".npy") else np.fromfile(p, dtype="<f4")
+    if v.shape[0] != width:
+        raise ValueError(f"{p}: {v.shape[0]} float32 values, expected the talker width {width} (a raw / .npy speaker embedding)")
+    return v
+
+
+def load_reference_codes(path: Any, n_groups: int) -> np.ndarray:
+    """Precomputed codec frames of the reference audio (`qwen3_tts_ref_rvq`): `.npy` int array [frames, groups] (or [groups, frames]) or
+    raw little-endian int32 laid out frame-major."""
+    p = os.fspath(path)
+    c = np.load(p) if p.endswith(".npy") else np.fromfile(p, dtype="<i4")
+    c = np.asarray(c, dtype=np.int64)
+    if c.ndim == 1:
+        if c.shape[0] % n_groups:
+            raise ValueError(f"{p}: {c.shape[0]} ids are not a whole number of {n_groups}-group frames")
+        c = c.reshape(-1, n_groups)
+    elif c.ndim == 2 and c.shape[1] != n_groups and c.shape[0] == n_groups:
+        c = c.T
+    if c.ndim != 2 or c.shape[1] != n_groups:
+        raise ValueError(f"{p}: expected [frames, {n_groups}] codec ids, got {c.shape}")
+    return c
+
+
 CJK_PATTERN = re.compile(r"[぀-ヿ㐀-䶿一-鿿가-힯豈-﫿\U00020000-\U0002fa1f]")
 
 
@@ -119,7 +161,8 @@ def build_tts_engine(model_name: str, device: str, dtype: str, max_batch: int, m
 
         eng.text_frontend = TableTextFrontend(text["text.embedding.weight"].numpy(), layout,
                                               tok if hasattr(tok, "encode") and not isinstance(tok, IdTextCodec) else None, proj,
-                                              codec_table=sd["talker.model.codec_embedding.weight"].float().numpy())
+                                              codec_table=sd["talker.model.codec_embedding.weight"].float().numpy(),
+                                              group_tables=[sd[f"code_predictor.model.codec_embedding.{g}.weight"].float().numpy() for g in range(dims.n_groups - 1)])
         return eng
     dims = TTS_DIMS[key]()
     sd = qwen3_tts_state_dict(dims, seed=seed or 5)
@@ -135,13 +178,29 @@ class MI355XQwen3TTSHandler(BaseHandler):
               speaker: str | None = None, language: str | None = "auto", instruct: str | None = None, streaming_chunk_size: int = 8,
               max_new_tokens: int = DEFAULT_MAX_NEW_TOKENS, blocksize: int = 512, max_batch: int = 64, batch_window_ms: float = 4.0,
               codec_context_frames: int = 25, lanes: int = 3, cancel_scope: Any = None, speculative_turns: Any = None, gen_kwargs: dict | None = None,
-              pool: SessionPool | None = None, lead_s: float = 0.0, admit_wait_ms: float = 0.0, **_ignored: Any) -> None:
+              pool: SessionPool | None = None, lead_s: float = 0.0, admit_wait_ms: float = 0.0, ref_audio: Any = None, ref_spk: Any = None,
+              ref_rvq: Any = None, ref_text: str | None = None, xvec_only: bool = False, non_streaming_mode: bool | None = None,
+              model_type: str | None = None, **_ignored: Any) -> None:
         self.should_listen = should_listen          # owned by the reference runtime; never touched here
+        self.model_name = model_name
+        self.ref_audio, self.ref_spk, self.ref_rvq, self.ref_text, self.xvec_only = ref_audio, ref_spk, ref_rvq, ref_text, bool(xvec_only)
+        # non_streaming_mode (reference arguments :103-108: "pre-fill the full target text before decode") is the only mode this engine
+        # has - the whole text is in the prefill; False cannot be honoured and is said so once
+        if non_streaming_mode is False:
+            logger.warning("mi355x-qwen3 always pre-fills the full text (non_streaming_mode=True); ignoring non_streaming_mode=False")
+        self.non_streaming_mode = True
+        self._model_type_override = model_type
         self.cancel_scope, self.speculative_turns = cancel_scope, speculative_turns
         self.streaming_chunk_size, self.max_new_tokens, self.blocksize = int(streaming_chunk_size), int(max_new_tokens), int(blocksize)
         self.speaker, self.language, self.instruct = speaker, language, instruct
+        # what on_session_end() restores (reference :206-209, :1005-1009)
+        self._initial_speaker, self._initial_ref_audio, self._initial_ref_spk, self._initial_ref_rvq = speaker, ref_audio, ref_spk, ref_rvq
+        self._voice_cache: dict = {}
+        self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms,
                                                   tts_chunk_size=self.streaming_chunk_size, tts_ctx_frames=codec_context_frames, tts_lanes=lanes)
+        if self._owns_pool:
+            self.pool.attach(self)
         if float(lead_s) > 0.0:             # paced frame loop (0 = eager, the pool's default)
             self.pool.configure(tts_lead_s=float(lead_s), tts_admit_wait_s=float(admit_wait_ms) * 1e-3)
         self.pool.ensure_engine("tts", lambda: build_tts_engine(model_name, device, dtype, max_batch, self.max_new_tokens, codec_context_frames,
@@ -153,7 +212,124 @@ class MI355XQwen3TTSHandler(BaseHandler):
         # case-insensitive speaker, first supported speaker when none is given
         layout = getattr(getattr(eng, "text_frontend", None), "layout", None)
         self._voice = resolve_voice(layout, speaker, language) if layout is not None else (None, None)
+        if self._has_voice_clone_reference():
+            self._voice_reference()      # a reference that cannot be loaded fails setup, not every turn
         self.pool.warm_tts_lanes()       # load + warm up synchronously, like the reference's setup()
+
+    # ---- generation modes (reference :402-414, :441-446, :506-553, :574-610, :841-858) -----------------------------------------------
+    def _layout(self) -> Any:
+        pool = getattr(self, "pool", None)
+        return getattr(getattr(pool.engine("tts"), "text_frontend", None), "layout", None) if pool is not None else None
+
+    def _model_type(self) -> str:
+        """The checkpoint's kind: an explicit `model_type` argument, else prompt_layout.json's `model_type`, else the reference's
+        inference from the model name (:402-414) when the name says anything."""
+        override = getattr(self, "_model_type_override", None)
+        if override:
+            return override
+        lay = self._layout()
+        if lay is not None and getattr(lay, "model_type", None):
+            return lay.model_type
+        name = str(getattr(self, "model_name", None) or "").lower()
+        if any(k in name for k in ("voicedesign", "customvoice", "base")):
+            return infer_model_type(name)
+        # no kind anywhere (synthetic models, exported test checkpoints): the reference's DEFAULT checkpoint is the CustomVoice one
+        # (arguments_classes/qwen3_tts_arguments.py) - plain text -> speech with the layout's first speaker, no reference needed
+        return "custom_voice"
+
+    def _supported_speakers(self) -> Optional[list[str]]:
+        lay = self._layout()
+        ids = getattr(lay, "speaker_ids", None) if lay is not None else None
+        return list(ids) if ids else None
+
+    def _has_voice_clone_reference(self) -> bool:
+        return bool(getattr(self, "ref_audio", None) or getattr(self, "ref_spk", None))
+
+    def _clear_cached_voice_reference(self) -> None:
+        self.ref_spk = None
+        self.ref_rvq = None
+
+    def _voice_reference(self) -> tuple[np.ndarray, Optional[np.ndarray]]:
+        """(speaker row, reference code rows | None) of the current voice-clone reference, loaded once per (ref_spk, ref_rvq, xvec_only).
+        A reference given only as AUDIO needs the speaker encoder and the codec ENCODER of the tokenizer - neither is on the path this
+        backend builds (SURVEY 8 a13 is the decoder): it is refused with the way out, not approximated."""
+        spk, rvq = getattr(self, "ref_spk", None), getattr(self, "ref_rvq", None)
+        if not spk:
+            raise ValueError("mi355x-qwen3 voice cloning needs a precomputed speaker embedding (qwen3_tts_ref_spk, and qwen3_tts_ref_rvq for "
+                             f"in-context cloning): extracting them from qwen3_tts_ref_audio={getattr(self, 'ref_audio', None)!r} takes the speaker "
+                             "encoder / codec encoder, which this backend does not implement")
+        xvec_only = bool(getattr(self, "xvec_only", False))
+        key = (os.fspath(spk), os.fspath(rvq) if rvq else None, xvec_only)
+        cache = self.__dict__.setdefault("_voice_cache", {})
+        if key not in cache:
+            eng = self.pool.engine("tts")
+            fe = eng.text_frontend
+            row = load_speaker_embedding(spk, int(eng.dims.t_hidden))
+            rows = None
+            if rvq and not xvec_only:
+                if not hasattr(fe, "code_rows"):
+                    raise ValueError("in-context voice cloning (qwen3_tts_ref_rvq) needs a checkpoint front-end; use xvec_only with a synthetic model")
+                rows = fe.code_rows(load_reference_codes(rvq, int(eng.dims.n_groups)))
+            cache.clear()
+            cache[key] = (row, rows)
+        return cache[key]
+
+    def _apply_session_voice_override(self, model_type: str, runtime_config: Any = None, response: Any = None) -> None:
+        """`response.audio.output.voice`, else `runtime_config.session.audio.output.voice` (reference :506-553).  Custom voice: a supported
+        speaker (case-insensitive) replaces the session's speaker and drops any clone reference; an unsupported name is ignored with a
+        warning.  Other kinds: the voice must be a reference file - here a `.spk` / `.npy` speaker embedding, since raw audio cannot be
+        encoded by this backend - else it is ignored with a warning."""
+        def _voice(obj: Any, *path: str) -> Optional[str]:
+            for name in path:
+                obj = getattr(obj, name, None)
+                if obj is None:
+                    return None
+            return str(obj) if obj else None
+
+        session_voice = _voice(response, "audio", "output", "voice") or _voice(runtime_config, "session", "audio", "output", "voice")
+        if not session_voice:
+            return
+        if model_type == "custom_voice":
+            supported = self._supported_speakers()
+            if supported is not None:
+                match = {s.lower(): s for s in supported}.get(session_voice.lower())
+                if match is None:
+                    logger.warning("Ignoring Qwen3-TTS session voice override %r because it is not a supported CustomVoice speaker. "
+                                   "Supported speakers: %s", session_voice, ", ".join(sorted(supported, key=str.lower)) or "unknown")
+                    return
+                session_voice = match
+            if session_voice != getattr(self, "speaker", None):
+                self._voice = None       # resolved again on the next prompt
+            self.speaker = session_voice
+            self.ref_audio = None
+            self._clear_cached_voice_reference()
+            return
+        if os.path.isfile(os.path.expanduser(session_voice)) and session_voice.lower().endswith((".spk", ".npy")):
+            self.ref_spk, self.ref_rvq, self.ref_audio = os.path.expanduser(session_voice), None, None
+            return
+        logger.warning("Ignoring Qwen3-TTS session voice override because it is not a speaker-embedding file path: %r", session_voice)
+
+    def on_session_end(self) -> None:
+        """Reference :1005-1009: the voice a session selected (speaker / clone reference) does not carry over to the next session of this
+        pipeline unit."""
+        self.speaker = getattr(self, "_initial_speaker", None)
+        self.ref_audio = getattr(self, "_initial_ref_audio", None)
+        self.ref_spk = getattr(self, "_initial_ref_spk", None)
+        self.ref_rvq = getattr(self, "_initial_ref_rvq", None)
+        self._voice = None
+        logger.debug("MI355X Qwen3-TTS session state reset")
+
+    def cleanup(self) -> None:
+        """Reference :1011-1034 deletes its model and empties the allocator cache; here the engines belong to the device's SessionPool: the
+        handler lets go, the pool closes them (weights, KV arenas, graphs) when its last `for_device` handler is gone."""
+        try:
+            self.__dict__.setdefault("_voice_cache", {}).clear()
+            pool, self.pool = getattr(self, "pool", None), None
+            if pool is not None and getattr(self, "_owns_pool", False) and pool.detach(self) and torch.cuda.is_available():
+                torch.cuda.empty_cache()
+            logger.info("MI355X Qwen3-TTS handler cleaned up")
+        except Exception as e:  # noqa: BLE001
+            logger.warning("Cleanup error: %s", e)
 
     def _estimate_max_new_tokens(self, text: Optional[str]) -> int:
         return estimate_max_new_tokens(text, self.streaming_chunk_size, self.max_new_tokens)
@@ -205,22 +381,47 @@ class MI355XQwen3TTSHandler(BaseHandler):
         return " ".join(parts).strip(), lang
 
     def _build_prompt(self, text: str) -> TTSPrompt:
+        """One utterance's prefill rows in the mode the reference's process() would pick (:847-858)."""
         eng = self.pool.engine("tts")
         fe = eng.text_frontend
-        if getattr(fe, "layout", None) is not None:      # checkpoint front-end: the session's voice / language select codec-side control rows
+        has_layout = getattr(fe, "layout", None) is not None
+        kw: dict = {}
+        lang = None
+        if has_layout:
             voice = getattr(self, "_voice", None)
-            if voice is None:                            # (handlers built without setup(): resolve on first use)
+            if voice is None:                            # (handlers built without setup(), or a session override: resolve on first use)
                 voice = self._voice = resolve_voice(fe.layout, getattr(self, "speaker", None), getattr(self, "language", None))
-            return TTSPrompt(fe.embed(text, eng.max_prompt, speaker=voice[0], language=voice[1]))
-        return TTSPrompt(fe.embed(text, eng.max_prompt))
+            lang = voice[1]
+            kw["language"] = lang
+        instruct = getattr(self, "instruct", None)
+        if self._has_voice_clone_reference():
+            row, ref_rows = self._voice_reference()
+            kw.update(speaker_row=row, ref_rows=ref_rows, ref_text=getattr(self, "ref_text", None) if ref_rows is not None else None)
+        else:
+            kind = self._model_type()
+            if kind == "custom_voice":
+                if has_layout:
+                    if getattr(fe.layout, "speaker_ids", None) and not self._voice[0]:
+                        raise ValueError("CustomVoice generation requires a speaker. Set qwen3_tts_speaker or use a voice-clone model with ref_audio.")
+                    kw["speaker"] = self._voice[0]
+                if instruct:
+                    kw["instruct"] = instruct
+            elif kind == "voice_design":
+                if instruct:
+                    kw["instruct"] = instruct
+            else:
+                raise ValueError("Qwen3-TTS Base model requires a voice-clone reference. Provide qwen3_tts_ref_audio or qwen3_tts_ref_spk, "
+                                 "or use a CustomVoice/VoiceDesign model.")
+        return TTSPrompt(fe.embed(text, eng.max_prompt, **kw))
 
     def _build_prompts(self, text: str) -> list[tuple[str, TTSPrompt]]:
         """One prompt per piece of text that fits the engine's prefill budget.  An over-long input is split at sentence ends, then at
         spaces (never truncated: the cut-off tail would silently not be spoken); the pieces are synthesised one after the other."""
         try:
             return [(text, self._build_prompt(text))]
-        except ValueError:
-            pass
+        except PromptTooLong:
+            if len(text) < 2:        # nothing left to split: the fixed rows alone exceed the budget
+                raise
         cut = -1
         mid = len(text) // 2
         for pat in (r"[.!?\u3002\uff01\uff1f]\s", r"[,;:]\s", r"\s"):
@@ -252,6 +453,8 @@ class MI355XQwen3TTSHandler(BaseHandler):
             speculative_turns.commit(tts_input.turn_id, tts_input.turn_revision)
         text, _lang = self._coalesce_pending_tts_input(tts_input)
         text = text or "Hello."          # the reference synthesises "Hello." for an empty response text
+        if getattr(tts_input, "runtime_config", None) is not None or getattr(tts_input, "response", None) is not None:
+            self._apply_session_voice_override(self._model_type(), tts_input.runtime_config, tts_input.response)
         gen = self.cancel_scope.generation if self.cancel_scope is not None else None
         start = perf_counter()
         try:

@@ -52,7 +52,10 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         self.last_language = language if language != "auto" else None
         kind, key, _ = parse_model_name(model_name) if pool is None or "whisper" not in getattr(pool, "_engines", {}) else ("pool", None, None)
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
+        self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
+        if self._owns_pool:
+            self.pool.attach(self)
         if int(batch_cap) > 0:
             self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("whisper", lambda: build_whisper_engine(model_name, device, torch_dtype, max_batch))
@@ -99,3 +102,19 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
             return
         yield Transcription(text=text, language_code=language_code, turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision,
                             speech_stopped_at_s=vad_audio.created_at_s)
+
+    def on_session_end(self) -> None:
+        """Per-session state back to its start values: the language carried from turn to turn (`last_language`, the fallback of an
+        auto-detect session) must not leak into the next session of this pipeline unit; BaseSTTHandler clears its completed-final set."""
+        super().on_session_end()
+        start = getattr(self, "start_language", None)
+        self.last_language = start if start != "auto" else None
+        logger.debug("MI355X Whisper session state reset")
+
+    def cleanup(self) -> None:
+        """The model belongs to the device's SessionPool (weights once per GPU): the handler lets go of it, the pool closes its engines
+        when the last handler that obtained it through `for_device` is gone."""
+        logger.info("Cleaning up %s", self.__class__.__name__)
+        pool, self.pool = getattr(self, "pool", None), None
+        if pool is not None and getattr(self, "_owns_pool", False):
+            pool.detach(self)

@@ -141,6 +141,7 @@ _DEV_SIGNATURES = {
     "s2s_prof_collect": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "s2s_op_gemm_dec_tune": [_i32, _i32, _i32],
     "s2s_op_gemm_dec_debug": [_vp],
+    "s2s_op_gemm_tile_debug": [_vp],
     "s2s_graph_bench_begin": [C.POINTER(_vp)],
     "s2s_graph_bench_end": [_i32, _i32, C.POINTER(C.c_double)],
     "s2s_op_gemm_decw_tune": [_i32, _i32, _i32],

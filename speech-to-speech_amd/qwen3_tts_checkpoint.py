@@ -53,6 +53,11 @@ class TTSPromptLayout:
     speaker_ids: dict[str, int] = field(default_factory=dict)   # speaker name -> codec-side token id
     language_ids: dict[str, int] = field(default_factory=dict)  # language code -> codec-side token id
     max_text_tokens: int = 126
+    # which of the three released model kinds the checkpoint is (reference `tts_model_type`, TTS/qwen3_tts_handler.py:574-580):
+    # "custom_voice" (speaker table), "voice_design" (instruct text describes the voice), "base" (voice clone from a reference)
+    model_type: str | None = None
+    instruct_bos: int | None = None             # text-side tokens wrapping the instruct text (None: the instruct tokens alone)
+    instruct_eos: int | None = None
 
     @classmethod
     def load(cls, path: str) -> "TTSPromptLayout":
@@ -235,9 +240,10 @@ class TableTextFrontend:
     embedding table, through the 2-layer projection when the checkpoint has one (text width != talker width)."""
 
     def __init__(self, table: np.ndarray, layout: TTSPromptLayout, tokenizer: Any = None, proj: list | None = None,
-                 codec_table: np.ndarray | None = None):
+                 codec_table: np.ndarray | None = None, group_tables: list | None = None):
         self.table, self.layout, self.tokenizer, self.proj = table.astype(np.float32), layout, tokenizer, proj
         self.codec_table = None if codec_table is None else np.asarray(codec_table, dtype=np.float32)
+        self.group_tables = [np.asarray(t, dtype=np.float32) for t in (group_tables or [])]      # code predictor tables, groups 1 .. G-1
         lay = layout
         if (lay.codec_prefix or lay.codec_bos is not None or lay.speaker_ids or lay.language_ids) and self.codec_table is None:
             # the layout asks for codec-side rows: without the codec embedding table they would silently be missing from the prefill
@@ -257,12 +263,33 @@ class TableTextFrontend:
             return list(self.tokenizer.encode(text))
         return list(text.encode("utf-8"))
 
-    def embed(self, text: str, max_tokens: int, speaker: str | None = None, language: str | None = None) -> np.ndarray:
+    def code_rows(self, codes: Any) -> np.ndarray:
+        """Reference codec frames [F, G] -> talker input rows: Σ_g table_g[codes[f, g]] - exactly what the frame loop feeds back for a frame
+        it generated itself (oracle/qwen3_tts.py talker_generate: sum of the G code embeddings), so in-context reference frames look like
+        the model's own history.  Group 0 = the talker's codec embedding, groups 1 .. G-1 = the code predictor's tables."""
+        if self.codec_table is None or not self.group_tables:
+            raise ValueError("reference codec frames need the codec embedding tables (front-end built without them)")
+        c = np.asarray(codes, dtype=np.int64)
+        if c.ndim != 2 or c.shape[1] != 1 + len(self.group_tables):
+            raise ValueError(f"reference codec frames must be [frames, {1 + len(self.group_tables)}], got {c.shape}")
+        if c.min() < 0 or c[:, 0].max() >= self.codec_table.shape[0] or any(c[:, g + 1].max() >= t.shape[0] for g, t in enumerate(self.group_tables)):
+            raise ValueError("reference codec frames hold ids outside the codebooks")
+        rows = self.codec_table[c[:, 0]].copy()
+        for g, t in enumerate(self.group_tables):
+            rows += t[c[:, g + 1]]
+        return rows.astype(np.float32)
+
+    def embed(self, text: str, max_tokens: int, speaker: str | None = None, language: str | None = None, instruct: str | None = None,
+              speaker_row: np.ndarray | None = None, ref_text: str | None = None, ref_rows: np.ndarray | None = None) -> np.ndarray:
         """Prefill rows, row i = text_side[i] + codec_side[i] (TTSPromptLayout):
-            [codec control rows: codec_prefix, then the language and the speaker token when given; text side = text_pad]
-            [text rows: text_bos, the text tokens, text_eos; no codec side]
+            [codec control rows: codec_prefix, then the language token and the speaker token when given - or `speaker_row`, an explicit
+             speaker embedding (voice clone: the x-vector projected to the talker width) in the speaker token's place; text side = text_pad]
+            [instruct rows (custom voice style / voice design): instruct_bos, the instruct tokens, instruct_eos; no codec side]
+            [text rows: text_bos, (the reference transcript,) the text tokens, text_eos; no codec side]
             [codec_bos row; text side = text_pad]
-        An unknown speaker / language name is an error (never a silent default voice)."""
+            [reference codec frames (voice clone in-context rows, `code_rows`); text side = text_pad]
+        An unknown speaker / language name is an error (never a silent default voice).  The control-row order and the in-context
+        placement are this repo's assumption about the absent qwen_tts prompt builder."""
         lay = self.layout
         ctrl = list(lay.codec_prefix)
         if language and language != "auto":
@@ -270,23 +297,36 @@ class TableTextFrontend:
                 if language not in lay.language_ids:
                     raise ValueError(f"language {language!r} is not in prompt_layout.json's language_ids {sorted(lay.language_ids)}")
                 ctrl.append(lay.language_ids[language])
-        if speaker:
+        if speaker and speaker_row is None:
             if speaker not in lay.speaker_ids:
                 raise ValueError(f"speaker {speaker!r} is not in prompt_layout.json's speaker_ids {sorted(lay.speaker_ids)[:16]}")
             ctrl.append(lay.speaker_ids[speaker])
         tail = [lay.codec_bos] if lay.codec_bos is not None else []
-        ids = self._ids(text)
-        n_fixed = (lay.text_bos is not None) + (lay.text_eos is not None) + len(ctrl) + len(tail)
+        ids = (self._ids(ref_text.strip() + " ") if ref_text else []) + self._ids(text)
+        ins = []
+        if instruct:
+            ins = ([lay.instruct_bos] if lay.instruct_bos is not None else []) + self._ids(instruct) + ([lay.instruct_eos] if lay.instruct_eos is not None else [])
+        n_ref = 0 if ref_rows is None else len(ref_rows)
+        n_fixed = (lay.text_bos is not None) + (lay.text_eos is not None) + len(ctrl) + len(tail) + len(ins) + (speaker_row is not None) + n_ref
         budget = min(lay.max_text_tokens, max_tokens - n_fixed)
         if len(ids) > budget:
-            raise ValueError(f"TTS input of {len(ids)} text tokens exceeds the prompt budget of {budget}; split the text into shorter sentences")
+            from .text import PromptTooLong
+
+            raise PromptTooLong(f"TTS input of {len(ids)} text tokens exceeds the prompt budget of {budget}; split the text into shorter sentences")
         ids = ([lay.text_bos] if lay.text_bos is not None else []) + ids + ([lay.text_eos] if lay.text_eos is not None else [])
-        rows = self._text_rows(ids)
-        if not ctrl and not tail:
+        rows = self._text_rows(ins + ids)
+        if not ctrl and not tail and speaker_row is None and not n_ref:
             return rows
-        pad = self._text_rows([lay.text_pad])[0] if lay.text_pad is not None else np.zeros(rows.shape[1], np.float32)
-        if self.codec_table.shape[1] != rows.shape[1]:
-            raise ValueError(f"codec embedding width {self.codec_table.shape[1]} != text row width {rows.shape[1]}")
-        head = self.codec_table[np.asarray(ctrl, dtype=np.int64)] + pad if ctrl else np.zeros((0, rows.shape[1]), np.float32)
-        foot = self.codec_table[np.asarray(tail, dtype=np.int64)] + pad if tail else np.zeros((0, rows.shape[1]), np.float32)
-        return np.concatenate([head, rows, foot]).astype(np.float32)
+        E = rows.shape[1]
+        pad = self._text_rows([lay.text_pad])[0] if lay.text_pad is not None else np.zeros(E, np.float32)
+        if (ctrl or tail) and self.codec_table.shape[1] != E:
+            raise ValueError(f"codec embedding width {self.codec_table.shape[1]} != text row width {E}")
+        head = self.codec_table[np.asarray(ctrl, dtype=np.int64)] + pad if ctrl else np.zeros((0, E), np.float32)
+        if speaker_row is not None:
+            sr = np.asarray(speaker_row, np.float32).reshape(-1)
+            if sr.shape[0] != E:
+                raise ValueError(f"speaker embedding has {sr.shape[0]} values, the talker rows are {E} wide")
+            head = np.concatenate([head, (sr + pad)[None]])
+        foot = self.codec_table[np.asarray(tail, dtype=np.int64)] + pad if tail else np.zeros((0, E), np.float32)
+        ref = (np.asarray(ref_rows, np.float32).reshape(-1, E) + pad) if n_ref else np.zeros((0, E), np.float32)
+        return np.concatenate([head, rows, foot, ref]).astype(np.float32)

@@ -145,9 +145,12 @@ def create_app(pool: Any, stt_model: str = "whisper", tokenizer: Any = None, stt
             return Response(float_pcm16_wav(pcm), media_type="audio/wav")
 
         def gen():
+            started = getattr(chunks, "started", None)      # (a pool that returns a plain iterator has no pacing signal)
             try:
                 for c in chunks:
-                    chunks.started.set()      # (no silence trimming on this path: the first chunk is the first audio)
+                    if started is not None:     # no silence trimming on this path: the first chunk is the first audio
+                        started.set()
+                        started = None
                     yield np.asarray(c, dtype="<i2").tobytes()
             finally:
                 cancel.set()         # client gone (generator closed) or stream complete: the lane stops generating for this request

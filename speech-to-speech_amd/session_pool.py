@@ -93,6 +93,27 @@ class SessionPool:
                         logger.warning("SessionPool(%s) already exists with %s=%s; ignoring %s=%s from a later handler", device, k, cur, k, v)
             return cls._pools[device]
 
+    def attach(self, handler: Any) -> None:
+        """A handler that obtained this pool through `for_device` registers itself; `detach` from the handler's cleanup() releases the
+        engines (weights, KV arenas, graphs) once the LAST handler of the device is gone - the pool-level equivalent of the reference
+        handlers' `del self.model` (STT/parakeet_tdt_handler.py:636-640, TTS/qwen3_tts_handler.py:1011-1034)."""
+        with self._pools_lock:
+            self.__dict__.setdefault("_attached", set()).add(id(handler))
+
+    def detach(self, handler: Any) -> bool:
+        """-> True when this was the last attached handler and the pool has been shut down (engines closed, device memory released)."""
+        with self._pools_lock:
+            att = self.__dict__.setdefault("_attached", set())
+            if id(handler) not in att:
+                return False
+            att.discard(id(handler))
+            last = not att and self._pools.get(self.device) is self
+            if last:
+                del self._pools[self.device]
+        if last:
+            self.shutdown()
+        return last
+
     def configure(self, *, tts_lead_s: float | None = None, tts_admit_wait_s: float | None = None, stt_max_batch: int | None = None) -> None:
         """Scheduling knobs a handler may set after the pool exists (the lanes read them every round).  One pool per GPU: a later handler
         asking for something else is told so, the first explicit setting stands."""
@@ -590,8 +611,9 @@ class SessionPool:
                 first = self._stt_q.get(timeout=0.05)
             except queue.Empty:
                 continue
-            if not isinstance(first, _STTRequest) or not hasattr(self._engines.get(first.model), "replica"):
-                self._stt_q.put(first)               # builds / stop / non-replicable engines: the first worker's
+            if (not isinstance(first, _STTRequest) or not hasattr(self._engines.get(first.model), "replica")
+                    or (self.stt_slots > 0 and hasattr(self._engines.get(first.model), "slots_step"))):
+                self._stt_q.put(first)               # builds / stop / non-replicable engines / models served by the slot loop: the first worker's
                 if first is _STOP:
                     return
                 time.sleep(0.002)
@@ -621,6 +643,18 @@ class SessionPool:
             for it in back:
                 self._stt_q.put(it)
             self._run_stt(reqs, model, eng)
+
+    @staticmethod
+    def _drop_cancelled(reqs: list) -> list:
+        """Requests cancelled while they waited leave the backlog WITH a terminal item on their chunk queue: a consumer that cancels and
+        keeps iterating must see the end of its stream, not block."""
+        keep = []
+        for r in reqs:
+            if r.cancelled.is_set():
+                r.chunks.put(None)
+            else:
+                keep.append(r)
+        return keep
 
     def _lane_engine(self, lane: int) -> Any:
         """Lane 0 streams on the pool's TTS engine; further lanes on replicas that share its weights (built on first use,
@@ -757,7 +791,7 @@ class SessionPool:
                             stop = True
                             break
                         backlog.append(it)
-                backlog = [r for r in backlog if not r.cancelled.is_set()]
+                backlog = self._drop_cancelled(backlog)
                 now = time.perf_counter()
                 can_admit = bool(backlog) and cb.free_slots > 0
                 waited = now - min(r.t_submit for r in backlog) if backlog else 0.0
@@ -873,7 +907,7 @@ class SessionPool:
                                 state["stop"] = True
                                 break
                             backlog.append(it)
-                    backlog = [r for r in backlog if not r.cancelled.is_set()]
+                    backlog = self._drop_cancelled(backlog)
                     n0 = len(backlog)
                     t_a = time.perf_counter()
                     backlog = nb.admit(backlog)
@@ -988,7 +1022,7 @@ class SessionPool:
             for it in drained:
                 if it is _STOP:
                     self._tts_q.put(_STOP)           # leave it for shutdown handling after this batch
-            batch = [r for r in [first] + [d for d in drained if d is not _STOP] if not r.cancelled.is_set()]
+            batch = self._drop_cancelled([first] + [d for d in drained if d is not _STOP])
             if not batch:
                 continue
             with self._stats_lock:

@@ -162,6 +162,11 @@ class WhisperVocab:
                    translate=int(translate) if translate is not None else None)
 
 
+class PromptTooLong(ValueError):
+    """The text does not fit the prefill budget: the handler splits it at sentence ends and synthesises the pieces one after the other
+    (every other ValueError of a front-end - unknown speaker, bad reference - is a configuration error and is NOT retried on pieces)."""
+
+
 class ByteTextFrontend:
     """Synthetic text side of the TTS prompt: UTF-8 bytes -> rows of a [258, E] table (256 bytes + bos + eos).
     (The real Qwen3-TTS chat template / text embedding + projection are in the unavailable qwen_tts package.)"""
@@ -170,10 +175,19 @@ class ByteTextFrontend:
         assert table.shape[0] == 258
         self.table = table.astype(np.float32)
 
-    def embed(self, text: str, max_tokens: int) -> np.ndarray:
-        raw = list(text.encode("utf-8"))
-        if len(raw) > max(0, max_tokens - 2):
+    def embed(self, text: str, max_tokens: int, instruct: str | None = None, speaker_row: np.ndarray | None = None, ref_text: str | None = None,
+              ref_rows: np.ndarray | None = None) -> np.ndarray:
+        """[speaker row] [bos instruct eos] [bos (ref_text) text eos] [reference code rows] - the synthetic stand-in of the voice modes'
+        prompt (voice design: instruct; voice clone: speaker row, reference text and, unless x-vector only, reference code rows)."""
+        raw = list(((ref_text.strip() + " ") if ref_text else "").encode("utf-8")) + list(text.encode("utf-8"))
+        ins = [256] + list(instruct.encode("utf-8")) + [257] if instruct else []
+        extra = len(ins) + (speaker_row is not None) + (0 if ref_rows is None else len(ref_rows))
+        if len(raw) > max(0, max_tokens - 2 - extra):
             # never truncate silently (the tail of the sentence would simply not be spoken): the handler splits long inputs
-            raise ValueError(f"TTS input of {len(raw)} bytes exceeds the prompt budget of {max_tokens - 2}; split the text into shorter sentences")
-        ids = [256] + raw + [257]
-        return self.table[np.asarray(ids)]
+            raise PromptTooLong(f"TTS input of {len(raw)} bytes exceeds the prompt budget of {max_tokens - 2 - extra}; split the text into shorter sentences")
+        ids = ins + [256] + raw + [257]
+        rows = self.table[np.asarray(ids)]
+        E = rows.shape[1]
+        head = np.asarray(speaker_row, np.float32).reshape(1, E) if speaker_row is not None else np.zeros((0, E), np.float32)
+        tail = np.asarray(ref_rows, np.float32).reshape(-1, E) if ref_rows is not None else np.zeros((0, E), np.float32)
+        return np.concatenate([head, rows, tail]) if len(head) or len(tail) else rows
