@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
 // 128-byte LDS rows: 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7) - the 16 lanes of every ds_read_b128 lane group
 // (MI355X_MICROARCH.md, LDS table) then cover the 16 distinct 16-byte slots of a 256-byte bank window.
 // VAR bit 0: no stagger (lock-step A/B arm); bit 1: no s_setprio.
-constexpr int T5_M = 256, T5_N = 256, T5_BK = 64, T5_HALF = 128 * 128, T5_BUF = 4 * T5_HALF, T5_LDS = 2 * T5_BUF;
+constexpr int T5_M = 256, T5_N = 256, T5_BK = 64, T5_HALF = 128 * 128, T5_BUF = 4 * T5_HALF, T5_LDS = 2 * T5_BUF + 2048;   // (+ 2 KiB: tail of the epilogue's staging rows)
 
 // the epilogue of the 256x256 kernels: wave tile 128 x 64 at (wm, wn), 8 passes of 16 rows staged through LDS (pitch 68 floats:
 // conflict-free fragment writes) and read back row-wise so that every lane moves 16 contiguous bytes of one output row.  The residual
@@ -1180,7 +1180,8 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, int tiles_total, RowMap rm, unsigned long long* dbg) {
     using T = __hip_bfloat16;
-    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0, PERSIST = (VAR & 4) != 0;
+    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0, PERSIST = (VAR & 4) != 0, EARLY = (VAR & 8) != 0;
+    static_assert(!EARLY || PERSIST, "the early prologue belongs to the persistent walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds5[];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
@@ -1193,36 +1194,29 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const int wr = wave >> 2, wc = wave & 3;    // wave tile: rows wr * 128 .., columns wc * 64 ..; group = wr
-  for (int vt = blockIdx.x; vt < tiles_total; vt += gridDim.x) {
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if (dbg) ts0 = __builtin_amdgcn_s_memrealtime();
-    const int wg = xcd_remap(vt, tiles_total);
-    int tm, tn;
-    tile_coords(wg, tiles_m, tiles_total / tiles_m, tm, tn);
-    const int m0 = tm * T5_M, n0 = tn * T5_N;
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
     // staging: a half-tile = 128 LDS rows x 8 chunks of 16 bytes = 1024 chunks, 2 per thread; chunk c -> (row c >> 3, slot c & 7),
     // LDS byte c * 16 inside the half; the SOURCE chunk of slot p is p ^ ((row >> 1) & 7) of the mapped tile row / column.
     const T* pa[2][2];
     const T* pw[2][2];
+    auto setup = [&](int v, int& m0_, int& n0_) {
+        const int wg = xcd_remap(v, tiles_total);
+        int tm, tn;
+        tile_coords(wg, tiles_m, tiles_total / tiles_m, tm, tn);
+        m0_ = tm * T5_M;
+        n0_ = tn * T5_N;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = i * 512 + tid, r = c >> 3;
-            const int lch = (c & 7) ^ ((r >> 1) & 7);
-            const int m = min(m0 + (r >> 6) * 128 + hh * 64 + (r & 63), M - 1);
-            const T* rowp = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
-            pa[hh][i] = rowp + lch * 8;
-            const int n = min(n0 + (r >> 5) * 64 + hh * 32 + (r & 31), N - 1);
-            pw[hh][i] = W + (long)n * rm.ldw + lch * 8;
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int c = i * 512 + tid, r = c >> 3;
+                const int lch = (c & 7) ^ ((r >> 1) & 7);
+                const int m = min(m0_ + (r >> 6) * 128 + hh * 64 + (r & 63), M - 1);
+                const T* rowp = rm.G < M ? A + (long)(m / rm.G) * rm.a_bs + (long)(m % rm.G) * lda : A + (long)m * lda;
+                pa[hh][i] = rowp + lch * 8;
+                const int n = min(n0_ + (r >> 5) * 64 + hh * 32 + (r & 31), N - 1);
+                pw[hh][i] = W + (long)n * rm.ldw + lch * 8;
+            }
+    };
     const int wave_base = wave * 1024;
     // half index inside a buffer: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order they are consumed in)
     auto stage_half = [&](int buf, int h, const T* (&p)[2], int adv) {
@@ -1285,12 +1279,28 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
 
     const int nk = K / T5_BK;
     // prologue: tile 0 complete, B0 / A0 of tile 1 (units 0 .. 5 of the staging sequence; phase g of the loop issues unit g + 6)
-    stage_half(0, 0, pw[0], 1 < nk ? T5_BK : 0);
-    stage_half(0, 1, pa[0], 1 < nk ? T5_BK : 0);
-    stage_half(0, 2, pw[1], 1 < nk ? T5_BK : 0);
-    stage_half(0, 3, pa[1], 1 < nk ? T5_BK : 0);
-    stage_half(1, 0, pw[0], 2 < nk ? T5_BK : 0);
-    stage_half(1, 1, pa[0], 2 < nk ? T5_BK : 0);
+    auto prologue = [&]() {
+        stage_half(0, 0, pw[0], 1 < nk ? T5_BK : 0);
+        stage_half(0, 1, pa[0], 1 < nk ? T5_BK : 0);
+        stage_half(0, 2, pw[1], 1 < nk ? T5_BK : 0);
+        stage_half(0, 3, pa[1], 1 < nk ? T5_BK : 0);
+        stage_half(1, 0, pw[0], 2 < nk ? T5_BK : 0);
+        stage_half(1, 1, pa[0], 2 < nk ? T5_BK : 0);
+    };
+    int m0 = 0, n0 = 0;
+    bool primed = false;                         // EARLY: the prologue of this tile was issued before the previous tile's epilogue
+  for (int vt = blockIdx.x; vt < tiles_total; vt += gridDim.x) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (dbg) ts0 = __builtin_amdgcn_s_memrealtime();
+    if (!primed) {
+        setup(vt, m0, n0);
+        prologue();
+    }
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     S2S_WAIT_VMCNT(8);                           // B0 / A0 of tile 0 have landed
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1342,14 +1352,25 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     S2S_WAIT_VMCNT(0);                           // the loads past the end of K still target the ring
     __builtin_amdgcn_s_barrier();
     if (dbg) ts2 = __builtin_amdgcn_s_memrealtime();
-    tile256_epilogue<CT>(acc, lds5, bias, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
+    int m1 = 0, n1 = 0;
+    if constexpr (EARLY) {                       // the ring is quiescent: the next tile's prologue flies under this tile's epilogue
+        const int nx = vt + (int)gridDim.x;
+        primed = nx < tiles_total;
+        if (primed) {
+            setup(nx, m1, n1);
+            prologue();
+        }
+    }
+    // the epilogue's staging rows: halves 2 / 3 of buffer 1 (+ 2 KiB past the ring) - the six half-tiles of a prologue stay clear of them
+    tile256_epilogue<CT>(acc, lds5 + T5_BUF + 2 * T5_HALF, bias, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
     if (dbg && tid == 0) {
         unsigned long long* d = dbg + ((long)blockIdx.y * tiles_total + vt) * 6;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memrealtime();
         d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: wave / simd / pipe / cu / sh / se
         d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
     }
-    if constexpr (PERSIST) __builtin_amdgcn_s_barrier();   // the next tile's prologue overwrites the epilogue's staging rows
+    if constexpr (EARLY) { m0 = m1; n0 = n1; }
+    if constexpr (PERSIST) __builtin_amdgcn_s_barrier();   // phase 0 of the next tile restages the epilogue's staging rows
   }
 }
 
@@ -1567,7 +1588,7 @@ static int tile5_mode() {
 static int tile5_var() {
     static const int v = [] {
         const char* e = getenv("S2S_TILE5_VAR");
-        return e ? atoi(e) & 7 : 0;
+        return e ? atoi(e) & 15 : 0;
     }();
     return v;
 }
@@ -1679,6 +1700,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 if (dev >= 0 && dev < 64) attr5[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
@@ -1692,6 +1714,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             if (var5 == 1) S2S_T5_LAUNCH(1, tiles);
             else if (var5 == 2) S2S_T5_LAUNCH(2, tiles);
             else if (var5 == 4) S2S_T5_LAUNCH(4, min(tiles, tile5_persist_wgs()));
+            else if (var5 == 12) S2S_T5_LAUNCH(12, min(tiles, tile5_persist_wgs()));
             else S2S_T5_LAUNCH(0, tiles);
 #undef S2S_T5_LAUNCH
         }
