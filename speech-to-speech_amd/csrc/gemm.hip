@@ -1170,6 +1170,139 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
     pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
 }
 
+// The same epilogue for the common case - an interior tile (no ragged edge), rows ldc apart (no row groups), 16-byte aligned rows - as
+// straight-line code.  tools/tile5_phases.py (round 5) showed the general epilogue above costing 17 us (bf16) / 34 us (f32 + residual)
+// per tile against a 33 us main loop at K = 1280: the activation switch was taken per ELEMENT (128 per lane, ~80 instructions each),
+// every store sat behind an s_waitcnt vmcnt(0) of the wavefront fences, and the residual of a pass was fetched only when the pass
+// began (one HBM round trip per pass).  Here the activation is a template argument, the LDS staging relies on the in-order LDS queue of
+// a wave (no fence, no wait on the stores), and the residual rows of pass p + 2 are in flight while pass p is stored.
+template <typename CT, int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {
+    if constexpr (ACT == S2S_ACT_GELU) return sizeof(CT) == 2 ? gelu_erf_bf16(v) : gelu_erf(v);
+    else if constexpr (ACT == S2S_ACT_SILU) return v / (1.0f + expf(-v));
+    else if constexpr (ACT == S2S_ACT_RELU) return fmaxf(v, 0.f);
+    else return v;
+}
+// the four bias values of a lane (columns j * 16 + lane % 16 of the wave tile), requested before anything else of the epilogue (ordinary
+// loads: the compiler waits for them - and only them - at their first use)
+__device__ __forceinline__ void tile256_bias_fetch(const float* __restrict__ bias, int N, int col0, int lane, float (&bv)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = 0.f;
+    if (bias) {
+        unsigned long long b = (unsigned long long)bias;
+        asm volatile("" : "+s"(b));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(b + (unsigned)min(col0 + j * 16 + (lane & 15), N - 1) * 4u);
+    }
+}
+template <typename CT, int ACT, bool RES, typename NextF>
+__device__ __forceinline__ void tile256_epilogue_fast(f32x4_t (&acc)[8][4], unsigned char* lds, const float* __restrict__ bias, int N, NextF&& next_prologue,
+                                                      const float* residual, CT* C, long ldc, long ldr, float alpha, int m0, int n0, int wm, int wn,
+                                                      int lane, int wave) {
+    constexpr int VEC = 16 / (int)sizeof(CT);   // 8 (bf16) / 4 (f32) columns per lane
+    constexpr int PITCH = 68;
+    constexpr int LPR = 64 / VEC;               // lanes per output row of the wave tile
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction
+    constexpr int NIT = 16 / RPI;               // instructions per 16-row pass
+    constexpr int RV = VEC / 4;                 // float4 per lane and row
+    constexpr int NL = NIT * RV;                // residual loads per pass and lane (4 for both output types)
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int cc = (lane % LPR) * VEC, rl = lane / LPR;
+    float* stg = reinterpret_cast<float*>(lds) + wave * (16 * PITCH);
+    float* swr = stg + lg * 4 * PITCH + l15;
+    const float* srd = stg + rl * PITCH + cc;
+    float bv[4];
+    tile256_bias_fetch(bias, N, n0 + wn, lane, bv);
+    // Global addresses = wave-uniform row base (a scalar register pair, made opaque so that it is not folded into 64 per-row vector
+    // addresses next to the 128 accumulators) + one 32-bit lane offset.  The LOADS are ordinary loads: the compiler counts their waits -
+    // vmcnt(loads issued since), which is what is wanted.  The STORES are inline assembly, invisible to that counting: with loads and
+    // stores of one counter in flight it would fall back to s_waitcnt vmcnt(0) before every use.  Loads return in order, stores do not
+    // return in order with them, and a count that only relies on the younger LOADS is safe whatever the stores did.
+    const unsigned c_lane = (unsigned)((rl * ldc + cc) * (long)sizeof(CT)), r_lane = (unsigned)((rl * ldr + cc) * 4);
+    const unsigned long long c_wave = (unsigned long long)C + (unsigned long long)(((long)(m0 + wm) * ldc + (n0 + wn)) * (long)sizeof(CT));
+    const unsigned long long r_wave = (unsigned long long)residual + (unsigned long long)(((long)(m0 + wm) * ldr + (n0 + wn)) * 4);
+    const unsigned long long c_step = (unsigned long long)(RPI * ldc * (long)sizeof(CT)), r_step = (unsigned long long)(RPI * ldr * 4);
+    f32x4_t rr[3][NIT][RV];
+    auto fetch = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (RES && p < 8) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                unsigned long long row = r_wave + (unsigned long long)(p * NIT + it) * r_step;
+                unsigned lane_off = r_lane;
+                asm volatile("" : "+s"(row), "+v"(lane_off));      // (scalar base + 32-bit lane offset survive instruction selection as such)
+#pragma unroll
+                for (int q = 0; q < RV; ++q) rr[p % 3][it][q] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4_t*>(row + lane_off + q * 16);    // (global, not flat)
+            }
+        }
+    };
+    auto pass = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p > 0) fetch(std::integral_constant<int, p + 2>{});
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swr[r * PITCH + j * 16] = apply_act_c<CT, ACT>(acc[p][j][r] + bv[j]) * alpha;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();          // (the LDS queue of a wave is in order: the reads below see the writes above)
+        f32x4_t t[NIT][RV];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int q = 0; q < RV; ++q) t[it][q] = *reinterpret_cast<const f32x4_t*>(srd + it * RPI * PITCH + q * 4);
+        if constexpr (RES) {                      // (requested two passes ago)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int q = 0; q < RV; ++q) t[it][q] += rr[p % 3][it][q];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const unsigned long long row = c_wave + (unsigned long long)(p * NIT + it) * c_step;
+            if constexpr (sizeof(CT) == 4) {
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(c_lane), "v"(t[it][0]), "s"(row) : "memory");   // (s_nop: the data registers may be rewritten next)
+            } else {
+                u32x4_t pk;
+                pk[0] = pack_bf16x2_hw(t[it][0][0], t[it][0][1]); pk[1] = pack_bf16x2_hw(t[it][0][2], t[it][0][3]);
+                pk[2] = pack_bf16x2_hw(t[it][1][0], t[it][1][1]); pk[3] = pack_bf16x2_hw(t[it][1][2], t[it][1][3]);
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(c_lane), "v"(pk), "s"(row) : "memory");
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();          // the next pass overwrites the staging rows (same queue: after the reads above)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 1>{});
+    fetch(std::integral_constant<int, 2>{});
+    next_prologue();
+    pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
+    pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
+}
+// entry: the straight-line variants for the epilogues the encoders use, the general one for everything else
+template <typename CT, typename NextF>
+__device__ __forceinline__ void tile256_store(f32x4_t (&acc)[8][4], unsigned char* lds, const float* __restrict__ bias, NextF&& next_prologue,
+                                              const float* residual, CT* C, long ldc, int M, int N, int act, const RowMap& rm, int m0, int n0,
+                                              int wm, int wn, int lane, int wave) {
+    const bool fast = rm.G >= M && m0 + T5_M <= M && n0 + T5_N <= N && (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)(ldc * sizeof(CT)) | (uintptr_t)(rm.ldr * 4)) & 15) == 0;
+    if (fast && act == S2S_ACT_NONE && residual)
+        tile256_epilogue_fast<CT, S2S_ACT_NONE, true>(acc, lds, bias, N, next_prologue, residual, C, ldc, rm.ldr, rm.alpha, m0, n0, wm, wn, lane, wave);
+    else if (fast && act == S2S_ACT_NONE && !residual)
+        tile256_epilogue_fast<CT, S2S_ACT_NONE, false>(acc, lds, bias, N, next_prologue, residual, C, ldc, rm.ldr, rm.alpha, m0, n0, wm, wn, lane, wave);
+    else if (fast && act == S2S_ACT_GELU && !residual)
+        tile256_epilogue_fast<CT, S2S_ACT_GELU, false>(acc, lds, bias, N, next_prologue, residual, C, ldc, rm.ldr, rm.alpha, m0, n0, wm, wn, lane, wave);
+    else if (fast && act == S2S_ACT_SILU && !residual)
+        tile256_epilogue_fast<CT, S2S_ACT_SILU, false>(acc, lds, bias, N, next_prologue, residual, C, ldc, rm.ldr, rm.alpha, m0, n0, wm, wn, lane, wave);
+    else {
+        next_prologue();
+        tile256_epilogue<CT>(acc, lds, bias, residual, C, ldc, M, N, act, rm, m0, n0, wm, wn, lane, wave);
+        // conditional loads of the general path may still be in flight as far as the compiler's counting can tell; left alone it protects
+        // the fragment registers of the NEXT tile's main loop with an s_waitcnt vmcnt(0) in every K tile (persistent arms)
+        S2S_WAIT_VMCNT(0);
+    }
+}
+
 // Persistent launch (PERSIST): gridDim.x = min(tiles, compute units) workgroups, each walks the logical tile ids blockIdx.x,
 // blockIdx.x + gridDim.x, ...  gridDim.x is a multiple of 8, so a workgroup's tiles keep the XCD the one-tile-per-workgroup launch
 // gives them (xcd_remap / tile_coords unchanged): what goes away is the workgroup launch between two tiles of a compute unit.
@@ -1178,9 +1311,9 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
 template <typename CT, int VAR>
 __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, int tiles_total, RowMap rm, unsigned long long* dbg) {
+    const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, int tiles_total, RowMap rm, unsigned long long* dbg, int spread_ticks) {
     using T = __hip_bfloat16;
-    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0, PERSIST = (VAR & 4) != 0, EARLY = (VAR & 8) != 0;
+    constexpr bool STAGGER = (VAR & 1) == 0, PRIO = (VAR & 2) == 0, PERSIST = (VAR & 4) != 0, EARLY = (VAR & 8) != 0, SPREAD = (VAR & 16) != 0;
     static_assert(!EARLY || PERSIST, "the early prologue belongs to the persistent walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds5[];
     {
@@ -1287,6 +1420,15 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
         stage_half(1, 0, pw[0], 2 < nk ? T5_BK : 0);
         stage_half(1, 1, pa[0], 2 < nk ? T5_BK : 0);
     };
+    if constexpr (SPREAD) {
+        // All compute units reach their epilogues together and the stores of 256 tiles then share ~2 TB/s of write bandwidth
+        // (tools/tile5_phases.py: 17 us per bf16 tile, 34 us with the f32 residual, against a 33 us main loop at K = 1280).  The
+        // persistent workgroups start spread over one tile period - position inside the XCD / 32 - and keep that phase, so only a
+        // fraction of the units store at any time.  (blockIdx.x >> 3 is small for the workgroups that walk one tile more.)
+        const long wait = (long)((blockIdx.x >> 3) & 31) * spread_ticks / 32;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < wait) __builtin_amdgcn_s_sleep(16);
+    }
     int m0 = 0, n0 = 0;
     bool primed = false;                         // EARLY: the prologue of this tile was issued before the previous tile's epilogue
   for (int vt = blockIdx.x; vt < tiles_total; vt += gridDim.x) {
@@ -1353,16 +1495,20 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     __builtin_amdgcn_s_barrier();
     if (dbg) ts2 = __builtin_amdgcn_s_memrealtime();
     int m1 = 0, n1 = 0;
-    if constexpr (EARLY) {                       // the ring is quiescent: the next tile's prologue flies under this tile's epilogue
-        const int nx = vt + (int)gridDim.x;
-        primed = nx < tiles_total;
-        if (primed) {
-            setup(nx, m1, n1);
+    // EARLY: the ring is quiescent, so the next tile's prologue flies under this tile's epilogue; the epilogue issues it AFTER its own
+    // first loads (bias, residual rows), which then never wait behind it.  It is issued unconditionally - the last tile of a workgroup
+    // re-requests its own first K tiles - so that every wait count of the epilogue is a constant (a conditional prologue makes the
+    // compiler fall back to s_waitcnt vmcnt(0)).
+    auto next_prologue = [&]() {
+        if constexpr (EARLY) {
+            const int nx = vt + (int)gridDim.x;
+            primed = nx < tiles_total;
+            setup(primed ? nx : vt, m1, n1);
             prologue();
         }
-    }
+    };
     // the epilogue's staging rows: halves 2 / 3 of buffer 1 (+ 2 KiB past the ring) - the six half-tiles of a prologue stay clear of them
-    tile256_epilogue<CT>(acc, lds5 + T5_BUF + 2 * T5_HALF, bias, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
+    tile256_store<CT>(acc, lds5 + T5_BUF + 2 * T5_HALF, bias, next_prologue, residual, C, ldc, M, N, act, rm, m0, n0, wr * 128, wc * 64, lane, wave);
     if (dbg && tid == 0) {
         unsigned long long* d = dbg + ((long)blockIdx.y * tiles_total + vt) * 6;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memrealtime();
@@ -1372,6 +1518,7 @@ __global__ __launch_bounds__(512) void gemm_tile5_kernel(
     if constexpr (EARLY) { m0 = m1; n0 = n1; }
     if constexpr (PERSIST) __builtin_amdgcn_s_barrier();   // phase 0 of the next tile restages the epilogue's staging rows
   }
+    if constexpr (EARLY) S2S_WAIT_VMCNT(0);      // (the last tile's prologue targets this workgroup's LDS)
 }
 
 // ---- skinny (decode) GEMM --------------------------------------------------
@@ -1575,20 +1722,21 @@ static bool tile4_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
            (long)cdiv(M, T4_M) * cdiv(N, T4_N) * nz >= 192;
 }
 
-// S2S_TILE5 = 1: the staggered 8-phase 256x256 kernel (round 5) takes the shapes tile4 serves (K a multiple of 64), = 2: every shape it can
-// run (parity tests: small / ragged shapes too); S2S_TILE5_VAR picks the
-// A/B arm (bit 0: lock-step, bit 1: no s_setprio)
+// S2S_TILE5 (default 1): the staggered 8-phase 256x256 kernel (round 5) takes the shapes tile4 served (K a multiple of 64); = 0: off
+// (gemm_tile4 / gemm_tile3 as in round 4), = 2: every shape it can run (parity tests: small / ragged shapes too).  S2S_TILE5_VAR picks
+// the arm: bit 0 lock-step, bit 1 no s_setprio, bit 2 persistent workgroups (default), bit 3 next tile's prologue under the epilogue,
+// bit 4 workgroups spread over one tile period (profiles/r05_tile5.txt: 4 and 12 are equal within noise, 28 is slower).
 static int tile5_mode() {
     static const int mode = [] {
         const char* e = getenv("S2S_TILE5");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 1;
     }();
     return mode;
 }
 static int tile5_var() {
     static const int v = [] {
         const char* e = getenv("S2S_TILE5_VAR");
-        return e ? atoi(e) & 15 : 0;
+        return e ? atoi(e) & 31 : 4;
     }();
     return v;
 }
@@ -1601,6 +1749,13 @@ static int tile5_persist_wgs() {
         return max(8, cus / 8 * 8);
     }();
     return n;
+}
+static int tile5_spread_pct() {
+    static const int v = [] {
+        const char* e = getenv("S2S_TILE5_SPREAD");
+        return e ? atoi(e) : 100;
+    }();
+    return v;
 }
 static unsigned long long*& tile5_dbg() {
     static unsigned long long* p = nullptr;
@@ -1701,6 +1856,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile5_kernel<CT, 28>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS));
                 if (dev >= 0 && dev < 64) attr5[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
@@ -1708,13 +1864,16 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             const int var5 = tile5_var();
             const int tiles = tiles_m * tiles_n;
             unsigned long long* dbg = tile5_dbg();
+            // one tile period on the 100 MHz counter: ~1.65 us per 64-wide K tile + the epilogue (S2S_TILE5_SPREAD: percent of it)
+            const int spread = (int)((long)(K / T5_BK * 165 + 600) * tile5_spread_pct() / 100);
 #define S2S_T5_LAUNCH(V, GRID)                                                                                            \
     launch_k(gemm_tile5_kernel<CT, V>, dim3(GRID, nz), dim3(512), T5_LDS, st, (const T*)g.A, g.lda, (const T*)g.W, g.bias, \
-             g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, tiles, rm, dbg)
+             g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, tiles, rm, dbg, spread)
             if (var5 == 1) S2S_T5_LAUNCH(1, tiles);
             else if (var5 == 2) S2S_T5_LAUNCH(2, tiles);
             else if (var5 == 4) S2S_T5_LAUNCH(4, min(tiles, tile5_persist_wgs()));
             else if (var5 == 12) S2S_T5_LAUNCH(12, min(tiles, tile5_persist_wgs()));
+            else if (var5 == 28) S2S_T5_LAUNCH(28, min(tiles, tile5_persist_wgs()));
             else S2S_T5_LAUNCH(0, tiles);
 #undef S2S_T5_LAUNCH
         }
