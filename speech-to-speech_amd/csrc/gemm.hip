@@ -23,7 +23,11 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace s2s {
 
@@ -52,18 +56,56 @@ __device__ __forceinline__ float gelu_erf_bf16(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-template <typename CT>
-__device__ __forceinline__ float apply_act_t(float v, int act) {
-    if constexpr (sizeof(CT) == 2) {
-        if (act == S2S_ACT_GELU) return gelu_erf_bf16(v);
-    }
+// GELU for a bf16 destination without transcendentals (quarter rate on the vector unit) and two elements per instruction:
+// gelu(x) = x * (0.5 + xc * Q(xc^2)), xc = clamp(x, -4, 4), Q = degree-8 polynomial fitted to 0.5 erf(x / sqrt 2) / x on [0, 4]
+// (tools/fit_gelu_poly.py: max |error| 1.6e-4 over all x, reached on the far negative tail where gelu itself is < 1.3e-4; <= 5.4e-5
+// inside [-4, 4]) - below the bf16 rounding of the result (2^-9 relative) wherever the activation is not negligible.  11 packed
+// instructions + 2 clamps per PAIR against ~16 scalar ones (2 of them v_rcp / v_exp) per element for gelu_erf_bf16: the fc1 epilogue of
+// the Whisper encoder ran 13 us per 256x256 tile against 4.5 us for the same tile without activation (tools/tile5_phases.py).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
+    f32x2_t xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f);
+    const f32x2_t t = xc * xc;
+    f32x2_t q = t * 8.524421446498565e-11f + -7.295211545965685e-09f;
+    q = q * t + 2.791634869936388e-07f;
+    q = q * t + -6.397717697836924e-06f;
+    q = q * t + 9.969574603019282e-05f;
+    q = q * t + -0.0011373028391972184f;
+    q = q * t + 0.009885039180517197f;
+    q = q * t + -0.06641801446676254f;
+    q = q * t + 0.3989247679710388f;
+    const f32x2_t phi = xc * q + 0.5f;
+    return x * phi;
+}
+
+template <typename CT, int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {
+    if constexpr (ACT == S2S_ACT_GELU) return sizeof(CT) == 2 ? gelu_erf_bf16(v) : gelu_erf(v);
+    else if constexpr (ACT == S2S_ACT_SILU) return v / (1.0f + expf(-v));
+    else if constexpr (ACT == S2S_ACT_RELU) return fmaxf(v, 0.f);
+    else return v;
+}
+// the activation switch taken ONCE around an epilogue's staging loops instead of once per element (f is called with the activation as a
+// compile-time constant; S2S_ACT_SNAKE is applied later, on the staged rows, and counts as none here)
+template <typename F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
     switch (act) {
-        case S2S_ACT_GELU: return gelu_erf(v);
-        case S2S_ACT_SILU: return v / (1.0f + expf(-v));
-        case S2S_ACT_RELU: return fmaxf(v, 0.f);
-        default: return v;
+        case S2S_ACT_GELU: f(std::integral_constant<int, S2S_ACT_GELU>{}); break;
+        case S2S_ACT_SILU: f(std::integral_constant<int, S2S_ACT_SILU>{}); break;
+        case S2S_ACT_RELU: f(std::integral_constant<int, S2S_ACT_RELU>{}); break;
+        default: f(std::integral_constant<int, S2S_ACT_NONE>{}); break;
     }
 }
+// LDS staging inside ONE wave: its LDS queue is in order, so a compiler barrier is all the write -> read (and read -> rewrite) hand-over
+// needs; the wavefront-scope fences used here until round 5 also made every pass wait for its global stores (s_waitcnt vmcnt(0)).
+#define S2S_WAVE_LDS_HANDOVER()                 \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_wave_barrier();        \
+        asm volatile("" ::: "memory");          \
+    } while (0)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -365,18 +407,19 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                 if (n + e < N) Elem<CT>::st(dp + e, w[e]);
         }
     };
+    auto half = [&](auto hc) {       // (compile-time half index: a runtime one under the activation dispatch sends the accumulators to scratch)
+        constexpr int h = decltype(hc)::value;
+        with_act(act, [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    stg[(ii * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[h * 2 + ii][j][r] + bv[j], act) * rm.alpha;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int r = 0; r < 4; ++r)
+                        stg[(ii * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_c<CT, ACTC>(acc[h * 2 + ii][j][r] + bv[j]) * rm.alpha;
+        });
+        S2S_WAVE_LDS_HANDOVER();
 #pragma unroll
         for (int i2 = 0; i2 < NIT / 2; ++i2) {
             const int it = h * (NIT / 2) + i2;
@@ -405,10 +448,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(
                 store_vec((CT*)rm.C2 + coff + n, w);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();      // the next half overwrites the staging rows
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+        S2S_WAVE_LDS_HANDOVER();      // the next half overwrites the staging rows
+    };
+    half(std::integral_constant<int, 0>{});
+    half(std::integral_constant<int, 1>{});
 }
 
 // ---- large-M tile GEMM: 256x128 tile, 8 waves, 3-stage LDS ring ----------------------------
@@ -658,17 +701,18 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
             const int nc = n0 + wn + j * 16 + l15;
             bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
         }
+        with_act(act, [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
+                    for (int r = 0; r < 4; ++r)
+                        stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_c<CT, ACTC>(acc[i][j][r] + bv[j]) * rm.alpha;
+        });
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    S2S_WAVE_LDS_HANDOVER();
     const int chmod = rm.sn_mod > 0 ? rm.sn_mod : (1 << 30);      // snake channel of column n (wraps at sn_mod)
     const int ch0 = n < N ? n % chmod : 0;
     float s1a[VEC], s1b[VEC], s2a[VEC], s2b[VEC];      // the lane's columns are fixed over the row loop
@@ -989,14 +1033,15 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
                     if (n + e < N) rres[it][e] = rp[e];
             }
         }
+        with_act(act, [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
 #pragma unroll
-        for (int j = 0; j < WNF; ++j)
+            for (int j = 0; j < WNF; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int r = 0; r < 4; ++r)
+                    stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_c<CT, ACTC>(acc[i][j][r] + bv[j]) * rm.alpha;
+        });
+        S2S_WAVE_LDS_HANDOVER();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int prow = it * RPI + lane / LPR;      // row inside the staged pass
@@ -1027,9 +1072,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
                     if (n + e < N) Elem<CT>::st(dp + e, v[e]);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();      // the next pass overwrites the staging rows
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        S2S_WAVE_LDS_HANDOVER();      // the next pass overwrites the staging rows
     };
     pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
@@ -1123,14 +1166,15 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
                     if (n + e < N) rres[it][e] = rp[e];
             }
         }
+        with_act(act, [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
 #pragma unroll
-        for (int j = 0; j < WNF; ++j)
+            for (int j = 0; j < WNF; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_t<CT>(acc[i][j][r] + bv[j], act) * rm.alpha;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int r = 0; r < 4; ++r)
+                    stg[(lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_c<CT, ACTC>(acc[i][j][r] + bv[j]) * rm.alpha;
+        });
+        S2S_WAVE_LDS_HANDOVER();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int prow = it * RPI + lane / LPR;      // row inside the staged pass
@@ -1161,9 +1205,7 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
                     if (n + e < N) Elem<CT>::st(dp + e, v[e]);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();      // the next pass overwrites the staging rows
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        S2S_WAVE_LDS_HANDOVER();      // the next pass overwrites the staging rows
     };
     pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
@@ -1176,13 +1218,6 @@ __device__ __forceinline__ void tile256_epilogue(f32x4_t (&acc)[8][4], unsigned 
 // every store sat behind an s_waitcnt vmcnt(0) of the wavefront fences, and the residual of a pass was fetched only when the pass
 // began (one HBM round trip per pass).  Here the activation is a template argument, the LDS staging relies on the in-order LDS queue of
 // a wave (no fence, no wait on the stores), and the residual rows of pass p + 2 are in flight while pass p is stored.
-template <typename CT, int ACT>
-__device__ __forceinline__ float apply_act_c(float v) {
-    if constexpr (ACT == S2S_ACT_GELU) return sizeof(CT) == 2 ? gelu_erf_bf16(v) : gelu_erf(v);
-    else if constexpr (ACT == S2S_ACT_SILU) return v / (1.0f + expf(-v));
-    else if constexpr (ACT == S2S_ACT_RELU) return fmaxf(v, 0.f);
-    else return v;
-}
 // the four bias values of a lane (columns j * 16 + lane % 16 of the wave tile), requested before anything else of the epilogue (ordinary
 // loads: the compiler waits for them - and only them - at their first use)
 __device__ __forceinline__ void tile256_bias_fetch(const float* __restrict__ bias, int N, int col0, int lane, float (&bv)[4]) {
@@ -1239,10 +1274,22 @@ __device__ __forceinline__ void tile256_epilogue_fast(f32x4_t (&acc)[8][4], unsi
     auto pass = [&](auto pc) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p > 0) fetch(std::integral_constant<int, p + 2>{});
+        if constexpr (ACT == S2S_ACT_GELU && sizeof(CT) == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) swr[r * PITCH + j * 16] = apply_act_c<CT, ACT>(acc[p][j][r] + bv[j]) * alpha;
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2_t v2 = {acc[p][j][r] + bv[j], acc[p][j][r + 1] + bv[j]};
+                    v2 = gelu_poly2(v2) * alpha;
+                    swr[r * PITCH + j * 16] = v2[0];
+                    swr[(r + 1) * PITCH + j * 16] = v2[1];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swr[r * PITCH + j * 16] = apply_act_c<CT, ACT>(acc[p][j][r] + bv[j]) * alpha;
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();          // (the LDS queue of a wave is in order: the reads below see the writes above)
         f32x4_t t[NIT][RV];
@@ -1770,6 +1817,11 @@ static bool tile5_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
     return K >= 2 * T5_BK && M >= 2048 && N >= 512 && (long)cdiv(M, T5_M) * cdiv(N, T5_N) * nz >= 192;
 }
 
+static bool gemm_trace() {
+    static const bool on = getenv("S2S_GEMM_TRACE") != nullptr;
+    return on;
+}
+
 static bool tile3_disabled() {
     static const bool off = getenv("S2S_NO_TILE3") != nullptr;   // A/B switch for tools/bench_ops.py
     return off;
@@ -1796,6 +1848,16 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     rm.C2 = g.C2; rm.sn2_a = g.snake2_a; rm.sn2_ib = g.snake2_ib;
     const bool ext = g.act == S2S_ACT_SNAKE || g.res_c || g.C2;      // tile-kernel epilogues only
     const int M = g.M, N = g.N, K = g.K;
+    if (gemm_trace()) {      // development (S2S_GEMM_TRACE=1): every distinct shape once, with the path it takes
+        static std::mutex mu;
+        static std::set<std::string> seen;
+        char key[256];
+        const char* path = M <= 128 && !(g.glu && M > 64) && !ext ? "skinny" : tile5_ok<T>(g, M, N, K, nz, ext) ? "tile5" : tile4_ok<T>(g, M, N, K, nz, ext) ? "tile4" : "tile3/tile";
+        snprintf(key, sizeof key, "gemm %s M=%d N=%d K=%d nz=%d G=%d tap=%d act=%d res=%d ext=%d%d%d in=%zu out=%zu", path, M, N, K, nz, rm.G, g.tap_len, g.act,
+                 g.residual != nullptr, g.act == S2S_ACT_SNAKE, g.res_c != nullptr, g.C2 != nullptr, sizeof(T), sizeof(CT));
+        std::lock_guard<std::mutex> lk(mu);
+        if (seen.insert(key).second) fprintf(stderr, "[s2s] %s\n", key);
+    }
     if (M <= 128 && !(g.glu && M > 64) && !ext) {
         const int MT = cdiv(M, 16);
         int NF = 1;
