@@ -9,7 +9,7 @@ for path in glob.glob(f"{src}/**/*counter_collection.csv", recursive=True):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
-            m = re.search(r"(gemm_tile3_kernel|gemm_tile_kernel|gemm_skinny_kernel|attn_mfma_kernel|attn_decode_kernel|attn_rows_kernel|norm_rows_kernel|snake_kernel)", name)
+            m = re.search(r"(gemm_tile5_kernel|gemm_tile3_kernel|gemm_tile_kernel|gemm_skinny_kernel|attn_mfma_kernel|attn_decode_kernel|attn_rows_kernel|norm_rows_kernel|snake_kernel)", name)
             fam = m.group(1) if m else "other"
             a = acc[fam][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"])
