@@ -797,14 +797,9 @@ constexpr int T4_M = 256, T4_N = 256, T4_BK = 32, T4_ROWB = 64, T4_A_BYTES = T4_
 // NWN = 4: 8 waves (2 x 4), wave tile 128 x 64 (44 flop per LDS byte, 128 accumulator registers, TWO waves per SIMD that hide
 //          each other's fragment reads).  (The 4-wave NWN = 2 variant - 128 x 128 wave tiles, one wave per SIMD - measured slower than
 //          gemm_tile3 in round 3 and is no longer instantiated.)
-// PIPE (S2S_TILE4_PIPE=1, round 4, UNMEASURED - off by default): the compiler's schedule of the plain loop reuses the two A-fragment
-// registers of a group of 8 MFMAs for the next group, so every k-step runs  6 reads - wait - 8 MFMA - 2 reads - wait - 8 MFMA - 2 reads -
-// wait ...  with each LDS latency exposed (ISA checked).  PIPE keeps the next group's two A fragments in their own registers (+ 8 VGPRs)
-// and pins the order  [2 reads of group g + 1] [8 MFMAs of group g]  with sched_group_barrier: three of the four waits of a k-step move
-// behind MFMA work.  PIPE = 2 additionally reads the FIRST operands of slab t + 1 (4 W + 2 A fragments) under the last MFMA group of slab t:
-// the top-of-step wait then requires slabs t AND t + 1 to have landed (two slabs of look-ahead in flight instead of three), and the
-// barrier that follows it makes slab t + 1 visible one step early.  Same arithmetic, same accumulation order in every variant.
-template <typename CT, int NWN, int PIPE = 0>
+// (Round 4's two software-pipelined variants of this main loop - S2S_TILE4_PIPE - measured within +-3 % of the plain loop on an MI355X,
+// profiles/r05_tile4_check.txt, and were removed when gemm_tile5 took over the encoder shapes.)
+template <typename CT, int NWN>
 __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
     const __hip_bfloat16* __restrict__ A, long lda, const __hip_bfloat16* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
@@ -892,75 +887,12 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
         offw[j] = T4_A_BYTES + rw * T4_ROWB + ((lg ^ ((rw >> 2) & 3)) << 4);
     }
     int stage = 0;
-    if constexpr (PIPE == 2) {
-        bf16x8_t nfw[WNF], nfa[2];           // first operands of the NEXT slab, read one step early
-        S2S_WAIT_VMCNT(4 * CPT);             // slab 0 has landed (1 and 2 in flight)
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int j = 0; j < WNF; ++j) nfw[j] = *reinterpret_cast<const bf16x8_t*>(lds4 + offw[j]);
-        nfa[0] = *reinterpret_cast<const bf16x8_t*>(lds4 + offa[0]);
-        nfa[1] = *reinterpret_cast<const bf16x8_t*>(lds4 + offa[1]);
-        for (int t = 0; t < nk; ++t) {
-            S2S_WAIT_VMCNT(2 * CPT);         // slabs t and t + 1 have landed; only slab t + 2 may still be in flight
-            __builtin_amdgcn_s_barrier();    // ... for every wave (slab t + 1 is readable from here on); every wave is done with slab t - 1
-            issue(stage >= 1 ? stage - 1 : T4_NST - 1, t + 3 < nk);
-            const unsigned char* sS = lds4 + stage * T4_STAGE;
-            const unsigned char* sN = lds4 + (stage + 1 == T4_NST ? 0 : stage + 1) * T4_STAGE;
-            bf16x8_t fw[WNF], fa[2][2];
-#pragma unroll
-            for (int j = 0; j < WNF; ++j) fw[j] = nfw[j];
-            fa[0][0] = nfa[0];
-            fa[0][1] = nfa[1];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) {
-                    fa[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8_t*>(sS + offa[2 * g + 2]);
-                    fa[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8_t*>(sS + offa[2 * g + 3]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                } else {                     // last group: the next slab's first operands (past the end of K: zero-page rows, never used)
-#pragma unroll
-                    for (int j = 0; j < WNF; ++j) nfw[j] = *reinterpret_cast<const bf16x8_t*>(sN + offw[j]);
-                    nfa[0] = *reinterpret_cast<const bf16x8_t*>(sN + offa[0]);
-                    nfa[1] = *reinterpret_cast<const bf16x8_t*>(sN + offa[1]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, WNF + 2, 0);
-                }
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < WNF; ++j)
-                        acc[2 * g + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][ii], fw[j], acc[2 * g + ii][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * WNF, 0);
-            }
-            stage = stage + 1 == T4_NST ? 0 : stage + 1;
-        }
-    } else {
     for (int t = 0; t < nk; ++t) {
         S2S_WAIT_VMCNT(4 * CPT);             // slab t has landed; the 2 x 2 CPT loads of slabs t + 1 and t + 2 may still be in flight
         __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading slab t - 1's stage
         issue(stage >= 1 ? stage - 1 : T4_NST - 1, t + 3 < nk);      // (t + 3) % 4 == (t - 1) % 4
         const unsigned char* sS = lds4 + stage * T4_STAGE;
-        if constexpr (PIPE == 1) {
-            bf16x8_t fw[WNF], fa[2][2];
-#pragma unroll
-            for (int j = 0; j < WNF; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(sS + offw[j]);
-            fa[0][0] = *reinterpret_cast<const bf16x8_t*>(sS + offa[0]);
-            fa[0][1] = *reinterpret_cast<const bf16x8_t*>(sS + offa[1]);
-            __builtin_amdgcn_sched_group_barrier(0x100, WNF + 2, 0);             // the k-step's first operands
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) {
-                    fa[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8_t*>(sS + offa[2 * g + 2]);
-                    fa[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8_t*>(sS + offa[2 * g + 3]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);           // next group's A fragments first ...
-                }
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < WNF; ++j)
-                        acc[2 * g + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][ii], fw[j], acc[2 * g + ii][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * WNF, 0);         // ... then this group's MFMAs (they cover the reads' latency)
-            }
-        } else {
+        {
             bf16x8_t fa[8], fw[WNF];
 #pragma unroll
             for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sS + offa[i]);
@@ -973,7 +905,6 @@ __global__ __launch_bounds__(128 * NWN) void gemm_tile4_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         stage = stage + 1 == T4_NST ? 0 : stage + 1;
-    }
     }
     S2S_WAIT_VMCNT(0);                       // the zero-page loads past the end of K still target the ring
     __builtin_amdgcn_s_barrier();
@@ -1754,14 +1685,6 @@ static int tile4_mode() {
     }();
     return mode;
 }
-// S2S_TILE4_PIPE = 1 | 2: the software-pipelined main loops of gemm_tile4_kernel (written at the end of round 4, UNMEASURED; default 0)
-static int tile4_pipe() {
-    static const int v = [] {
-        const char* e = getenv("S2S_TILE4_PIPE");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
 template <typename T>
 static bool tile4_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
     const bool on = tile4_mode() > 0;
@@ -1947,23 +1870,13 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
             int dev = 0;
             S2S_HIP_CHECK(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr4[dev]) {
-                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile4_kernel<CT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                 if (dev >= 0 && dev < 64) attr4[dev] = true;
             }
             ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
                            ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
-            const int pipe4 = tile4_pipe();      // (unmeasured variants 1 / 2, see the kernel; default 0)
-            if (pipe4 == 2)
-                launch_k(gemm_tile4_kernel<CT, 4, 2>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
-            else if (pipe4 == 1)
-                launch_k(gemm_tile4_kernel<CT, 4, 1>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
-            else
-                launch_k(gemm_tile4_kernel<CT, 4, 0>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
-                         (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+            launch_k(gemm_tile4_kernel<CT, 4>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
         }
     } else if (constexpr int BK3 = ROWB / (int)sizeof(T);
                (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && (long)cdiv(M, T3_M) * cdiv(N, T3_N) * nz >= 192 && !tile3_disabled()) {

@@ -1,0 +1,126 @@
+"""Row a6 on the GPU: the live-partial path of ``--stt mi355x-parakeet`` - ``PooledParakeetModel.transcribe(timestamps=True)`` and the
+``SentenceWindow`` policy (reference STT/smart_progressive_streaming.py:69-157) - on the REAL float32 engine behind a SessionPool,
+against the same adapter code driven by the CPU oracle (oracle/parakeet.py: log-mel -> FastConformer -> TDT greedy on that window alone).
+
+The float32 engine is step-exact against the oracle, so everything derived from its steps must be IDENTICAL: the window's text, every
+``timestamp["segment"]`` entry (text, start, end = encoder frame x 80 ms) and - over a turn growing in 0.5 s increments past the window
+cap - every (fixed, active) pair, including the calls where sentences are fixed and the shortened window is transcribed again.  Several
+sessions run their partials concurrently so that the pool batches windows of different lengths into one encoder pass (what a tick of
+live sessions looks like)."""
+
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as OL
+from oracle import parakeet as OP
+from speech_to_speech_amd.handlers.parakeet import PooledParakeetModel, SentenceWindow
+from speech_to_speech_amd.parakeet import ParakeetEngine
+from speech_to_speech_amd.session_pool import SessionPool
+from speech_to_speech_amd.synth import synth_audio
+from speech_to_speech_amd.synth_weights import ParakeetDims, parakeet_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+class _Codec:
+    """token id -> word; ids divisible by 5 end a sentence (so that random-weight transcripts have sentence structure)."""
+
+    def decode(self, ids):
+        return " ".join(f"w{i}" + ("." if i % 5 == 0 else "") for i in ids)
+
+
+class _OracleModel:
+    """The same ``model`` surface (transcribe(audio, timestamps)) computed by the CPU oracle on that window alone."""
+
+    def __init__(self, dims, sd, tok):
+        self.dims, self.sd, self.tok, self.calls = dims, sd, tok, 0
+
+    def steps(self, audio):
+        a = np.asarray(audio, dtype=np.float32)
+        if len(a) < 1280:
+            a = np.pad(a, (0, 1280 - len(a)))
+        feats = torch.from_numpy(OL.parakeet_logmel(a, 128, t_total=len(a) // 160 + 1)[0].astype(np.float32))[None]
+        with torch.no_grad():
+            enc, elen = OP.encode(self.sd, feats, torch.tensor([len(a) // 160]), self.dims.n_heads, self.dims.layers)
+            toks, durs, frames = OP.tdt_greedy(self.sd, enc, elen, self.dims.vocab, self.dims.blank)
+        keep = [k for k, t in enumerate(toks[0]) if t != self.dims.blank]
+        return [toks[0][k] for k in keep], [frames[0][k] * 0.08 for k in keep], [(frames[0][k] + max(durs[0][k], 1)) * 0.08 for k in keep]
+
+    def transcribe(self, audio, timestamps=False):
+        self.calls += 1
+        ids, starts, ends = self.steps(audio)
+        text = self.tok.decode(ids).strip()
+        if not timestamps:
+            return SimpleNamespace(text=text)
+        segs, cur = [], []                      # (restated here, not imported: a segment closes after a sentence-final token, the tail is one more)
+        for j, tid in enumerate(ids):
+            cur.append(j)
+            if self.tok.decode([tid]).strip().endswith("."):
+                segs.append(cur)
+                cur = []
+        if cur:
+            segs.append(cur)
+        return SimpleNamespace(text=text, timestamp={"segment": [{"segment": self.tok.decode([ids[j] for j in g]).strip(), "start": float(starts[g[0]]),
+                                                                  "end": float(ends[g[-1]])} for g in segs]})
+
+
+@pytest.fixture(scope="module")
+def rig():
+    dims = ParakeetDims.test_tiny()
+    sd = parakeet_state_dict(dims, seed=12, gain=1.5)
+    pool = SessionPool("cuda:0", max_batch=4, batch_window_ms=20.0)
+    pool.ensure_engine("parakeet", lambda: ParakeetEngine(dims, sd, dtype=torch.float32, max_batch=4, max_seconds=12.0))
+    yield dims, sd, pool, _Codec()
+    pool.shutdown()
+
+
+def test_timestamped_transcribe_matches_oracle_segments(rig):
+    dims, sd, pool, tok = rig
+    model, oracle = PooledParakeetModel(pool, tok), _OracleModel(dims, sd, tok)
+    for i, n in enumerate((48000, 30500, 96000, 8000)):
+        audio = synth_audio(n, 900 + i)
+        got, want = model.transcribe(audio, timestamps=True), oracle.transcribe(audio, timestamps=True)
+        segs = got.timestamp["segment"]
+        print(f"{n / 16000:.2f} s: {len(want.text.split())} words, {len(segs)} segments, ends {[round(s['end'], 2) for s in segs]}")
+        assert got.text == want.text
+        assert [s["segment"] for s in segs] == [s["segment"] for s in want.timestamp["segment"]]
+        assert [(round(s["start"], 4), round(s["end"], 4)) for s in segs] == [(round(s["start"], 4), round(s["end"], 4)) for s in want.timestamp["segment"]]
+        assert model.transcribe(audio).text == want.text
+
+
+def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig):
+    """Three sessions speak at once; each turn grows by 0.5 s per tick to 9 s with a 4 s window cap and a 1 s sentence buffer (the
+    reference's 15 s / 2 s scaled to a test-sized turn).  Every tick's (fixed, active) of every session equals the oracle-driven
+    SentenceWindow's, sentences get fixed along the way, and the pool served windows of different sessions in shared batches."""
+    dims, sd, pool, tok = rig
+    n_sessions, total, step = 3, 9 * 16000, 8000
+    turns = [synth_audio(total, 950 + i) for i in range(n_sessions)]
+    want = []
+    for a in turns:
+        w = SentenceWindow(_OracleModel(dims, sd, tok), max_window_s=4.0, sentence_buffer_s=1.0)
+        want.append([w.update(a[:n]) for n in range(step, total + 1, step)])
+        assert w.fixed, "the turn never fixed a sentence: the test would not cover the window move"
+    before = dict(pool.stats)
+    got = [[] for _ in turns]
+    barrier = threading.Barrier(n_sessions)
+
+    def session(i):
+        w = SentenceWindow(PooledParakeetModel(pool, tok), max_window_s=4.0, sentence_buffer_s=1.0)
+        for n in range(step, total + 1, step):
+            barrier.wait(timeout=120)           # a tick: every live session sends its partial now
+            got[i].append(w.update(turns[i][:n]))
+
+    ts = [threading.Thread(target=session, args=(i,)) for i in range(n_sessions)]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    for i in range(n_sessions):
+        assert got[i] == want[i], f"session {i}: first differing tick {next(k for k, (g, w_) in enumerate(zip(got[i], want[i])) if g != w_)}"
+    n_req = pool.stats["stt_requests"] - before.get("stt_requests", 0) if "stt_requests" in pool.stats else None
+    n_bat = pool.stats["stt_batches"] - before.get("stt_batches", 0)
+    print(f"{n_sessions} sessions x {total // step} ticks: {n_req} window transcriptions in {n_bat} encoder passes (largest batch {pool.stats['max_stt_batch']}); "
+          f"fixed sentences per session {[len(w[-1][0].split('.')) - 1 for w in want]}")
+    assert pool.stats["max_stt_batch"] >= 2 and n_bat < n_sessions * (total // step)       # partials of a tick share encoder passes
