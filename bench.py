@@ -100,6 +100,8 @@ def parse(argv=None):
     ap.add_argument("--tts-merge", type=int, default=None, help="STT turn-batches merged into ONE TTS run on a lane (default 4 for c3: 4 x 64 sessions = 256 rows per decode kernel; "
                     "experimental, default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sessions", type=int, default=8, help="c3: sessions of the batch decoded by a float32 engine with the SAME weights next to the bf16 engine "
+                    "(token agreement in the line's `parity`; 0 = off)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=25.0, help="measurement window of one open-loop probe")
     ap.add_argument("--confirm-probes", type=int, default=2, help="repeats (other arrival phases) of the probe at the sustained session count; a failed repeat steps the figure down")
@@ -620,6 +622,7 @@ def main():
     audios = [synth_audio(int(utt_s * 16000), sid) for sid in sessions]
     pcm, ns = pack_pcm(audios, dev)                                     # inputs resident in HBM before the timed region
 
+    parity = None
     if wdims is not None:
         from speech_to_speech_amd.whisper import WhisperEngine
 
@@ -634,6 +637,29 @@ def main():
             stt.encode(feats)
             ids, _ = stt.decode(prompt, eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
             return ids
+        # VERDICT r4 #2b: what the bf16 serving engine's greedy ids are worth on THIS batch - a float32 engine (the bit-exact policy,
+        # tests/test_full_depth_gpu.py) with the same weight values decodes the first sessions next to it; outside the timed region
+        if args.parity_sessions > 0 and rank == 0 and not args.probe_only:
+            try:
+                n_par = min(int(args.parity_sessions), B)
+                ref = WhisperEngine(wdims, None, torch.float32, max_batch=n_par, device=dev, engine_tensors={k: v.float() for k, v in stt._weights.items() if not k.endswith((".f", ".lf", ".lb", ".cs"))})      # (not the bf16 engine's derived decode layouts)
+                ref.encode(ref.features(audios[:n_par]))
+                want, _ = ref.decode(prompt[:n_par], eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
+                ref.close()
+                del ref
+                stt.encode(stt.features(audios[:n_par]))
+                got, _ = stt.decode(prompt[:n_par], eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
+                first = [next((k for k, (a, b) in enumerate(zip(g_, w_)) if a != b), len(w_)) for g_, w_ in zip(got, want)]
+                tot = sum(len(w_) for w_ in want)
+                parity = {"what": f"greedy ids of the bf16 engine vs a float32 engine with the same weight values, first {n_par} sessions of the batch, {args.decode_tokens} tokens each "
+                                  "(random-init weights: near-ties are as frequent as the logit statistics of an untrained model make them; the float32 engine itself is "
+                                  "bit-exact against the CPU oracle at this depth, tests/test_full_depth_gpu.py)",
+                          "sessions": n_par, "tokens": tot, "sessions_identical": sum(int(f == len(w_)) for f, w_ in zip(first, want)),
+                          "tokens_before_first_difference": sum(first), "agreement": round(sum(first) / max(tot, 1), 4),
+                          "positionwise_agreement": round(sum(int(a == b) for g_, w_ in zip(got, want) for a, b in zip(g_, w_)) / max(tot, 1), 4)}
+                torch.cuda.empty_cache()
+            except Exception as ex:  # pragma: no cover
+                parity = {"error": repr(ex)}
     else:
         from speech_to_speech_amd.parakeet import ParakeetEngine
         from speech_to_speech_amd.synth_weights import parakeet_state_dict
@@ -966,6 +992,8 @@ def main():
     }
     if boundary is not None:
         line["boundary"] = boundary
+    if parity is not None:
+        line["parity"] = parity
     if not args.no_cpu_baseline and world == 1:
         try:
             line["cpu_baseline"] = cpu_baseline_c1()
