@@ -581,8 +581,12 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------
 
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
+// DMA (round 5): the K and V^T tiles go global -> LDS directly (global_load_lds, the XOR swizzle in the per-lane SOURCE address) into a DOUBLE
+// buffer: tile t + 1 is requested right after the barrier that opens tile t, has the whole tile's MFMA + softmax time to land, and the loop needs
+// ONE barrier per tile instead of two (register staging: load -> compute -> barrier -> ds_write -> barrier).  K rows past the valid length are
+// clamped to the last valid row (their scores are masked below), V^T is zero-padded by the transpose; same arithmetic in both variants.
+template <int D, bool DMA>
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfmaParams p) {
     constexpr int KT = 64;                       // keys per tile
     constexpr int KROWB = D * 2;                 // bytes per K row in LDS
     constexpr int KCH = KROWB / 16;              // 16-byte chunks per K row (8 or 16)
@@ -591,7 +595,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
     constexpr int KPT = K_CHUNKS / 256, VPT = V_CHUNKS / 256;
     constexpr int KK = D / 32;                   // k-steps of the QK^T MFMA
     constexpr int DT = D / 16;                   // output d fragments
-    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KROWB + D * 128];
+    constexpr int TILE_LDS = KT * KROWB + D * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? 2 : 1) * TILE_LDS];
     unsigned char* sK = lds;
     unsigned char* sV = lds + KT * KROWB;
 
@@ -671,16 +676,52 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
         }
     };
 
+    // DMA variant: one wave instruction moves 64 lanes x 16 bytes = 1 KiB of LDS (K: 1024 / KROWB rows; V^T: 8 rows of 128 bytes), lane-linear in
+    // LDS, so the lane that fills slot (row, pos) fetches the source chunk pos ^ (row & mask) - the same image store_tile writes
+    constexpr int K_INSTR = KT * KROWB / 1024, V_INSTR = D * 128 / 1024;        // wave instructions per tile (8 / 16 and 8 / 16)
+    constexpr int KI_PW = K_INSTR / 4, VI_PW = V_INSTR / 4;                      // ... per wave
+    auto dma_tile = [&](int j0, int buf) {
+        unsigned char* base = lds + buf * TILE_LDS;
+#pragma unroll
+        for (int i = 0; i < KI_PW; ++i) {
+            const int blk = wave * KI_PW + i;                                    // 1 KiB block of the K tile
+            const int row = blk * (1024 / KROWB) + lane / KCH, pos = lane % KCH;
+            const int ch = pos ^ (row & (KCH - 1));
+            const __hip_bfloat16* src = Kb + (long)min(j0 + row, kv - 1) * p.k_rs + ch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + blk * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < VI_PW; ++i) {
+            const int blk = wave * VI_PW + i;                                    // 8 rows (d) of the V^T tile
+            const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+            const int ch = pos ^ (row & 7);
+            const __hip_bfloat16* src = Vb + (long)row * p.Tp + j0 + ch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + KT * KROWB + blk * 1024), 16, 0, 0);
+        }
+    };
     const int ntiles = (kv + KT - 1) / KT;
-    if (ntiles > 0) {
-        load_tile(0);
-        store_tile();
+    if constexpr (DMA) {
+        if (ntiles > 0) dma_tile(0, 0);
+    } else {
+        if (ntiles > 0) {
+            load_tile(0);
+            store_tile();
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * KT;
-        if (t + 1 < ntiles) load_tile(j0 + KT);
-
+        if constexpr (DMA) {
+            __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));      // vmcnt(0): this wave's part of tile t has landed ...
+            __builtin_amdgcn_s_barrier();                               // ... everyone's has; and every wave is done with tile t - 1's buffer
+            if (t + 1 < ntiles) dma_tile(j0 + KT, (t + 1) & 1);
+            sK = lds + (t & 1) * TILE_LDS;
+            sV = sK + KT * KROWB;
+        } else {
+            if (t + 1 < ntiles) load_tile(j0 + KT);
+        }
         // ---- S^T[key][q] for 4 key fragments x 2 query fragments
         f32x4_t s[4][2];
 #pragma unroll
@@ -808,10 +849,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnMfmaParams p) {
                 oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[1][k2], oacc[1][dt], 0, 0, 0);
             }
         }
-        __syncthreads();
-        if (t + 1 < ntiles) {
-            store_tile();
+        if constexpr (!DMA) {
             __syncthreads();
+            if (t + 1 < ntiles) {
+                store_tile();
+                __syncthreads();
+            }
         }
     }
     // ---- write O[q][h*D + d]: lane holds d = dt*16 + lg*4 + r (4 consecutive) for q = l15
@@ -836,8 +879,14 @@ int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
     dim3 grid(cdiv(p.Tq, 128), p.H, p.B);
     ProfScope prof(st, S2S_PROF_ATTN_MFMA, 4.0 * p.B * p.H * (double)p.Tq * p.Tk * D,
                    2.0 * p.B * p.H * ((double)p.Tq * D * 2 + (double)p.Tk * D * 2));
-    if (D == 64) launch_k(attn_mfma_kernel<64>, grid, dim3(256), 0, st, p);
-    else if (D == 128) launch_k(attn_mfma_kernel<128>, grid, dim3(256), 0, st, p);
+    static const bool dma = [] {                 // S2S_ATTN_DMA=0: the register-staged loop of rounds 2 - 4 (A/B)
+        const char* e = getenv("S2S_ATTN_DMA");
+        return !e || atoi(e) != 0;
+    }();
+    if (D == 64 && dma) launch_k(attn_mfma_kernel<64, true>, grid, dim3(256), 0, st, p);
+    else if (D == 128 && dma) launch_k(attn_mfma_kernel<128, true>, grid, dim3(256), 0, st, p);
+    else if (D == 64) launch_k(attn_mfma_kernel<64, false>, grid, dim3(256), 0, st, p);
+    else if (D == 128) launch_k(attn_mfma_kernel<128, false>, grid, dim3(256), 0, st, p);
     else return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
