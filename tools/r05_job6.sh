@@ -6,7 +6,7 @@ O=$R/gpurun_out/${1:-r5f}
 mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; tail -5 $O/tests_gpu.log
-SER="--serial --tts-merge 8 --steps 8 --warmup 8 --no-cpu-baseline --no-boundary"
+SER="--serial --tts-merge 8 --steps 8 --warmup 8 --no-cpu-baseline --no-boundary --parity-sessions 0"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o c3s -- python bench.py $SER > $O/bench_c3_serial_prof.json 2> $O/bench_c3_serial_prof.err
 timeout 300 python bench.py $SER --breakdown > $O/bench_c3_serial.json 2> $O/bench_c3_serial.err
 cp $(find $O/prof_serial -name "*kernel_stats.csv" | head -1) $O/c3_serial_kernel_stats.csv 2>/dev/null
