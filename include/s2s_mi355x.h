@@ -32,7 +32,7 @@ extern "C" {
 #define S2S_ERR_STATE (-3)
 #define S2S_ERR_UNSUPPORTED (-4)
 
-#define S2S_ABI_VERSION 3 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots */
+#define S2S_ABI_VERSION 4 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots; 4: s2s_logmel_parakeet_cached */
 
 /* element types of device buffers */
 #define S2S_F32 0
@@ -106,6 +106,17 @@ int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float* pcm_dev,
                             int64_t pcm_stride, const int32_t* n_samples_dev, int32_t B,
                             int32_t t_max, void* out_dev, int32_t out_dtype,
                             int32_t* n_frames_dev);
+
+/* The same features for a GROWING window (live partials: the reference re-transcribes the turn's window every 0.5 s,
+ * STT/smart_progressive_streaming.py:87-157, STT/parakeet_tdt_handler.py:259-330).  cache_dev: float32 [B][t_max][n_mels], owned by the
+ * caller, holding the UN-normalised log-mel frames of the rows' earlier, shorter prefixes; first_frame_dev int32[B]: frames below it are
+ * taken from the cache, frames from it on are computed and written to the cache (0 = compute everything).  A frame depends on the 400
+ * samples around it only, so with first_frame = max(0, (previous n_samples - 200) / 160) the result is bit-identical to
+ * s2s_logmel_parakeet on the whole window (tests/test_logmel_gpu.py); the per-feature normalisation always runs over the whole window.
+ * With B = 1 the cache layout does not depend on t_max: one buffer serves a stream as its window grows. */
+int32_t s2s_logmel_parakeet_cached(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
+                                   const int32_t* n_samples_dev, const int32_t* first_frame_dev, int32_t B, int32_t t_max,
+                                   float* cache_dev, void* out_dev, int32_t out_dtype, int32_t* n_frames_dev);
 
 /* ------------------------------------------------------------------------- *
  * Primitive operators (exported so the parity tests can pin each kernel

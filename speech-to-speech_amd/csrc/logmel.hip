@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     const float* __restrict__ basis, const float* __restrict__ melw,
     const float* __restrict__ window, int n_bin_tiles, int n_mel_tiles, int mel_ksteps,
     int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax, int time_major,
-    int window_samples, const float* __restrict__ norm) {
+    int window_samples, const float* __restrict__ norm, const int* __restrict__ first_frame = nullptr) {
+    // first_frame (s2s_logmel_parakeet_cached): frames below first_frame[b] are already in `out` from an earlier, shorter prefix of the same
+    // signal - a frame only depends on the 400 samples around it, so a tile that ends below it has nothing to do
+    if (first_frame && (int)blockIdx.x * FT + FT <= first_frame[blockIdx.y]) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* raw = smem;                       // RAW_LDS floats; later reused as the out stage
     float* win = smem + RAW_LDS;             // TAPS
@@ -565,6 +568,37 @@ extern "C" int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float
     else
         parakeet_normalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(
             f->scratch, n_samples_dev, f->stats, t_max, f->n_mels, (__hip_bfloat16*)out_dev, n_frames_dev, total);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+/* Live partials (reference STT/smart_progressive_streaming.py:87-157 re-transcribes a GROWING window): the un-normalised log-mel frames of the
+ * prefix are kept in a caller-owned cache and only the frames the new samples can change are computed. */
+extern "C" int32_t s2s_logmel_parakeet_cached(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
+                                              const int32_t* n_samples_dev, const int32_t* first_frame_dev, int32_t B, int32_t t_max,
+                                              float* cache_dev, void* out_dev, int32_t out_dtype, int32_t* n_frames_dev) {
+    Frontend* f = (Frontend*)frontend;
+    S2S_REQUIRE(f && f->kind == S2S_FRONTEND_PARAKEET, "not a Parakeet front-end");
+    S2S_REQUIRE(B >= 0 && B <= f->max_batch, "batch %d exceeds max_batch %d", B, f->max_batch);
+    S2S_REQUIRE(t_max > 0 && t_max <= f->max_frames, "t_max %d out of range (1..%d)", t_max, f->max_frames);
+    S2S_REQUIRE(out_dtype == S2S_F32 || out_dtype == S2S_BF16, "bad out_dtype %d", out_dtype);
+    if (B == 0) return S2S_OK;
+    S2S_REQUIRE(pcm_dev && n_samples_dev && first_frame_dev && cache_dev && out_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(t_max, FT), B);
+    logmel_tile_kernel<S2S_FRONTEND_PARAKEET><<<grid, 256, tile_lds_bytes(f), st>>>(
+        pcm_dev, (long)pcm_stride, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles,
+        f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, cache_dev, nullptr, 1, 0, nullptr, first_frame_dev);
+    S2S_LAUNCH_CHECK();
+    parakeet_stats_kernel<<<dim3(cdiv(f->n_mels, 32), B), dim3(32, 8), 0, st>>>(cache_dev, n_samples_dev, t_max, f->n_mels, f->stats);
+    S2S_LAUNCH_CHECK();
+    const long total = (long)B * t_max * f->n_mels;
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+    if (out_dtype == S2S_F32)
+        parakeet_normalize_kernel<float><<<blocks, 256, 0, st>>>(cache_dev, n_samples_dev, f->stats, t_max, f->n_mels, (float*)out_dev, n_frames_dev, total);
+    else
+        parakeet_normalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(cache_dev, n_samples_dev, f->stats, t_max, f->n_mels, (__hip_bfloat16*)out_dev,
+                                                                        n_frames_dev, total);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

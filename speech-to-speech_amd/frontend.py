@@ -127,12 +127,16 @@ class LogMelFrontend:
         return out
 
     def parakeet(self, pcm: torch.Tensor, n_samples: torch.Tensor, t_max: int,
-                 out_dtype: torch.dtype = torch.float32):
-        """-> (features [B, t_max, n_mels] zero beyond valid frames, n_frames int32 [B])."""
+                 out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None, n_frames: torch.Tensor | None = None):
+        """-> (features [B, t_max, n_mels] zero beyond valid frames, n_frames int32 [B]); `out` / `n_frames`: write into these rows of a
+        larger batch instead of new tensors."""
         assert self.kind == "parakeet"
         B = pcm.shape[0]
-        out = torch.empty((B, t_max, self.n_mels), dtype=out_dtype, device=self.device)
-        n_frames = torch.empty((B,), dtype=torch.int32, device=self.device)
+        if out is None:
+            out = torch.empty((B, t_max, self.n_mels), dtype=out_dtype, device=self.device)
+        if n_frames is None:
+            n_frames = torch.empty((B,), dtype=torch.int32, device=self.device)
+        assert out.is_contiguous() and out.shape == (B, t_max, self.n_mels) and out.dtype == out_dtype and n_frames.is_contiguous()
         with torch.cuda.device(self.device):
             native.check(
                 self._lib.s2s_logmel_parakeet(self._handle, native.stream_handle(), native.ptr(pcm), pcm.stride(0),
@@ -141,3 +145,16 @@ class LogMelFrontend:
                 "s2s_logmel_parakeet",
             )
         return out, n_frames
+
+    def parakeet_cached(self, pcm_row: torch.Tensor, n_samples: torch.Tensor, first_frame: torch.Tensor, t_max: int, cache: torch.Tensor,
+                        out_row: torch.Tensor, n_frames_row: torch.Tensor) -> None:
+        """One growing window (s2s_logmel_parakeet_cached, B = 1): pcm_row [1][cap] holds the window's samples so far, cache [cap_frames][n_mels]
+        float32 its un-normalised log-mel frames; frames from first_frame on are computed, the normalised features go to out_row [1][t_max][n_mels]."""
+        assert self.kind == "parakeet" and cache.dtype == torch.float32 and cache.is_contiguous() and out_row.is_contiguous()
+        with torch.cuda.device(self.device):
+            native.check(
+                self._lib.s2s_logmel_parakeet_cached(self._handle, native.stream_handle(), native.ptr(pcm_row), pcm_row.stride(0), native.ptr(n_samples),
+                                                     native.ptr(first_frame), 1, int(t_max), native.ptr(cache), native.ptr(out_row),
+                                                     native.dtype_code(out_row.dtype), native.ptr(n_frames_row)),
+                "s2s_logmel_parakeet_cached",
+            )

@@ -82,15 +82,18 @@ class PooledParakeetModel:
     def __init__(self, pool: SessionPool, tokenizer: Any, best_effort: bool = False):
         self.pool, self.tokenizer, self.best_effort = pool, tokenizer, best_effort
 
-    def transcribe(self, audio: Any, timestamps: bool = False) -> Any:
+    def transcribe(self, audio: Any, timestamps: bool = False, stream: Any = None, stream_key: Any = None) -> Any:
+        """`stream` (a parakeet.ProgressiveStream) marks the audio as the current state of ONE growing window that starts at `stream_key` in its
+        turn: the engine then uploads and featurises only what is new since the window's last partial (same transcript, bit for bit)."""
         from types import SimpleNamespace
 
+        extra = {} if stream is None else {"stream": stream, "stream_key": stream_key}
         if self.best_effort:
-            res = self.pool.try_transcribe("parakeet", audio, max_queue=self.pool.max_batch)
+            res = self.pool.try_transcribe("parakeet", audio, max_queue=self.pool.max_batch, **extra)
             if res is None:
                 raise BlockingIOError("pool busy")
         else:
-            res = self.pool.transcribe("parakeet", audio)
+            res = self.pool.transcribe("parakeet", audio, **extra)
         text = self.tokenizer.decode(res["ids"]).strip()
         if not timestamps:
             return SimpleNamespace(text=text)
@@ -104,11 +107,22 @@ class SentenceWindow:
     sentence; once that window reaches 15 s and holds more than one sentence, fix every sentence that ends more than 2 s
     before the window end, move the window start there and transcribe the shorter window again."""
 
-    def __init__(self, model: Any, max_window_s: float = PROGRESSIVE_WINDOW_S, sentence_buffer_s: float = SENTENCE_BUFFER_S):
+    def __init__(self, model: Any, max_window_s: float = PROGRESSIVE_WINDOW_S, sentence_buffer_s: float = SENTENCE_BUFFER_S, incremental: bool = False):
         self.model, self.max_window_s, self.sentence_buffer_s = model, max_window_s, sentence_buffer_s
         self.fixed: list[str] = []
         self.fixed_end_s = 0.0
         self.last_len = 0
+        # incremental (MI355X pool only): the window between two moves of its start is a growing prefix - one ProgressiveStream per window
+        self.stream = None
+        if incremental:
+            from ..parakeet import ProgressiveStream
+
+            self.stream = ProgressiveStream()
+
+    def _transcribe(self, audio: Any, start: int) -> Any:
+        if self.stream is None:
+            return self.model.transcribe(audio[start:], timestamps=True)
+        return self.model.transcribe(audio[start:], timestamps=True, stream=self.stream, stream_key=start)
 
     def update(self, audio: Any) -> tuple[str, str] | None:
         """-> (fixed_text, active_text), or None when there is nothing new to transcribe (< 0.5 s or no new samples)."""
@@ -117,7 +131,7 @@ class SentenceWindow:
             return None
         self.last_len = n
         window = audio[int(self.fixed_end_s * 16000):]
-        res = self.model.transcribe(window, timestamps=True)
+        res = self._transcribe(audio, int(self.fixed_end_s * 16000))
         segs = res.timestamp.get("segment", [])
         dur = len(window) / 16000.0
         if dur >= self.max_window_s and len(segs) > 1:
@@ -129,7 +143,7 @@ class SentenceWindow:
                 moved = self.fixed_end_s + sg["end"]
             if moved is not None:
                 self.fixed_end_s = moved
-                res = self.model.transcribe(audio[int(self.fixed_end_s * 16000):], timestamps=True)
+                res = self._transcribe(audio, int(self.fixed_end_s * 16000))
         return " ".join(self.fixed), res.text.strip()
 
 
@@ -221,7 +235,7 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
             if win is None:
                 windows.clear()              # one live turn per pipeline unit
                 live = self.__dict__.setdefault("_live_model", PooledParakeetModel(self.pool, self.tokenizer, best_effort=True))
-                win = windows[vad_audio.turn_id] = SentenceWindow(live)
+                win = windows[vad_audio.turn_id] = SentenceWindow(live, incremental=getattr(self, "incremental_partials", True))
             try:
                 upd = win.update(audio)
             except BlockingIOError:

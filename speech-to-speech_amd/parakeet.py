@@ -21,7 +21,7 @@ import logging
 
 import ctypes as C
 import math
-from typing import Mapping, Sequence
+from typing import Any, Mapping, Sequence
 
 import numpy as np
 import torch
@@ -103,6 +103,20 @@ def convert_parakeet_state_dict(sd: Mapping[str, torch.Tensor], dims: ParakeetDi
     return out
 
 
+class ProgressiveStream:
+    """Host-side token of ONE growing window of live partials (reference STT/smart_progressive_streaming.py:87-157 re-transcribes the window from the
+    last fixed sentence to "now" every 0.5 s).  The engine attaches the device state on first use: the window's samples so far (only the NEW
+    samples of a partial cross PCIe) and its un-normalised log-mel frames (only the frames the new samples can change are computed).  Everything
+    behind the log-mel - per-feature normalisation over the whole window, the full-context encoder, TDT - is recomputed, so a partial is
+    bit-identical to transcribing the whole window from scratch (tests/test_parakeet_progressive_gpu.py)."""
+
+    def __init__(self):
+        self.key = None            # the window's start in the turn: a new start is a new window
+        self.n = 0                 # samples on the device
+        self.pcm = self.cache = self.tail = None
+        self.stats = {"partials": 0, "samples_uploaded": 0, "samples_total": 0, "frames_computed": 0, "frames_total": 0, "restarts": 0}
+
+
 class ParakeetEngine:
     """One Parakeet-TDT replica on one GPU: log-mel + FastConformer encoder + TDT greedy decode for session batches."""
 
@@ -147,6 +161,35 @@ class ParakeetEngine:
         T = max(8, max(len(a) for a in audios) // 160 + 1)
         feats, nf = self.frontend.parakeet(pcm, ns, T, out_dtype=self.dtype)
         return feats, nf, T
+
+    def stream_features(self, st: ProgressiveStream, audio: np.ndarray, key: Any, t_max: int, out_row: torch.Tensor, nf_row: torch.Tensor) -> None:
+        """Features of a growing window into row `out_row` [1][t_max][n_mels] of a batch: uploads the samples that are new since the stream's last
+        partial and computes the log-mel frames they can change (frame t depends on samples t * 160 - 200 .. t * 160 + 199 and, through the
+        pre-emphasis, one more to the left), the rest comes from the stream's cache."""
+        n = len(audio)
+        cap = (self.max_feat_frames - 1) * 160
+        assert 0 < n <= cap
+        same = (st.pcm is not None and st.key == key and st.n > 0 and n >= st.n
+                and np.array_equal(np.asarray(audio[max(0, st.n - 64):st.n], dtype=np.float32), st.tail))
+        if not same:
+            if st.pcm is None:
+                st.pcm = torch.zeros((1, (cap + 7) // 8 * 8), dtype=torch.float32, device=self.device)
+                st.cache = torch.zeros((self.max_feat_frames, self.dims.n_mels), dtype=torch.float32, device=self.device)
+            st.n, st.key = 0, key
+            st.stats["restarts"] += 1
+        new = np.ascontiguousarray(audio[st.n:n], dtype=np.float32)
+        if len(new):
+            st.pcm[0, st.n:n].copy_(torch.from_numpy(new))
+        first = max(0, (st.n - 200) // 160) if st.n > 0 else 0
+        ns = torch.tensor([n], dtype=torch.int32, device=self.device)
+        ff = torch.tensor([first], dtype=torch.int32, device=self.device)
+        self.frontend.parakeet_cached(st.pcm, ns, ff, t_max, st.cache, out_row, nf_row)
+        st.stats["partials"] += 1
+        st.stats["samples_uploaded"] += len(new)
+        st.stats["samples_total"] += n
+        st.stats["frames_computed"] += (min(t_max, n // 160 + 1) - first // 64 * 64)       # (whole 64-frame tiles from the one that holds `first`)
+        st.stats["frames_total"] += n // 160 + 1
+        st.n, st.tail = n, np.array(audio[max(0, n - 64):n], dtype=np.float32, copy=True)
 
     def encode(self, feats: torch.Tensor, n_frames: torch.Tensor) -> None:
         B, T, _ = feats.shape
@@ -195,8 +238,28 @@ class ParakeetEngine:
                 offset.append(s0 / 16000.0)
         blank = self.dims.blank
         out = [{"ids": [], "starts_s": [], "ends_s": []} for _ in audios]
+        n_pieces = [owner.count(i) for i in range(len(audios))]
         for b0 in range(0, len(pieces), self.max_batch):
-            feats, nf, _ = self.features(pieces[b0 : b0 + self.max_batch])
+            chunk = pieces[b0 : b0 + self.max_batch]
+            # live partials that carry a ProgressiveStream (options["stream"], one-window turns only): their rows come from the stream's device
+            # state, everyone else's from the batched front-end call - ONE encoder pass for all of them either way
+            streams = [(options[owner[b0 + j]] or {}).get("stream") if n_pieces[owner[b0 + j]] == 1 else None for j in range(len(chunk))]
+            if any(s is not None for s in streams):
+                T = max(8, max(len(a) for a in chunk) // 160 + 1)
+                feats = torch.empty((len(chunk), T, self.dims.n_mels), dtype=self.dtype, device=self.device)
+                nf = torch.empty((len(chunk),), dtype=torch.int32, device=self.device)
+                plain = [j for j, s in enumerate(streams) if s is None]
+                order = plain + [j for j, s in enumerate(streams) if s is not None]
+                if plain:
+                    pcm, ns = pack_pcm([chunk[j] for j in plain], self.device)
+                    self.frontend.parakeet(pcm, ns, T, out_dtype=self.dtype, out=feats[: len(plain)], n_frames=nf[: len(plain)])
+                for r in range(len(plain), len(order)):
+                    j = order[r]
+                    self.stream_features(streams[j], chunk[j], (options[owner[b0 + j]] or {}).get("stream_key"), T, feats[r : r + 1], nf[r : r + 1])
+                own_c, off_c = [owner[b0 + j] for j in order], [offset[b0 + j] for j in order]
+                owner[b0 : b0 + len(chunk)], offset[b0 : b0 + len(chunk)] = own_c, off_c
+            else:
+                feats, nf, _ = self.features(chunk)
             self.encode(feats, nf)
             toks, durs, frames = self.tdt_greedy()
             for j, (tk, du, fr) in enumerate(zip(toks, durs, frames)):

@@ -18,6 +18,7 @@ import torch
 from oracle import logmel as OL
 from oracle import parakeet as OP
 from speech_to_speech_amd.handlers.parakeet import PooledParakeetModel, SentenceWindow
+from speech_to_speech_amd.frontend import pack_pcm
 from speech_to_speech_amd.parakeet import ParakeetEngine
 from speech_to_speech_amd.session_pool import SessionPool
 from speech_to_speech_amd.synth import synth_audio
@@ -92,8 +93,49 @@ def test_timestamped_transcribe_matches_oracle_segments(rig):
         assert model.transcribe(audio).text == want.text
 
 
-def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig):
-    """Three sessions speak at once; each turn grows by 0.5 s per tick to 9 s with a 4 s window cap and a 1 s sentence buffer (the
+def test_cached_features_are_bit_identical_to_the_whole_window(rig):
+    """Row f3 (the part that IS reusable): s2s_logmel_parakeet_cached on a window that grows by 0.5 s (and once by an odd amount, once not at
+    all) gives the features of s2s_logmel_parakeet on the whole window BIT FOR BIT - float32 and bf16 outputs, also as a row of a larger
+    batch - while uploading only the new samples and computing only the 64-frame tiles the new samples touch; a new window start or audio that
+    is not an extension of the last partial restarts the stream."""
+    from speech_to_speech_amd.parakeet import ProgressiveStream
+
+    dims, sd, pool, tok = rig
+    eng = pool._engines["parakeet"]
+    full = synth_audio(11 * 16000, 980)
+    for dtype in (torch.float32, torch.bfloat16):
+        st = ProgressiveStream()
+        lens = list(range(8000, 11 * 16000 + 1, 8000))
+        lens[5] += 1234                                   # an odd increment
+        lens.insert(9, lens[8])                           # a partial without new samples
+        for n in lens:
+            T = max(8, n // 160 + 1) + (3 if n % 16000 == 0 else 0)       # (as a row of a batch whose longest item is longer)
+            row = torch.empty((1, T, dims.n_mels), dtype=dtype, device="cuda:0")
+            nf = torch.empty((1,), dtype=torch.int32, device="cuda:0")
+            eng.stream_features(st, full[:n], 0, T, row, nf)
+            pcm, ns = pack_pcm([full[:n]], eng.device)
+            want, wnf = eng.frontend.parakeet(pcm, ns, T, out_dtype=dtype)
+            assert int(nf[0]) == int(wnf[0]) == n // 160
+            assert torch.equal(row, want), f"{dtype} n = {n}: cached features differ from the whole-window features"
+        s_ = st.stats
+        print(f"{dtype}: {s_['partials']} partials, uploaded {s_['samples_uploaded']} of {s_['samples_total']} samples ({s_['samples_uploaded'] / s_['samples_total']:.1%}), "
+              f"computed {s_['frames_computed']} of {s_['frames_total']} frames ({s_['frames_computed'] / s_['frames_total']:.1%}), restarts {s_['restarts']}")
+        assert s_["restarts"] == 1 and s_["samples_uploaded"] == lens[-1] and s_["frames_computed"] < 0.5 * s_["frames_total"]
+        # not an extension (another signal / a moved window): the stream restarts instead of reusing anything
+        other = synth_audio(40000, 981)
+        row = torch.empty((1, 251, dims.n_mels), dtype=dtype, device="cuda:0")
+        nf = torch.empty((1,), dtype=torch.int32, device="cuda:0")
+        eng.stream_features(st, other, 0, 251, row, nf)
+        pcm, ns = pack_pcm([other], eng.device)
+        assert torch.equal(row, eng.frontend.parakeet(pcm, ns, 251, out_dtype=dtype)[0]) and st.stats["restarts"] == 2
+        eng.stream_features(st, full[16000:64000], 16000, 301, torch.empty((1, 301, dims.n_mels), dtype=dtype, device="cuda:0"), nf)
+        assert st.stats["restarts"] == 3
+
+
+@pytest.mark.parametrize("incremental", [False, True])
+def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig, incremental):
+    """(incremental = True: every window is a ProgressiveStream - only new samples uploaded, only new log-mel tiles computed, same results.)
+    Three sessions speak at once; each turn grows by 0.5 s per tick to 9 s with a 4 s window cap and a 1 s sentence buffer (the
     reference's 15 s / 2 s scaled to a test-sized turn).  Every tick's (fixed, active) of every session equals the oracle-driven
     SentenceWindow's, sentences get fixed along the way, and the pool served windows of different sessions in shared batches."""
     dims, sd, pool, tok = rig
@@ -106,10 +148,12 @@ def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig):
         assert w.fixed, "the turn never fixed a sentence: the test would not cover the window move"
     before = dict(pool.stats)
     got = [[] for _ in turns]
+    wins = [None] * n_sessions
     barrier = threading.Barrier(n_sessions)
 
     def session(i):
-        w = SentenceWindow(PooledParakeetModel(pool, tok), max_window_s=4.0, sentence_buffer_s=1.0)
+        w = SentenceWindow(PooledParakeetModel(pool, tok), max_window_s=4.0, sentence_buffer_s=1.0, incremental=incremental)
+        wins[i] = w
         for n in range(step, total + 1, step):
             barrier.wait(timeout=120)           # a tick: every live session sends its partial now
             got[i].append(w.update(turns[i][:n]))
@@ -124,3 +168,9 @@ def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig):
     print(f"{n_sessions} sessions x {total // step} ticks: {n_req} window transcriptions in {n_bat} encoder passes (largest batch {pool.stats['max_stt_batch']}); "
           f"fixed sentences per session {[len(w[-1][0].split('.')) - 1 for w in want]}")
     assert pool.stats["max_stt_batch"] >= 2 and n_bat < n_sessions * (total // step)       # partials of a tick share encoder passes
+    if incremental:
+        for w in wins:
+            s_ = w.stream.stats
+            print(f"stream: {s_['partials']} partials in {s_['restarts']} windows, uploaded {s_['samples_uploaded'] / s_['samples_total']:.1%} of the samples, "
+                  f"computed {s_['frames_computed'] / s_['frames_total']:.1%} of the log-mel frames a whole-window recompute handles")
+            assert s_["partials"] >= total // step and s_["restarts"] >= 2 and s_["samples_uploaded"] < 0.6 * s_["samples_total"]
