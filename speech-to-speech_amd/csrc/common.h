@@ -195,12 +195,36 @@ __device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, i
     __shared__ int si[4];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        float x = row[v];
-        if ((mask && mask[v]) || (mask2 && mask2[v])) x = -INFINITY;
-        if (x > best || (x == best && v < bi)) {
-            best = x;
-            bi = v;
+    // 8 independent loads per thread in flight (a vocabulary row is 50 k floats for 256 threads: one load at a time made the Whisper pick 98 us
+    // per step, rocprof round 5); compared in index order, so ties still go to the lowest index
+    for (int v0 = threadIdx.x; v0 < V; v0 += 256 * 8) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = v0 + k * 256;
+            x[k] = v < V ? row[v] : -INFINITY;
+        }
+        if (mask) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = v0 + k * 256;
+                if (v < V && mask[v]) x[k] = -INFINITY;
+            }
+        }
+        if (mask2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = v0 + k * 256;
+                if (v < V && mask2[v]) x[k] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = v0 + k * 256;
+            if (v < V && (x[k] > best || (x[k] == best && v < bi))) {
+                best = x[k];
+                bi = v;
+            }
         }
     }
 #pragma unroll
