@@ -66,6 +66,35 @@ def test_gemm_matches_reference(M, N, K, dt):
         assert err < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 3072, 256), (6144, 2048, 128), (2560, 5120, 1280)])
+def test_tile_gemm_straight_line_epilogues(M, N, K):
+    """Every interior-tile epilogue of the 256 x 256 tile GEMM (csrc/gemm.hip tile256_epilogue_fast) plus what falls back to the general
+    one: bf16 / f32 outputs, with and without bias, f32 residual into a bf16 output, the residual added IN PLACE (C == residual, the
+    encoders' x += proj(...)), GELU (packed polynomial for bf16 outputs: within bf16 rounding of the exact erf form), SiLU, ReLU."""
+    lib = native.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) * (2.0 / K ** 0.5) + torch.arange(N)[:, None] * 1e-5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    for act, use_bias, res_mode, cdt in [(native.ACT_NONE, True, None, torch.bfloat16), (native.ACT_NONE, False, None, torch.bfloat16),
+                                         (native.ACT_NONE, True, "f32", torch.bfloat16), (native.ACT_NONE, True, "inplace", torch.float32),
+                                         (native.ACT_NONE, False, "f32", torch.float32), (native.ACT_GELU, True, None, torch.bfloat16),
+                                         (native.ACT_GELU, True, None, torch.float32), (native.ACT_SILU, True, None, torch.bfloat16),
+                                         (native.ACT_RELU, True, None, torch.bfloat16)]:
+        C = resid.clone() if res_mode == "inplace" else torch.empty((M, N), dtype=cdt, device=DEV)
+        rptr = native.ptr(C) if res_mode == "inplace" else (native.ptr(resid) if res_mode else None)
+        native.check(lib.s2s_op_gemm(native.stream_handle(), native.ptr(A), A.stride(0), native.ptr(W), native.ptr(bias) if use_bias else None, rptr,
+                                     native.ptr(C), C.stride(0), M, N, K, native.S2S_BF16, native.dtype_code(cdt), act))
+        torch.cuda.synchronize()
+        ref = _ref(A, W, bias if use_bias else None, resid if res_mode else None, act)
+        err = (C.double().cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        tol = (2e-4 if cdt == torch.float32 else 6e-3) * max(1.0, scale)       # f32 out: summation order only; bf16 out: + one rounding (2^-8)
+        print(f"tile gemm M={M} N={N} K={K} act={act} bias={use_bias} res={res_mode} c={cdt}: max_err={err:.3e} (scale {scale:.2f})")
+        assert err < tol
+
+
 def test_gemm_identity_detects_transposes():
     M = N = K = 128
     A = torch.eye(M, K).to(DEV)
