@@ -189,15 +189,16 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // block-wide argmax of one logits row with optional suppress masks; ties -> lowest index (torch.argmax)
-__device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
-                                                const unsigned char* __restrict__ mask2) {
+// (range form: indices v_lo .. V - 1 of the row; `best_out` receives the winning value)
+__device__ __forceinline__ int block_argmax_256_range(const float* __restrict__ row, int v_lo, int V, const unsigned char* __restrict__ mask,
+                                                      const unsigned char* __restrict__ mask2, float* best_out) {
     __shared__ float sv[4];
     __shared__ int si[4];
     float best = -INFINITY;
     int bi = 0x7fffffff;
     // 8 independent loads per thread in flight (a vocabulary row is 50 k floats for 256 threads: one load at a time made the Whisper pick 98 us
     // per step, rocprof round 5); compared in index order, so ties still go to the lowest index
-    for (int v0 = threadIdx.x; v0 < V; v0 += 256 * 8) {
+    for (int v0 = v_lo + threadIdx.x; v0 < V; v0 += 256 * 8) {
         float x[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -249,7 +250,48 @@ __device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, i
             best = sv[w];
             bi = si[w];
         }
+    if (best_out) *best_out = best;
     return bi;
+}
+__device__ __forceinline__ int block_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
+                                                const unsigned char* __restrict__ mask2) {
+    return block_argmax_256_range(row, 0, V, mask, mask2, nullptr);
+}
+// The argmax of one row by ARGMAX_SLICES workgroups (blockIdx.y = slice): every workgroup publishes its slice's candidate and takes a ticket;
+// the LAST arriver combines the candidates in slice order (lowest index wins ties, as in the one-workgroup form), resets the ticket and gets
+// the result - every other workgroup gets -1 and returns.  Candidates and tickets are agent-scope atomics (a row's workgroups run on
+// different XCDs; their L2s are not coherent with each other).  A vocabulary row of 50 k floats took one 256-thread workgroup 90 - 98 us.
+constexpr int ARGMAX_SLICES = 8;
+__device__ __forceinline__ int sliced_argmax_256(const float* __restrict__ row, int V, const unsigned char* __restrict__ mask,
+                                                 const unsigned char* __restrict__ mask2, int b, float* cand_v, int* cand_i, unsigned* ticket) {
+    __shared__ unsigned last_s;
+    const int s = blockIdx.y;
+    const int chunk = ((V + ARGMAX_SLICES - 1) / ARGMAX_SLICES + 255) / 256 * 256;
+    float best;
+    const int bi = block_argmax_256_range(row, s * chunk, min(V, (s + 1) * chunk), mask, mask2, &best);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(cand_v + b * ARGMAX_SLICES + s, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cand_i + b * ARGMAX_SLICES + s, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        last_s = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last_s != (unsigned)(ARGMAX_SLICES - 1)) return -1;
+    int win = 0x7fffffff;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float wv = -INFINITY;
+        for (int k = 0; k < ARGMAX_SLICES; ++k) {
+            const float v = __hip_atomic_load(cand_v + b * ARGMAX_SLICES + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i = __hip_atomic_load(cand_i + b * ARGMAX_SLICES + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v > wv || (v == wv && i < win)) {
+                wv = v;
+                win = i;
+            }
+        }
+        __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the next step's launch: stream order)
+    }
+    return win;      // (valid in thread 0 - the thread that advances the row)
 }
 
 

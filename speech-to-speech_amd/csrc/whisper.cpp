@@ -75,6 +75,9 @@ struct Whisper {
         *slot_out = nullptr;
     unsigned char* smask = nullptr;     // [3][vocab]: suppress, begin-suppress, prompt-fill
     int slot_eos = -1;
+    float* cand_v = nullptr;            // [max_batch][ARGMAX_SLICES] slice candidates of the vocabulary argmax (value, index) and the per-row tickets
+    int* cand_i = nullptr;
+    unsigned* pick_ticket = nullptr;
     int slots_live = 0;                 // host-side count of reserved + admitted slots (always == number of non-zero bytes of slot_live_map)
     std::vector<unsigned char> slot_live_map;   // per slot: 0 idle, 1 reserved (s2s_whisper_encode_at wrote its cross K|V), 2 admitted to the token loop
                                                 // - the scheduler's contract is checked, not trusted
@@ -191,6 +194,12 @@ static int finalize(Whisper* m) {
         S2S_HIP_CHECK(hipMalloc((void**)&mb, 3 * (size_t)c.vocab));
         S2S_HIP_CHECK(hipMemset(mb, 0, 3 * (size_t)c.vocab));
         m->mask_sup = mb; m->mask_begin = mb + c.vocab; m->mask_fill = mb + 2 * (size_t)c.vocab;
+        char* cb = nullptr;
+        const size_t nc = (size_t)B * ARGMAX_SLICES;
+        S2S_HIP_CHECK(hipMalloc((void**)&cb, nc * 8 + B * 4));
+        S2S_HIP_CHECK(hipMemset(cb, 0, nc * 8 + B * 4));
+        m->cand_v = (float*)cb; m->cand_i = (int*)(cb + nc * 4); m->pick_ticket = (unsigned*)(cb + nc * 8);
+        m->owned.push_back(cb);
     }
     if (c.dtype == S2S_BF16 && getenv("S2S_NO_DEC_FUSION") == nullptr && d % 32 == 0 && c.ffn % 32 == 0 && d >= 256 && c.ffn >= 256 && c.dec_layers > 0) {
         // fragment-major copies ("<name>.f", s2s_op_to_frag) are made once by the host side and shared by every engine replica
@@ -462,13 +471,14 @@ __global__ __launch_bounds__(256) void whisper_pick_advance_kernel(const float* 
                                                                    const unsigned char* __restrict__ mask_fill,
                                                                    const int* __restrict__ step_dev, const int* __restrict__ params,
                                                                    const int* __restrict__ prompt, int* cur_ids, int* pos,
-                                                                   int* out_ids, int* out_len, int* finished) {
+                                                                   int* out_ids, int* out_len, int* finished, float* cand_v, int* cand_i,
+                                                                   unsigned* ticket) {
     const int b = blockIdx.x;
     const int step = *step_dev, P = params[0], max_new = params[1], eos = params[2];
     const bool in_prompt = step + 1 < P;
-    const int picked = block_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup,
-                                        (!in_prompt && step == P - 1) ? mask_begin : nullptr);
-    if (threadIdx.x != 0) return;
+    const int picked = sliced_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup,
+                                         (!in_prompt && step == P - 1) ? mask_begin : nullptr, b, cand_v, cand_i, ticket);
+    if (threadIdx.x != 0 || picked < 0) return;      // (only the last arriver of the row's slices advances it)
     // `step` is the index of the token just consumed; the next input sits at position step+1
     int next;
     if (in_prompt) {
@@ -502,8 +512,9 @@ __global__ void whisper_set_params_kernel(int* params, int P, int max_new, int e
 static int step_body(Whisper* m, hipStream_t st, int B, bool split_ok) {
     int rc = decode_step(m, st, B, split_ok);
     if (rc) return rc;
-    whisper_pick_advance_kernel<<<B, 256, 0, st>>>(m->logits, m->cfg.vocab, m->mask_sup, m->mask_begin, m->mask_fill, m->step_dev,
-                                                   m->params_dev, m->prompt_buf, m->cur_ids, m->pos, m->out_ids, m->out_len, m->finished);
+    whisper_pick_advance_kernel<<<dim3(B, ARGMAX_SLICES), 256, 0, st>>>(m->logits, m->cfg.vocab, m->mask_sup, m->mask_begin, m->mask_fill, m->step_dev,
+                                                                        m->params_dev, m->prompt_buf, m->cur_ids, m->pos, m->out_ids, m->out_len, m->finished,
+                                                                        m->cand_v, m->cand_i, m->pick_ticket);
     S2S_LAUNCH_CHECK();
     whisper_step_inc_kernel<<<1, 1, 0, st>>>(m->step_dev);
     S2S_LAUNCH_CHECK();
@@ -544,13 +555,15 @@ __global__ __launch_bounds__(256) void whisper_slot_pick_kernel(const float* __r
                                                                 const unsigned char* __restrict__ mask_fill, int eos, int tmax, int* step_a,
                                                                 const int* __restrict__ P_a, const int* __restrict__ maxnew_a,
                                                                 const int* __restrict__ active_a, const int* __restrict__ prompt, int* fill,
-                                                                int* cur_ids, int* pos, int* out, int* out_len, int* finished) {
+                                                                int* cur_ids, int* pos, int* out, int* out_len, int* finished, float* cand_v, int* cand_i,
+                                                                unsigned* ticket) {
     const int b = blockIdx.x;
-    if (!active_a[b] || finished[b]) return;      // (block-uniform; read before the barriers of the argmax below)
+    if (!active_a[b] || finished[b]) return;      // (uniform over the row's slices: the row's state only changes after ALL of them took their ticket)
     const int step = step_a[b], P = P_a[b], max_new = maxnew_a[b];
     const bool in_prompt = step + 1 < P;
-    const int picked = block_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup, (!in_prompt && step == P - 1) ? mask_begin : nullptr);
-    if (threadIdx.x != 0) return;
+    const int picked = sliced_argmax_256(logits + (long)b * V, V, in_prompt ? mask_fill : mask_sup, (!in_prompt && step == P - 1) ? mask_begin : nullptr, b,
+                                         cand_v, cand_i, ticket);
+    if (threadIdx.x != 0 || picked < 0) return;
     int next;
     if (in_prompt) {
         next = prompt[b * WH_SLOT_PMAX + step + 1];
@@ -612,9 +625,10 @@ static int slot_step_body(Whisper* m, hipStream_t st, int rows, bool split_ok) {
     int rc = decode_step(m, st, rows, split_ok);
     if (rc) return rc;
     const int V = m->cfg.vocab;
-    whisper_slot_pick_kernel<<<rows, 256, 0, st>>>(m->logits, V, m->smask, m->smask + V, m->smask + 2 * (size_t)V, m->slot_eos, m->tmax, m->slot_step,
-                                                   m->slot_P, m->slot_maxnew, m->slot_active, m->slot_prompt, m->slot_fill, m->cur_ids, m->pos, m->slot_out,
-                                                   m->out_len, m->finished);
+    whisper_slot_pick_kernel<<<dim3(rows, ARGMAX_SLICES), 256, 0, st>>>(m->logits, V, m->smask, m->smask + V, m->smask + 2 * (size_t)V, m->slot_eos, m->tmax,
+                                                                        m->slot_step, m->slot_P, m->slot_maxnew, m->slot_active, m->slot_prompt, m->slot_fill,
+                                                                        m->cur_ids, m->pos, m->slot_out, m->out_len, m->finished, m->cand_v, m->cand_i,
+                                                                        m->pick_ticket);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
