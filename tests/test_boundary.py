@@ -384,6 +384,34 @@ def test_timestamped_transcribe_builds_sentence_segments():
     assert model.transcribe(_ramp_audio(2.0)).text == "w0 w1"
 
 
+def test_incremental_sentence_window_marks_each_window_as_one_stream():
+    """SentenceWindow(incremental=True) hands the pool ONE ProgressiveStream per window plus the window's start sample as its key: the key
+    changes exactly when sentences are fixed and the window start moves (the engine then restarts the stream), the texts are those of the plain
+    window (the stream only changes where the features come from - tests/test_parakeet_progressive_gpu.py checks that on the device)."""
+    from speech_to_speech_amd.handlers.parakeet import PooledParakeetModel, SentenceWindow
+
+    class _Recording(_ScriptedPool):
+        def transcribe(self, model, audio, **kw):
+            self.seen.append((kw.get("stream"), kw.get("stream_key"), len(audio)))
+            return super().transcribe(model, audio)
+
+    pool, plain_pool = _Recording(_script(), 24 * 16000), _ScriptedPool(_script(), 24 * 16000)
+    pool.seen = []
+    win = SentenceWindow(PooledParakeetModel(pool, _PunctCodec()), incremental=True)
+    plain = SentenceWindow(PooledParakeetModel(plain_pool, _PunctCodec()))
+    full = _ramp_audio(24.0)
+    for n in range(8000, len(full) + 1, 8000):
+        assert win.update(full[:n]) == plain.update(full[:n])
+    streams = {id(s) for s, _, _ in pool.seen}
+    assert len(streams) == 1 and pool.seen[0][0] is win.stream                    # one token object, the engine keeps the device state on it
+    keys = [k for _, k, _ in pool.seen]
+    assert keys[0] == 0 and keys == sorted(keys) and len(set(keys)) >= 2           # the window start only moves forward, and it did move
+    for (_, k0, n0), (_, k1, n1) in zip(pool.seen, pool.seen[1:]):
+        if k1 == k0:
+            assert n1 > n0                                                         # same window: a longer prefix every time
+    assert [c for c in pool.calls] == [c for c in plain_pool.calls]                # same windows transcribed, in the same order
+
+
 def test_sentence_window_fixes_sentences_like_the_reference_streamer():
     """Growing audio in 0.5 s increments up to 24 s: below 15 s the window is the whole turn; at 15 s the sentences ending
     before (window - 2 s) are fixed and the window restarts at the last fixed end.  When the reference is present
