@@ -112,7 +112,7 @@ int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float* pcm_dev,
  * caller, holding the UN-normalised log-mel frames of the rows' earlier, shorter prefixes; first_frame_dev int32[B]: frames below it are
  * taken from the cache, frames from it on are computed and written to the cache (0 = compute everything).  A frame depends on the 400
  * samples around it only, so with first_frame = max(0, (previous n_samples - 200) / 160) the result is bit-identical to
- * s2s_logmel_parakeet on the whole window (tests/test_logmel_gpu.py); the per-feature normalisation always runs over the whole window.
+ * s2s_logmel_parakeet on the whole window (tests/test_parakeet_progressive_gpu.py); the per-feature normalisation always runs over the whole window.
  * With B = 1 the cache layout does not depend on t_max: one buffer serves a stream as its window grows. */
 int32_t s2s_logmel_parakeet_cached(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
                                    const int32_t* n_samples_dev, const int32_t* first_frame_dev, int32_t B, int32_t t_max,

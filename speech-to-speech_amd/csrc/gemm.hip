@@ -57,16 +57,21 @@ __device__ __forceinline__ float gelu_erf_bf16(float x) {
 }
 
 // GELU for a bf16 destination without transcendentals (quarter rate on the vector unit) and two elements per instruction:
-// gelu(x) = x * (0.5 + xc * Q(xc^2)), xc = clamp(x, -4, 4), Q = degree-8 polynomial fitted to 0.5 erf(x / sqrt 2) / x on [0, 4]
-// (tools/fit_gelu_poly.py: max |error| 1.6e-4 over all x, reached on the far negative tail where gelu itself is < 1.3e-4; <= 5.4e-5
-// inside [-4, 4]) - below the bf16 rounding of the result (2^-9 relative) wherever the activation is not negligible.  11 packed
-// instructions + 2 clamps per PAIR against ~16 scalar ones (2 of them v_rcp / v_exp) per element for gelu_erf_bf16: the fc1 epilogue of
-// the Whisper encoder ran 13 us per 256x256 tile against 4.5 us for the same tile without activation (tools/tile5_phases.py).
+// gelu(x) = max(x, -4) * (0.5 + xc * Q(xc^2)), xc = clamp(x, -4, 4), Q = degree-8 polynomial fitted to 0.5 erf(x / sqrt 2) / x on [0, 4]
+// (tools/fit_gelu_poly.py).  Error against the exact erf form, float32 evaluation: <= 5.4e-5 inside [-4, 4]; for x < -4 the factor stays
+// at its x = -4 value (Phi(-4) = 3.2e-5, it does not decay) so the multiplicand is clamped at -4 as well: the result is the constant
+// -7.9e-5 where gelu is < 1.3e-4 and -> 0, i.e. |error| <= 7.9e-5 for EVERY x < -4 (with x unclamped it grew as 2e-5 |x|: ADVICE r5);
+// for x > 4 the result is x (1 - 2e-5), below 2^-15 relative.  All of it is below the bf16 rounding of the result (2^-9 relative) wherever the
+// activation is not negligible; tests/test_ops_gpu.py::test_gelu_poly_matches_erf_form_over_a_wide_range pins it on [-1e4, 1e4].
+// 11 packed instructions + 4 clamps per PAIR against ~16 scalar ones (2 of them v_rcp / v_exp) per element for gelu_erf_bf16: the fc1
+// epilogue of the Whisper encoder ran 13 us per 256x256 tile against 4.5 us for the same tile without activation (tools/tile5_phases.py).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
-    f32x2_t xc;
+    f32x2_t xc, xm;
     xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f);
     xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f);
+    xm[0] = fmaxf(x[0], -4.0f);
+    xm[1] = fmaxf(x[1], -4.0f);
     const f32x2_t t = xc * xc;
     f32x2_t q = t * 8.524421446498565e-11f + -7.295211545965685e-09f;
     q = q * t + 2.791634869936388e-07f;
@@ -77,7 +82,7 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
     q = q * t + -0.06641801446676254f;
     q = q * t + 0.3989247679710388f;
     const f32x2_t phi = xc * q + 0.5f;
-    return x * phi;
+    return xm * phi;
 }
 
 template <typename CT, int ACT>

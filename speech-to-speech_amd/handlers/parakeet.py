@@ -11,7 +11,7 @@ import torch
 
 from ..boundary import BaseSTTHandler, PartialTranscription, Transcription
 from ..checkpoints import PARAKEET_DIMS, load_safetensors_dir, parse_model_name
-from ..session_pool import SessionPool
+from ..session_pool import SessionPool, release_pool_on_failure
 from ..text import load_tokenizer
 
 logger = logging.getLogger(__name__)
@@ -79,8 +79,11 @@ class PooledParakeetModel:
     """The ``model`` object STT/smart_progressive_streaming.py:38-57 expects (nano-parakeet's surface):
     ``transcribe(audio, timestamps=True)`` -> ``.text`` and ``.timestamp["segment"]``, served by the MI355X session pool."""
 
-    def __init__(self, pool: SessionPool, tokenizer: Any, best_effort: bool = False):
-        self.pool, self.tokenizer, self.best_effort = pool, tokenizer, best_effort
+    def __init__(self, pool: SessionPool, tokenizer: Any, best_effort: bool = False, shed_queue: int = 0):
+        # best_effort: the requests are live partials - the pool serves them behind every queued final (session_pool._stt_pq).
+        # shed_queue > 0 additionally drops a partial when that many requests already wait in the POOL (rounds 2 - 5 did this with
+        # shed_queue = max_batch; off by default since round 6: it is not the reference's rule - see MI355XParakeetSTTHandler.process)
+        self.pool, self.tokenizer, self.best_effort, self.shed_queue = pool, tokenizer, best_effort, int(shed_queue)
 
     def transcribe(self, audio: Any, timestamps: bool = False, stream: Any = None, stream_key: Any = None) -> Any:
         """`stream` (a parakeet.ProgressiveStream) marks the audio as the current state of ONE growing window that starts at `stream_key` in its
@@ -88,12 +91,12 @@ class PooledParakeetModel:
         from types import SimpleNamespace
 
         extra = {} if stream is None else {"stream": stream, "stream_key": stream_key}
-        if self.best_effort:
-            res = self.pool.try_transcribe("parakeet", audio, max_queue=self.pool.max_batch, **extra)
+        if self.best_effort and self.shed_queue > 0:
+            res = self.pool.try_transcribe("parakeet", audio, max_queue=self.shed_queue, **extra)
             if res is None:
                 raise BlockingIOError("pool busy")
         else:
-            res = self.pool.transcribe("parakeet", audio, **extra)
+            res = self.pool.transcribe("parakeet", audio, live=self.best_effort, **extra)
         text = self.tokenizer.decode(res["ids"]).strip()
         if not timestamps:
             return SimpleNamespace(text=text)
@@ -177,6 +180,7 @@ def build_parakeet_engine(model_name: str, device: str, compute_type: str, max_b
 
 
 class MI355XParakeetSTTHandler(BaseSTTHandler):
+    @release_pool_on_failure
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", compute_type: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, max_seconds: float = 30.0, enable_live_transcription: bool = False,
               live_transcription_update_interval: float = 0.5, gen_kwargs: dict | None = None, pool: SessionPool | None = None, batch_cap: int = 0,
@@ -194,8 +198,7 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
-        if self._owns_pool:
-            self.pool.attach(self)
+        self.pool.attach(self)                 # every user is counted, also one that was handed its pool (session_pool.attach)
         if int(batch_cap) > 0:
             self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("parakeet", lambda: build_parakeet_engine(model_name, device, compute_type, max_batch, max_seconds))
@@ -231,15 +234,33 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
         if vad_audio.mode == "progressive":
             if getattr(self, "processing_final", False):
                 return     # a final of this unit is in flight: its progressive items are stale (:259-262)
-            win = windows.get(vad_audio.turn_id)
-            if win is None:
-                windows.clear()              # one live turn per pipeline unit
-                live = self.__dict__.setdefault("_live_model", PooledParakeetModel(self.pool, self.tokenizer, best_effort=True))
-                win = windows[vad_audio.turn_id] = SentenceWindow(live, incremental=getattr(self, "incremental_partials", True))
+            # The reference skips a progressive item only while THIS unit's compute lock is held - `with self._compute_lock_context(timeout=0.01)`
+            # around its own inference (:264-295; the lock is per handler, :129) - never because OTHER units are busy.  Same rule here: one
+            # lock per handler, 10 ms try-acquire; every partial that gets it is transcribed (the pool serves it behind the queued finals).
+            # Rounds 2 - 5 dropped a partial when the pool's queue was longer than max_batch: that shed 32 % of the partials at the C5 load.
+            lock = self.__dict__.get("_compute_lock")
+            if lock is None:
+                import threading
+
+                lock = self.__dict__.setdefault("_compute_lock", threading.Lock())
+            if not lock.acquire(timeout=0.01):
+                logger.debug("Skipping progressive update (compute busy)")
+                return
             try:
-                upd = win.update(audio)
-            except BlockingIOError:
-                return     # busy: skip this partial, exactly like the reference's 10 ms try-lock
+                win = windows.get(vad_audio.turn_id)
+                if win is None:
+                    windows.clear()              # one live turn per pipeline unit
+                    live = self.__dict__.get("_live_model") or self.__dict__.setdefault("_live_model", PooledParakeetModel(self.pool, self.tokenizer, best_effort=True))
+                    win = windows[vad_audio.turn_id] = SentenceWindow(live, incremental=getattr(self, "incremental_partials", True))
+                try:
+                    upd = win.update(audio)
+                except BlockingIOError:
+                    return     # (only with PooledParakeetModel(shed_queue > 0))
+                except Exception as e:  # noqa: BLE001
+                    logger.debug("Progressive transcription failed: %s", e)      # (:289-290: logged, the item is dropped)
+                    return
+            finally:
+                lock.release()
             if upd is not None:
                 fixed, active = upd
                 yield PartialTranscription(text=(fixed + " " + active).strip(), turn_id=vad_audio.turn_id, turn_revision=vad_audio.turn_revision)
@@ -276,5 +297,5 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
         self.__dict__.setdefault("_windows", {}).clear()
         pool, self.pool = getattr(self, "pool", None), None
         self._live_model = None
-        if pool is not None and getattr(self, "_owns_pool", False):
+        if pool is not None:
             pool.detach(self)

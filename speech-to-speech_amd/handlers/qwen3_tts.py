@@ -27,7 +27,7 @@ import torch
 from ..boundary import (AUDIO_RESPONSE_DONE, PIPELINE_END, SESSION_END, AssistantOutputEvent, AssistantTextPart, BaseHandler, EndOfResponse, TTSInput,
                         is_control_message)
 from ..checkpoints import TTS_DIMS, load_safetensors_dir, parse_model_name
-from ..session_pool import SessionPool
+from ..session_pool import SessionPool, release_pool_on_failure
 from ..text import ByteTextFrontend, PromptTooLong
 from ..tts import AudioBlocker, TTSPrompt
 
@@ -174,6 +174,7 @@ def build_tts_engine(model_name: str, device: str, dtype: str, max_batch: int, m
 
 
 class MI355XQwen3TTSHandler(BaseHandler):
+    @release_pool_on_failure
     def setup(self, should_listen: Any = None, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", dtype: str = "bfloat16",
               speaker: str | None = None, language: str | None = "auto", instruct: str | None = None, streaming_chunk_size: int = 8,
               max_new_tokens: int = DEFAULT_MAX_NEW_TOKENS, blocksize: int = 512, max_batch: int = 64, batch_window_ms: float = 4.0,
@@ -199,8 +200,7 @@ class MI355XQwen3TTSHandler(BaseHandler):
         self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms,
                                                   tts_chunk_size=self.streaming_chunk_size, tts_ctx_frames=codec_context_frames, tts_lanes=lanes)
-        if self._owns_pool:
-            self.pool.attach(self)
+        self.pool.attach(self)                 # every user is counted, also one that was handed its pool (session_pool.attach)
         if float(lead_s) > 0.0:             # paced frame loop (0 = eager, the pool's default)
             self.pool.configure(tts_lead_s=float(lead_s), tts_admit_wait_s=float(admit_wait_ms) * 1e-3)
         self.pool.ensure_engine("tts", lambda: build_tts_engine(model_name, device, dtype, max_batch, self.max_new_tokens, codec_context_frames,
@@ -325,7 +325,7 @@ class MI355XQwen3TTSHandler(BaseHandler):
         try:
             self.__dict__.setdefault("_voice_cache", {}).clear()
             pool, self.pool = getattr(self, "pool", None), None
-            if pool is not None and getattr(self, "_owns_pool", False) and pool.detach(self) and torch.cuda.is_available():
+            if pool is not None and pool.detach(self) and torch.cuda.is_available():
                 torch.cuda.empty_cache()
             logger.info("MI355X Qwen3-TTS handler cleaned up")
         except Exception as e:  # noqa: BLE001

@@ -12,7 +12,7 @@ import torch
 
 from ..boundary import BaseSTTHandler, PartialTranscription, Transcription
 from ..checkpoints import WHISPER_DIMS, load_safetensors_dir, parse_model_name
-from ..session_pool import SessionPool
+from ..session_pool import SessionPool, release_pool_on_failure
 from ..text import WhisperVocab, load_tokenizer
 
 logger = logging.getLogger(__name__)
@@ -44,6 +44,7 @@ def build_whisper_engine(model_name: str, device: str, torch_dtype: str, max_bat
 
 
 class MI355XWhisperSTTHandler(BaseSTTHandler):
+    @release_pool_on_failure
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", torch_dtype: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, gen_kwargs: dict | None = None, vocab: WhisperVocab | None = None,
               pool: SessionPool | None = None, batch_cap: int = 0, **_ignored: Any) -> None:
@@ -54,8 +55,7 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         self.tokenizer = load_tokenizer(key if kind == "dir" else None)
         self._owns_pool = pool is None
         self.pool = pool or SessionPool.for_device(device, max_batch=max_batch, batch_window_ms=batch_window_ms)
-        if self._owns_pool:
-            self.pool.attach(self)
+        self.pool.attach(self)                 # every user is counted, also one that was handed its pool (session_pool.attach)
         if int(batch_cap) > 0:
             self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("whisper", lambda: build_whisper_engine(model_name, device, torch_dtype, max_batch))
@@ -82,8 +82,12 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         forced = self.gen_kwargs.get("language") or (self.start_language if self.start_language not in (None, "auto") else None)
         opts = dict(language=forced or "auto", max_new_tokens=int(self.gen_kwargs.get("max_new_tokens", 128)), vocab=self.vocab, task=getattr(self, "task", "transcribe"))
         if vad_audio.mode == "progressive":
-            res = self.pool.try_transcribe("whisper", vad_audio.audio, max_queue=self.pool.max_batch, **opts)
-            if res is None:
+            # the reference transcribes EVERY progressive item (STT/whisper_stt_handler.py:166-282 has no skip path); the pool serves live
+            # partials behind the queued finals (live=True) but never drops them (rounds 2 - 5 shed them by pool backlog)
+            try:
+                res = self.pool.transcribe("whisper", vad_audio.audio, live=True, **opts)
+            except Exception as e:  # noqa: BLE001
+                logger.debug("Whisper progressive transcription failed: %s", e)
                 return
         else:
             try:
@@ -116,5 +120,5 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         when the last handler that obtained it through `for_device` is gone."""
         logger.info("Cleaning up %s", self.__class__.__name__)
         pool, self.pool = getattr(self, "pool", None), None
-        if pool is not None and getattr(self, "_owns_pool", False):
+        if pool is not None:
             pool.detach(self)

@@ -21,6 +21,7 @@ import logging
 
 import ctypes as C
 import math
+import zlib
 from typing import Any, Mapping, Sequence
 
 import numpy as np
@@ -31,6 +32,28 @@ from .frontend import LogMelFrontend, pack_pcm
 from .synth_weights import ParakeetDims
 
 logger = logging.getLogger(__name__)
+
+try:      # (xxh3 runs at memory speed; crc32 is the fallback - either one sees every byte of the prefix)
+    import xxhash as _xxhash
+except Exception:  # noqa: BLE001  pragma: no cover
+    _xxhash = None
+
+
+class _PrefixDigest:
+    """Streaming checksum over the samples a ProgressiveStream has uploaded so far."""
+
+    def __init__(self):
+        self._h = _xxhash.xxh3_64() if _xxhash is not None else 0
+
+    def update(self, samples: np.ndarray) -> None:
+        buf = memoryview(np.ascontiguousarray(samples, dtype=np.float32)).cast("B")
+        if _xxhash is not None:
+            self._h.update(buf)
+        else:
+            self._h = zlib.crc32(buf, self._h)
+
+    def value(self) -> int:
+        return self._h.intdigest() if _xxhash is not None else self._h
 
 
 def _half_up(n: int) -> int:
@@ -113,7 +136,8 @@ class ProgressiveStream:
     def __init__(self):
         self.key = None            # the window's start in the turn: a new start is a new window
         self.n = 0                 # samples on the device
-        self.pcm = self.cache = self.tail = None
+        self.pcm = self.cache = None
+        self.digest = None         # checksum of those n samples: a caller whose buffer changed BEHIND the tail restarts the stream
         self.stats = {"partials": 0, "samples_uploaded": 0, "samples_total": 0, "frames_computed": 0, "frames_total": 0, "restarts": 0}
 
 
@@ -169,17 +193,25 @@ class ParakeetEngine:
         n = len(audio)
         cap = (self.max_feat_frames - 1) * 160
         assert 0 < n <= cap
-        same = (st.pcm is not None and st.key == key and st.n > 0 and n >= st.n
-                and np.array_equal(np.asarray(audio[max(0, st.n - 64):st.n], dtype=np.float32), st.tail))
+        # "same growing window" = same key, not shorter, and the caller's first st.n samples are still the ones on the device: a checksum over
+        # the WHOLE prefix (comparing only the last 64 samples missed a re-based / trimmed / enhanced buffer and a tail of digital
+        # silence, and then reused stale device PCM and log-mel frames); one pass over the prefix, continued over the new samples below
+        dg = _PrefixDigest()
+        same = st.pcm is not None and st.key == key and st.n > 0 and n >= st.n
+        if same:
+            dg.update(audio[: st.n])
+            same = dg.value() == st.digest
         if not same:
             if st.pcm is None:
                 st.pcm = torch.zeros((1, (cap + 7) // 8 * 8), dtype=torch.float32, device=self.device)
                 st.cache = torch.zeros((self.max_feat_frames, self.dims.n_mels), dtype=torch.float32, device=self.device)
             st.n, st.key = 0, key
+            dg = _PrefixDigest()
             st.stats["restarts"] += 1
         new = np.ascontiguousarray(audio[st.n:n], dtype=np.float32)
         if len(new):
             st.pcm[0, st.n:n].copy_(torch.from_numpy(new))
+            dg.update(new)
         first = max(0, (st.n - 200) // 160) if st.n > 0 else 0
         ns = torch.tensor([n], dtype=torch.int32, device=self.device)
         ff = torch.tensor([first], dtype=torch.int32, device=self.device)
@@ -189,7 +221,7 @@ class ParakeetEngine:
         st.stats["samples_total"] += n
         st.stats["frames_computed"] += (min(t_max, n // 160 + 1) - first // 64 * 64)       # (whole 64-frame tiles from the one that holds `first`)
         st.stats["frames_total"] += n // 160 + 1
-        st.n, st.tail = n, np.array(audio[max(0, n - 64):n], dtype=np.float32, copy=True)
+        st.n, st.digest = n, dg.value()
 
     def encode(self, feats: torch.Tensor, n_frames: torch.Tensor) -> None:
         B, T, _ = feats.shape

@@ -177,9 +177,14 @@ def main(argv=None) -> None:  # pragma: no cover - thin CLI
     ap.add_argument("--max-batch", type=int, default=64)
     a = ap.parse_args(argv)
     pool = SessionPool.for_device(a.device, max_batch=a.max_batch)
-    pool.ensure_engine("whisper", lambda: build_whisper_engine(a.stt_model, a.device, "bfloat16", a.max_batch))
-    vocab = WhisperVocab.synthetic(pool.engine("whisper").dims.vocab)
-    uvicorn.run(create_app(pool, "whisper", stt_options={"vocab": vocab, "max_new_tokens": 128}), host=a.host, port=a.port)
+    user = object()
+    pool.attach(user)          # the server is a user of the device's pool like any handler: handlers coming and going do not take its engines away
+    try:
+        pool.ensure_engine("whisper", lambda: build_whisper_engine(a.stt_model, a.device, "bfloat16", a.max_batch))
+        vocab = WhisperVocab.synthetic(pool.engine("whisper").dims.vocab)
+        uvicorn.run(create_app(pool, "whisper", stt_options={"vocab": vocab, "max_new_tokens": 128}), host=a.host, port=a.port)
+    finally:
+        pool.detach(user)
 
 
 if __name__ == "__main__":  # pragma: no cover

@@ -39,6 +39,7 @@ class _STTRequest:
     options: dict
     future: Future = field(default_factory=Future)
     t_submit: float = field(default_factory=time.perf_counter)
+    live: bool = False              # a live partial (best effort): served behind every queued final, in the rows a batch has left
 
 
 @dataclass
@@ -73,6 +74,25 @@ class _ChunkStream:
         return item
 
 
+def release_pool_on_failure(setup):
+    """Decorator for a handler's setup(): a setup that raises after it attached itself to a pool (a bad checkpoint, an unknown speaker) lets
+    go of the pool again - otherwise the stale attachment keeps the device's pool (and its engines) alive for ever."""
+    import functools
+
+    @functools.wraps(setup)
+    def wrapper(self, *a, **kw):
+        try:
+            return setup(self, *a, **kw)
+        except BaseException:
+            pool = getattr(self, "pool", None)
+            if pool is not None and hasattr(pool, "detach"):
+                self.pool = None
+                pool.detach(self)
+            raise
+
+    return wrapper
+
+
 class SessionPool:
     _pools: dict[str, "SessionPool"] = {}
     _pools_lock = threading.Lock()
@@ -93,20 +113,22 @@ class SessionPool:
                         logger.warning("SessionPool(%s) already exists with %s=%s; ignoring %s=%s from a later handler", device, k, cur, k, v)
             return cls._pools[device]
 
-    def attach(self, handler: Any) -> None:
-        """A handler that obtained this pool through `for_device` registers itself; `detach` from the handler's cleanup() releases the
-        engines (weights, KV arenas, graphs) once the LAST handler of the device is gone - the pool-level equivalent of the reference
-        handlers' `del self.model` (STT/parakeet_tdt_handler.py:636-640, TTS/qwen3_tts_handler.py:1011-1034)."""
+    def attach(self, user: Any) -> None:
+        """EVERY user of a pool registers itself: the handlers (whether they obtained the pool through `for_device` or were handed it as
+        `pool=`) and direct `for_device` callers such as the server (any object serves as the token).  `detach` from the user's cleanup()
+        releases the engines (weights, KV arenas, graphs) once the LAST user of a `for_device` pool is gone - the pool-level equivalent of the
+        reference handlers' `del self.model` (STT/parakeet_tdt_handler.py:636-640, TTS/qwen3_tts_handler.py:1011-1034).  A pool somebody
+        constructed directly (`SessionPool(...)`: tests, bench.py) belongs to that caller and is never shut down from here."""
         with self._pools_lock:
-            self.__dict__.setdefault("_attached", set()).add(id(handler))
+            self.__dict__.setdefault("_attached", set()).add(id(user))
 
-    def detach(self, handler: Any) -> bool:
-        """-> True when this was the last attached handler and the pool has been shut down (engines closed, device memory released)."""
+    def detach(self, user: Any) -> bool:
+        """-> True when this was the last attached user of a `for_device` pool and the pool has been shut down (engines closed, device memory released)."""
         with self._pools_lock:
             att = self.__dict__.setdefault("_attached", set())
-            if id(handler) not in att:
+            if id(user) not in att:
                 return False
-            att.discard(id(handler))
+            att.discard(id(user))
             last = not att and self._pools.get(self.device) is self
             if last:
                 del self._pools[self.device]
@@ -189,7 +211,14 @@ class SessionPool:
         self._engines: dict[str, Any] = {}
         self._lane_replicas: list[Any] = []
         self._factories: dict[str, Callable[[], Any]] = {}
+        # STT queues.  _stt_q: final transcriptions, shared by all STT workers.  _stt_pq: live partials, shared; a batch takes them only into the
+        # rows the queued finals leave free (finals sit in front of a session's first audio, partials are best effort).  _stt_q0: what ONLY the
+        # first worker may serve - engine builds, host calls, the stop token and, with several workers, requests for engines that cannot be
+        # replicated or that the slot loop serves (the extra workers used to take such items and append them again, which reordered
+        # the FIFO and spun a core)
         self._stt_q: "queue.Queue[Any]" = queue.Queue()
+        self._stt_pq: "queue.Queue[Any]" = queue.Queue()
+        self._stt_q0: "queue.Queue[Any]" = queue.Queue()
         self._tts_q: "queue.Queue[Any]" = queue.Queue()
         self._wake = threading.Event()
         self._engine_lock = threading.Lock()
@@ -231,7 +260,7 @@ class SessionPool:
             fut = self._building.get(name)            # a second caller waits for the build already in flight instead of starting another
             if fut is None:
                 fut = self._building[name] = Future()
-                self._stt_q.put(("build", name, factory, fut))
+                self._stt_q0.put(("build", name, factory, fut))
                 self._wake.set()
         try:
             fut.result()
@@ -255,25 +284,37 @@ class SessionPool:
         if self.stt_stages <= 1:
             return
         fut: Future = Future()
-        self._stt_q.put(("call", lambda: self._stt_pipeline_build(model), fut))
+        self._stt_q0.put(("call", lambda: self._stt_pipeline_build(model), fut))
         self._wake.set()
         fut.result(timeout)
 
     # ---- client API (handler threads) -----------------------------------------------------------
-    def transcribe(self, model: str, audio: np.ndarray, **options) -> dict:
+    def _stt_route(self, req: _STTRequest) -> "queue.Queue[Any]":
+        if self.stt_workers > 1:
+            eng = self._engines.get(req.model)
+            if not hasattr(eng, "replica") or (self.stt_slots > 0 and hasattr(eng, "slots_step")):
+                return self._stt_q0
+        return self._stt_pq if req.live else self._stt_q
+
+    def stt_backlog(self) -> int:
+        """Transcription requests waiting for a batch (finals + live partials)."""
+        return self._stt_q.qsize() + self._stt_pq.qsize() + self._stt_q0.qsize()
+
+    def transcribe(self, model: str, audio: np.ndarray, live: bool = False, **options) -> dict:
+        """Blocks until the transcript of `audio` is there.  live=True marks a live partial: same computation, lower priority."""
         if self._stopping:
             raise RuntimeError("SessionPool is shut down")
-        req = _STTRequest(model, np.array(audio, dtype=np.float32, copy=True), options)
-        self._stt_q.put(req)
+        req = _STTRequest(model, np.array(audio, dtype=np.float32, copy=True), options, live=bool(live))
+        self._stt_route(req).put(req)
         self._wake.set()
         return req.future.result()
 
     def try_transcribe(self, model: str, audio: np.ndarray, max_queue: int, **options) -> dict | None:
-        """Progressive (live partial) requests are best-effort, like the reference's try-lock-and-skip
-        (STT/parakeet_tdt_handler.py:264-295): when the pool is already backed up the partial is skipped."""
-        if self._stt_q.qsize() >= max_queue:
+        """Load shedding by POOL backlog (round 2 - 5 default for live partials; off since round 6: the reference skips a partial only while
+        the SAME unit's compute lock is held, STT/parakeet_tdt_handler.py:264-295 - see handlers/parakeet.py).  Kept for callers that want it."""
+        if self.stt_backlog() >= max_queue:
             return None
-        return self.transcribe(model, audio, **options)
+        return self.transcribe(model, audio, live=True, **options)
 
     def synthesize(self, prompt: Any, max_new_tokens: int, min_frames: int = 0) -> tuple[Iterator[np.ndarray], threading.Event]:
         """-> (iterator over int16 16 kHz chunks of one utterance, cancel event).  min_frames > 0 masks eos until the utterance
@@ -289,7 +330,7 @@ class SessionPool:
     def _fail_pending(self) -> None:
         """Requests still queued at shutdown are failed, so no handler thread blocks forever on a future / chunk queue."""
         err = RuntimeError("SessionPool is shut down")
-        for q in (self._stt_q, self._tts_q):
+        for q in (self._stt_q0, self._stt_q, self._stt_pq, self._tts_q):
             while True:
                 try:
                     it = q.get_nowait()
@@ -309,7 +350,7 @@ class SessionPool:
         built itself are always closed."""
         self._stopping = True
         self._fail_pending()
-        self._stt_q.put(_STOP)
+        self._stt_q0.put(_STOP)
         for _ in self._lanes:
             self._tts_q.put(_STOP)
         self._wake.set()
@@ -352,11 +393,12 @@ class SessionPool:
         ctx = self._lane_stream_ctx(self.stt_priority)
         ctx.__enter__()
         while True:
-            try:
-                first = self._stt_q.get(timeout=0.05)
-            except queue.Empty:
+            self._wake.clear()
+            first = self._stt_take(own=True)
+            if first is None:
                 if self._stopping:
                     return
+                self._wake.wait(0.05)
                 continue
             if self.batch_window_s > 0 and isinstance(first, _STTRequest):
                 time.sleep(self.batch_window_s)      # let concurrent sessions' finals join the batch
@@ -365,7 +407,7 @@ class SessionPool:
                 cap = min(cap, int(getattr(self._engines.get(first.model), "max_batch", cap)))     # never hand an engine more rows than it was built for
                 if self.stt_max_batch > 0:
                     cap = min(cap, self.stt_max_batch)
-            items = [first] + self._drain(self._stt_q, cap - 1)
+            items = self._stt_fill([first], cap, own=True)
             reqs: list[_STTRequest] = []
             for it in items:
                 if it is _STOP:
@@ -401,8 +443,24 @@ class SessionPool:
                     self._run_stt_staged(mine, model)
                 else:
                     self._run_stt(mine, model)
-            if self._stopping and self._stt_q.empty():
+            if self._stopping and self.stt_backlog() == 0:
                 return
+
+    def _stt_take(self, own: bool) -> Any:
+        """Next STT item without blocking: the first worker's own queue (own=True), then finals, then live partials."""
+        for q in ((self._stt_q0,) if own else ()) + (self._stt_q, self._stt_pq):
+            try:
+                return q.get_nowait()
+            except queue.Empty:
+                pass
+        return None
+
+    def _stt_fill(self, items: list, cap: int, own: bool) -> list:
+        """Fill a batch that starts with `items` up to `cap` entries: finals before live partials (a partial never takes a final's row)."""
+        for q in ((self._stt_q0,) if own else ()) + (self._stt_q, self._stt_pq):
+            if len(items) < cap:
+                items += self._drain(q, cap - len(items))
+        return items
 
     # ---- continuous token loop (slots) ------------------------------------------------------------
     def _stt_slots_submit(self, reqs: list[_STTRequest], model: str) -> None:
@@ -607,16 +665,9 @@ class SessionPool:
         ctx.__enter__()
         replicas: dict[str, Any] = {}
         while not self._stopping:
-            try:
-                first = self._stt_q.get(timeout=0.05)
-            except queue.Empty:
-                continue
-            if (not isinstance(first, _STTRequest) or not hasattr(self._engines.get(first.model), "replica")
-                    or (self.stt_slots > 0 and hasattr(self._engines.get(first.model), "slots_step"))):
-                self._stt_q.put(first)               # builds / stop / non-replicable engines / models served by the slot loop: the first worker's
-                if first is _STOP:
-                    return
-                time.sleep(0.002)
+            first = self._stt_take(own=False)        # (only replicable, batch-served models reach the shared queues: _stt_route)
+            if first is None:
+                time.sleep(0.005)
                 continue
             if self.batch_window_s > 0:
                 time.sleep(self.batch_window_s)
@@ -631,17 +682,18 @@ class SessionPool:
                         self._lane_replicas.append(replicas[model])
             except BaseException as e:  # noqa: BLE001
                 logger.error("STT worker %d could not build its %s replica: %s", k, model, e, exc_info=True)
-                self._stt_q.put(first)
+                self._stt_q0.put(first)              # the first worker serves it on the engine itself
+                self._wake.set()
                 return
             eng = replicas[model]
             reqs, back = [first], []
             cap = min(self.max_batch, int(getattr(eng, "max_batch", self.max_batch)))
             if self.stt_max_batch > 0:
                 cap = min(cap, self.stt_max_batch)
-            for it in self._drain(self._stt_q, cap - 1):
-                (reqs if isinstance(it, _STTRequest) and it.model == model else back).append(it)
-            for it in back:
-                self._stt_q.put(it)
+            for it in self._stt_fill([], cap - 1, own=False):
+                (reqs if it.model == model else back).append(it)
+            for it in back:                          # (another model's request: rare - two STT models on one pool)
+                self._stt_route(it).put(it)
             self._run_stt(reqs, model, eng)
 
     @staticmethod

@@ -6,6 +6,7 @@ design, :841-858, :910-1003) and the per-session voice override (:506-553).  The
 
 import logging
 import threading
+import time
 from queue import Queue
 from threading import Event
 from types import SimpleNamespace
@@ -228,13 +229,49 @@ def test_cleanup_releases_the_device_pool_with_its_last_handler():
     b.cleanup()
     assert "fake:cleanup" not in SessionPool._pools and eng.closed
     b.cleanup()                                            # idempotent
-    # a handler that was GIVEN its pool does not own it
+    # a pool somebody CONSTRUCTED belongs to that caller: its handlers' cleanup never shuts it down
     p2 = SessionPool("fake:given", max_batch=2, batch_window_ms=1.0, tts_lanes=1)
     c = object.__new__(MI355XParakeetSTTHandler)
     c.pool, c._owns_pool = p2, False
+    p2.attach(c)
     c.cleanup()
     assert not p2._stopping
     p2.shutdown()
+
+
+def test_every_user_of_a_device_pool_is_counted_and_a_failed_setup_lets_go():
+    """(a) a handler that was GIVEN a `for_device` pool, and a direct `for_device` user (server, bench), keep the engines alive
+    after the last self-served handler cleaned up; (b) a setup() that raises after attaching does not leave a stale attachment."""
+    from speech_to_speech_amd.session_pool import release_pool_on_failure
+
+    pool = SessionPool.for_device("fake:users", max_batch=2, batch_window_ms=1.0, tts_lanes=1)
+    eng = FakeTTS(ByteTextFrontend(np.zeros((258, E_), np.float32)))
+    pool._engines["tts"] = eng
+    server = object()
+    pool.attach(server)
+    own, given = object.__new__(MI355XWhisperSTTHandler), object.__new__(MI355XQwen3TTSHandler)
+    own.pool = given.pool = pool
+    pool.attach(own)
+    pool.attach(given)
+    own.cleanup()
+    assert SessionPool._pools.get("fake:users") is pool and not getattr(eng, "closed", False)
+    given.cleanup()
+    assert SessionPool._pools.get("fake:users") is pool and not getattr(eng, "closed", False)      # the server still uses it
+
+    class Boom:
+        pool = None
+
+        @release_pool_on_failure
+        def setup(self):
+            self.pool = pool
+            pool.attach(self)
+            raise RuntimeError("bad checkpoint")
+
+    b = Boom()
+    with pytest.raises(RuntimeError):
+        b.setup()
+    assert b.pool is None and id(b) not in pool._attached
+    assert pool.detach(server) and "fake:users" not in SessionPool._pools and eng.closed
 
 
 # ---- Parakeet: language ID hook + lifecycle ----------------------------------------------------------------------------------------
@@ -296,3 +333,104 @@ def test_cancelled_request_dropped_from_a_backlog_terminates_its_stream():
     dead.cancelled.set()
     assert SessionPool._drop_cancelled([live, dead]) == [live]
     assert dead.chunks.get_nowait() is None and live.chunks.empty()
+
+
+# ---- pool: live partials behind the finals, per-unit skip rule, worker routing ---------------------------
+class _GatedSTT:
+    """Blocks its first batch until released; records what every batch held."""
+
+    max_batch = 4
+
+    def __init__(self):
+        self.batches, self.gate, self.entered = [], threading.Event(), threading.Event()
+
+    def transcribe_batch(self, audios, options):
+        self.batches.append([int(a[0]) for a in audios])
+        self.entered.set()
+        self.gate.wait(10)
+        return [{"ids": [int(a[0])], "language": None, "starts_s": [0.0]} for a in audios]
+
+    def replica(self):
+        return self
+
+    def close(self):
+        pass
+
+
+def _tagged(tag):
+    a = np.zeros(1600, np.float32)
+    a[0] = tag
+    return a
+
+
+def test_pool_serves_finals_before_queued_live_partials_and_drops_none():
+    p = SessionPool("fake:prio", max_batch=4, batch_window_ms=1.0, tts_lanes=1)
+    eng = _GatedSTT()
+    p._engines["parakeet"] = eng
+    out = {}
+    try:
+        def call(tag, live):
+            out[tag] = p.transcribe("parakeet", _tagged(tag), live=live)["ids"]
+
+        first = threading.Thread(target=call, args=(1, False))
+        first.start()
+        assert eng.entered.wait(5)                       # batch [1] is on the engine: everything below queues up behind it
+        ths = [threading.Thread(target=call, args=(10 + k, True)) for k in range(6)]         # six live partials first ...
+        [t.start() for t in ths]
+        while p.stt_backlog() < 6:
+            time.sleep(0.002)
+        fin = [threading.Thread(target=call, args=(2 + k, False)) for k in range(2)]         # ... then two finals
+        [t.start() for t in fin]
+        while p.stt_backlog() < 8:
+            time.sleep(0.002)
+        eng.gate.set()
+        [t.join(10) for t in [first] + ths + fin]
+        assert eng.batches[0] == [1]
+        assert set(eng.batches[1][:2]) == {2, 3} and len(eng.batches[1]) == 4          # the finals lead the next batch, partials fill its free rows
+        assert sorted(sum(eng.batches, [])) == [1, 2, 3, 10, 11, 12, 13, 14, 15]        # every partial was answered: the pool sheds nothing
+        assert all(out[t] == [t] for t in out) and len(out) == 9
+    finally:
+        eng.gate.set()
+        p.shutdown()
+
+
+def test_extra_stt_workers_never_see_what_only_the_first_worker_serves():
+    """builds, host calls and requests for engines without replica() used to be taken and re-appended by the extra workers."""
+    p = SessionPool("fake:route", max_batch=4, batch_window_ms=1.0, tts_lanes=1, stt_workers=2)
+    try:
+        p._engines["norep"] = FakeSTT([7])                                # no replica(): first worker only
+        req_q = p._stt_route(SimpleNamespace(model="norep", live=False))
+        assert req_q is p._stt_q0
+        p._engines["rep"] = _GatedSTT()
+        p._engines["rep"].gate.set()
+        assert p._stt_route(SimpleNamespace(model="rep", live=False)) is p._stt_q and p._stt_route(SimpleNamespace(model="rep", live=True)) is p._stt_pq
+        assert p.transcribe("norep", _tagged(5))["ids"] == [7]
+        assert p.transcribe("rep", _tagged(5))["ids"] == [5]
+        built = []
+        p.ensure_engine("late", lambda: built.append(threading.current_thread().name) or FakeSTT([1]))
+        assert built and built[0].endswith("fake:route")                  # built on the first worker's thread
+    finally:
+        p.shutdown()
+
+
+def test_parakeet_partial_is_skipped_only_while_this_units_own_partial_runs():
+    """Reference STT/parakeet_tdt_handler.py:264-295: `with self._compute_lock_context(timeout=0.01)` - the lock is the handler's own (:129).
+    A deep POOL backlog (other units' work) does not skip a partial; a held lock of this unit does."""
+    p = SessionPool("fake:unit", max_batch=2, batch_window_ms=1.0, tts_lanes=1)
+    try:
+        h = _parakeet(p, "hello there")
+        h.incremental_partials = False
+        for k in range(12):                               # a backlog far beyond max_batch, made of OTHER units' partials
+            threading.Thread(target=lambda k=k: p.transcribe("parakeet", _tagged(k), live=True), daemon=True).start()
+        va = VADAudio(audio=np.zeros(16000, np.float32), mode="progressive", turn_id="t", turn_revision=0)
+        got = list(h.process(va))
+        assert len(got) == 1 and got[0].text == "hello there"
+        h._compute_lock.acquire()
+        try:
+            va2 = VADAudio(audio=np.zeros(24000, np.float32), mode="progressive", turn_id="t", turn_revision=0)
+            assert list(h.process(va2)) == []
+        finally:
+            h._compute_lock.release()
+        assert len(list(h.process(va2))) == 1
+    finally:
+        p.shutdown()

@@ -95,6 +95,26 @@ def test_tile_gemm_straight_line_epilogues(M, N, K):
         assert err < tol
 
 
+def test_gelu_poly_matches_erf_form_over_a_wide_range():
+    """the packed polynomial GELU of the 256 x 256 tile epilogue (csrc/gemm.hip gelu_poly2, interior tiles with a bf16 destination) against
+    the exact erf form on inputs far outside the fitted interval - large negative values must come out as (almost) zero, not as -2e-5 |x|.
+    out[m, n] = gelu(v[m] * 1) with v spanning [-1e4, 1e4]: A[:, 0] = v, W[:, 0] = 1, everything else zero."""
+    M, N, K = 512, 512, 64
+    v = torch.cat([torch.linspace(-8, 8, 256), -torch.logspace(1, 4, 128), torch.logspace(1, 4, 128)]).to(torch.bfloat16)
+    A = torch.zeros(M, K, dtype=torch.bfloat16)
+    A[:, 0] = v
+    W = torch.zeros(N, K, dtype=torch.bfloat16)
+    W[:, 0] = 1.0
+    C = _gemm(A.to(DEV), W.to(DEV), None, None, native.ACT_GELU, torch.bfloat16, M, N, K).float().cpu()
+    ref = torch.nn.functional.gelu(v.double())
+    err = (C.double() - ref[:, None]).abs().max(dim=1).values
+    tol = 2e-4 + ref.abs() * 2.0 ** -8          # the polynomial's 7.9e-5 + one bf16 rounding of the result
+    worst = int((err - tol).argmax())
+    print(f"gelu_poly2: max abs error {err.max().item():.3e}; at v = -1e4: {C[v.float() == v.float().min()][0, 0].item():.3e}")
+    assert bool((err <= tol).all()), (float(v[worst]), float(C[worst, 0]), float(ref[worst]))
+    assert C[v.float() < -4].abs().max().item() < 2e-4        # no linear growth on the negative tail
+
+
 def test_gemm_identity_detects_transposes():
     M = N = K = 128
     A = torch.eye(M, K).to(DEV)

@@ -130,6 +130,19 @@ def test_cached_features_are_bit_identical_to_the_whole_window(rig):
         assert torch.equal(row, eng.frontend.parakeet(pcm, ns, 251, out_dtype=dtype)[0]) and st.stats["restarts"] == 2
         eng.stream_features(st, full[16000:64000], 16000, 301, torch.empty((1, 301, dims.n_mels), dtype=dtype, device="cuda:0"), nf)
         assert st.stats["restarts"] == 3
+        # a buffer that changed BEHIND its tail (re-based / enhanced turn, or a tail of digital silence that looks the same) is
+        # not an extension either - the whole uploaded prefix is checksummed, the stream restarts and the features are those of the new buffer
+        quiet = full[:48000].copy()
+        quiet[-4000:] = 0.0
+        st2 = ProgressiveStream()
+        row = torch.empty((1, 351, dims.n_mels), dtype=dtype, device="cuda:0")
+        eng.stream_features(st2, quiet, 0, 351, row, nf)
+        edited = np.concatenate([quiet, np.zeros(8000, dtype=np.float32)])
+        edited[1000:3000] *= 0.5                           # same length prefix, same last 64 samples, different content before them
+        row = torch.empty((1, 351, dims.n_mels), dtype=dtype, device="cuda:0")
+        eng.stream_features(st2, edited, 0, 351, row, nf)
+        pcm, ns = pack_pcm([edited], eng.device)
+        assert st2.stats["restarts"] == 2 and torch.equal(row, eng.frontend.parakeet(pcm, ns, 351, out_dtype=dtype)[0])
 
 
 @pytest.mark.parametrize("incremental", [False, True])

@@ -18,15 +18,17 @@ for ck in Ch.cheb2poly(c):
     pt = P.polyadd(pt, ck * powu)
     powu = P.polymul(powu, np.array([-1.0, 2 / X0 ** 2]))
 pt = pt.astype(np.float32)
-xs = np.linspace(-8, 8, 400001).astype(np.float32)
+xs = np.concatenate([np.linspace(-8, 8, 400001), -np.logspace(1, 4, 2001), np.logspace(1, 4, 2001)]).astype(np.float32)
 xc = np.clip(xs, -X0, X0)
 t = xc * xc
 q = np.full_like(t, pt[-1])
 for ck in pt[-2::-1]:
     q = q * t + ck
-g = xs * (np.float32(0.5) + xc * q)
+g = np.maximum(xs, np.float32(-X0)) * (np.float32(0.5) + xc * q)      # the multiplicand is clamped below as well: the factor does not decay for x < -X0
 ref = xs.astype(np.float64) * 0.5 * (1 + erf(xs.astype(np.float64) / np.sqrt(2)))
 err = np.abs(g - ref)
 inside = np.abs(xs) <= X0
 print("coefficients (x^0 .. x^%d of x^2):" % deg, [float(v) for v in pt])
-print(f"max |gelu error| all x in [-8, 8]: {err.max():.3e} at x = {xs[err.argmax()]:.3f};  inside [-{X0}, {X0}]: {err[inside].max():.3e}")
+rel = err / np.maximum(np.abs(ref), 1e-30)
+print(f"max |gelu error| over [-1e4, 1e4]: {err[xs <= X0].max():.3e} at x = {xs[xs <= X0][err[xs <= X0].argmax()]:.3f};  inside [-{X0}, {X0}]: {err[inside].max():.3e};  "
+      f"x > {X0}: max relative error {rel[xs > X0].max():.3e}")
