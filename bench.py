@@ -100,8 +100,9 @@ def parse(argv=None):
     ap.add_argument("--tts-merge", type=int, default=None, help="STT turn-batches merged into ONE TTS run on a lane (default 4 for c3: 4 x 64 sessions = 256 rows per decode kernel; "
                     "experimental, default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-sessions", type=int, default=8, help="c3: sessions of the batch decoded by a float32 engine with the SAME weights next to the bf16 engine "
-                    "(token agreement in the line's `parity`; 0 = off)")
+    ap.add_argument("--parity-sessions", type=int, default=-1, help="sessions of the batch decoded by a float32 engine with the SAME weight values next to the bf16 engine: STT ids "
+                    "(Whisper greedy tokens / Parakeet TDT steps) over this many sessions (-1 = the whole batch), TTS codes over min(8, this) sessions x 16 frames x all groups "
+                    "(agreement in the line's `parity`; 0 = off)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the handler / SessionPool open-loop probe")
     ap.add_argument("--boundary-seconds", type=float, default=25.0, help="measurement window of one open-loop probe")
     ap.add_argument("--confirm-probes", type=int, default=2, help="repeats (other arrival phases) of the probe at the sustained session count; a failed repeat steps the figure down")
@@ -130,6 +131,8 @@ def parse(argv=None):
     ap.add_argument("--prof-steps", type=int, default=1, help="extra steps after the timed region used for the kernel-timestamp roofline sample")
     ap.add_argument("--no-graphs", action="store_true", help="launch every decode kernel on the stream instead of replaying captured hipGraphs")
     ap.add_argument("--breakdown", action="store_true", help="per-kernel-family and per-stage times on stderr")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (two rocprofv3 --pmc runs of a reduced step of this same bench, after the timed region)")
+    ap.add_argument("--pmc-timeout", type=float, default=300.0, help="seconds allowed per counter pass")
     return ap.parse_args(argv)
 
 
@@ -154,6 +157,90 @@ def spawn_ranks(args) -> int:
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc
+
+
+# --------------------------------------------------------------------------------------------- live HBM traffic (rocprofv3 --pmc)
+PMC_FAMILIES = {"gemm_dec": ("gemm_dec_kernel", "gemm_dec2_kernel", "gemm_decw_kernel", "gemm_skinny_kernel"),
+                "gemm_tile": ("gemm_tile3_kernel", "gemm_tile4_kernel", "gemm_tile5_kernel", "gemm_tile_kernel"), "attn_mfma": ("attn_mfma_kernel",),
+                "attn_rows": ("attn_step_kernel", "attn_decode_kernel", "attn_rows_kernel")}
+
+
+def pmc_family_sums(out_dir: str, counter: str) -> dict:
+    """{family: (sum of `counter` over its dispatches [KiB], dispatches)} from the counter_collection CSVs rocprofv3 wrote under out_dir."""
+    import csv
+    import glob
+
+    tot = {k: [0.0, 0] for k in PMC_FAMILIES}
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                for fam, pats in PMC_FAMILIES.items():
+                    if any(p in row["Kernel_Name"] for p in pats):
+                        tot[fam][0] += float(row["Counter_Value"])
+                        tot[fam][1] += 1
+                        break
+    return {k: tuple(v) for k, v in tot.items()}
+
+
+def live_hbm_traffic(workload: str, timeout_s: float = 300.0) -> dict:
+    """HBM traffic of every kernel family measured IN THIS RUN (rounds 2 - 5 multiplied by a ratio stored under profiles/): two
+    `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE - they do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a reduced
+    serial run of this same bench (two turn-batches with 4 greedy tokens and one 8-frame TTS chunk each, no probe), each with --kernel-trace only.  Corrections as the
+    guide's HBM section prescribes: both counters are KiB; FETCH_SIZE tallies 64 B per 128-B request for the 16-B-per-lane streaming reads all
+    these kernels issue -> x 2; WRITE_SIZE is taken as is (uncalibrated).  -> {family: {hbm_bytes, dispatches, algorithmic_bytes,
+    hbm_over_algorithmic}} + "command"; {"error": ...} when rocprofv3 is missing, the bench already runs under a profiler, or a pass fails."""
+    import shutil
+    import tempfile
+
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH")) or "rocprofiler-sdk-tool" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "bench.py itself runs under rocprofv3: nested counter passes skipped"}
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    sub = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--serial", "--tts-merge", "1", "--steps", "1", "--warmup", "0", "--prof-steps", "1",
+           "--no-cpu-baseline", "--no-boundary", "--no-pmc", "--parity-sessions", "0", "--decode-tokens", "4", "--reply-frames", "8"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", str(int(os.environ.get("LOCAL_RANK", "0")))) if "WORLD_SIZE" in os.environ else os.environ.get("HIP_VISIBLE_DEVICES", "")
+    if not env["HIP_VISIBLE_DEVICES"]:
+        env.pop("HIP_VISIBLE_DEVICES")
+    root = tempfile.mkdtemp(prefix="s2s_pmc_", dir="/tmp")
+    sums, line = {}, None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(root, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + sub
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            sums[counter] = pmc_family_sums(d, counter)
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    line = json.loads(ln)
+            shutil.rmtree(d, ignore_errors=True)
+    except subprocess.TimeoutExpired:
+        return {"error": f"a counter pass exceeded {timeout_s:g} s"}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    # algorithmic bytes of the reduced run: its own roofline sample (1 step) x the turn-batches it executed (1 timed + 1 sampled, same kernels)
+    fams_sub = ((line or {}).get("roofline") or {}).get("families") or {}
+    alg = {k: v["algorithmic_gb_per_step"] * 1e9 * 2 for k, v in fams_sub.items()}
+    out = {"command": " ".join(["rocprofv3", "--pmc", "<FETCH_SIZE | WRITE_SIZE>", "--kernel-trace", "--"] + ["python", "bench.py"] + sub[2:])}
+    for fam in PMC_FAMILIES:
+        f_kib, n_f = sums["FETCH_SIZE"][fam]
+        w_kib, _ = sums["WRITE_SIZE"][fam]
+        if not n_f:
+            continue
+        hbm = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
+        a = float(alg.get(fam, 0.0))
+        out[fam] = {"dispatches": n_f, "FETCH_SIZE_KiB_sum": round(f_kib, 1), "WRITE_SIZE_KiB_sum": round(w_kib, 1), "hbm_bytes": hbm, "hbm_bytes_per_launch": round(hbm / n_f),
+                    "algorithmic_bytes": a, "hbm_over_algorithmic": round(hbm / a, 4) if a > 0 else None}
+    return out
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline (C1)
@@ -358,7 +445,7 @@ def _rand_tts_sd(dims, g):
 
 # --------------------------------------------------------------------------------------------- boundary probe
 def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_s, n_sessions, window_s, lanes, audios, seed=0, continuous=True, stt_priority=0, stt_workers=1, lead_s=float("inf"), fill_first=0, lane_cus=8, stt_max_batch=0,
-                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0, nursery_priority=0, stt_slots=0, stt_slot_steps=4):
+                   admit_wait_s=0.0, stt_stages=1, partial_windows=(), nursery_slots=0, nursery_priority=0, stt_slots=0, stt_slot_steps=4, whisper_key="large-v3", decode_tokens=32):
     """Open-loop load THROUGH the drop-in boundary: `n_sessions` conversation sessions with uniformly staggered phases, each
     ending an utterance every turn period; every turn is a pipeline-unit's work: MI355X STT handler.process(VADAudio final) ->
     echo -> MI355X TTS handler.process(TTSInput) -> int16[512] blocks.  Handlers share one SessionPool on this GPU (the engines of
@@ -373,10 +460,7 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     from types import SimpleNamespace
 
     from speech_to_speech_amd.boundary import GenerateResponseRequest, TTSInput, VADAudio
-    from speech_to_speech_amd.handlers.qwen3_tts import MI355XQwen3TTSHandler
-    from speech_to_speech_amd.handlers.whisper import MI355XWhisperSTTHandler
     from speech_to_speech_amd.session_pool import SessionPool
-    from speech_to_speech_amd.text import IdTextCodec, WhisperVocab
 
     B = int(getattr(stt_engine, "max_batch", tts_engine.max_batch))      # STT batches; the TTS lane's rows are the TTS engine's slots
     pool = SessionPool(str(dev), max_batch=B, batch_window_ms=4.0, tts_chunk_size=CHUNK_FRAMES, tts_lanes=lanes, continuous=continuous, stt_priority=stt_priority, stt_workers=stt_workers, tts_lead_s=lead_s, tts_fill_first=fill_first, tts_lane_cus=lane_cus, stt_max_batch=stt_max_batch,
@@ -392,48 +476,79 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     if partial_windows:      # C5: a session's thread also lives through its utterance (live partials every 0.5 s)
         workers = int(min(2048, n_sessions * 1.2 + 8))
 
+    # Pipeline units are built the way `speech-to-speech serve` builds them: the registry entries a maintainer adds (INTEGRATION.md section 2,
+    # boundary/registry.py register_mi355x_backends) -> BackendSpec.normalize(arguments dataclass) -> create_handler(HandlerContext, config) ->
+    # Handler.__init__ -> setup() (reference backend_registry.py:206-264).  The probe's pool is registered as the device's pool, so setup()
+    # finds the bench's engines through SessionPool.for_device / ensure_engine instead of building its own (rounds 3 - 5
+    # assembled the handlers with object.__new__ and never ran setup()).
+    from queue import Queue as _Queue
+    from threading import Event as _Event
+
+    from speech_to_speech_amd import arguments as A
+    from speech_to_speech_amd.boundary.registry import HandlerContext, register_mi355x_backends
+
+    STT_B, TTS_B, LLM_B = {}, {}, {}
+    register_mi355x_backends(STT_B, TTS_B, LLM_B)
+    dev_key = str(dev)
+    with SessionPool._pools_lock:
+        SessionPool._pools[dev_key] = pool
+    pace = dict(qwen3_tts_lead_s=float(lead_s), qwen3_tts_admit_wait_ms=float(admit_wait_s) * 1e3) if np.isfinite(lead_s) else {}
+    if stt_model == "whisper":
+        stt_spec = STT_B["mi355x-whisper"]
+        stt_args = A.MI355XWhisperSTTHandlerArguments(stt_model_name=f"synthetic:{whisper_key}", stt_device=dev_key, stt_max_batch=B, stt_batch_window_ms=4.0, language="en",
+                                                      stt_batch_cap=int(stt_max_batch), stt_gen_max_new_tokens=int(decode_tokens))
+    else:
+        stt_spec = STT_B["mi355x-parakeet"]
+        stt_args = A.MI355XParakeetSTTHandlerArguments(parakeet_tdt_model_name="synthetic:tdt-0.6b", parakeet_tdt_device=dev_key, parakeet_tdt_max_batch=B,
+                                                       parakeet_tdt_batch_window_ms=4.0, parakeet_tdt_batch_cap=int(stt_max_batch), parakeet_tdt_max_seconds=float(utt_s), language="en")
+    tts_spec, llm_spec = TTS_B["mi355x-qwen3"], LLM_B["echo"]
+    tts_args = A.MI355XQwen3TTSHandlerArguments(qwen3_tts_model_name="synthetic:1.7b", qwen3_tts_device=dev_key, qwen3_tts_streaming_chunk_size=CHUNK_FRAMES,
+                                                qwen3_tts_max_new_tokens=n_frames, qwen3_tts_blocksize=512, qwen3_tts_max_batch=B, qwen3_tts_batch_window_ms=4.0, qwen3_tts_lanes=lanes, **pace)
+    unit_counter = [0]
+
     def make_handlers():
-        if stt_model == "whisper":
-            s = object.__new__(MI355XWhisperSTTHandler)
-            s.gen_kwargs, s.start_language, s.last_language = {"max_new_tokens": 32}, "en", "en"
-            s.vocab = WhisperVocab.synthetic(stt_engine.dims.vocab)
-            s.task = "transcribe"
-        else:
-            from speech_to_speech_amd.handlers.parakeet import MI355XParakeetSTTHandler
+        with lock:
+            unit_counter[0] += 1
+            idx = unit_counter[0]
 
-            s = object.__new__(MI355XParakeetSTTHandler)
-            s.language = "en"
-        s.tokenizer, s.pool, s._times = IdTextCodec(), pool, []
-        t = object.__new__(MI355XQwen3TTSHandler)
-        t.queue_in, t.queue_out, t._times = _q.Queue(), _q.Queue(), []
-        t.should_listen, t.cancel_scope, t.speculative_turns = None, None, None
-        t.streaming_chunk_size, t.max_new_tokens, t.blocksize, t.pool = CHUNK_FRAMES, n_frames, 512, pool
+        def ctx():
+            return HandlerContext(stop_event=_Event(), queue_in=_Queue(), queue_out=_Queue(), text_output_queue=_Queue(), should_listen=_Event(), cancel_scope=None,
+                                  speculative_turns=None, pipeline_index=idx, sample_rate=16000, enable_live_transcription=bool(partial_windows),
+                                  live_transcription_update_interval=0.5)
+
+        s = stt_spec.create_handler(ctx(), stt_spec.normalize(stt_args))
+        t = tts_spec.create_handler(ctx(), tts_spec.normalize(tts_args))
         t.min_new_tokens = n_frames          # replies of the full length (eos masked), so that every counted turn did the whole work
-        from speech_to_speech_amd.handlers.echo_llm import EchoLLMHandler
-
-        llm = object.__new__(EchoLLMHandler)          # the registered `--llm echo` backend (BASELINE config C1's stub LLM)
-        llm.prefix, llm.cancel_scope, llm.speculative_turns = "", None, None
+        llm = llm_spec.create_handler(ctx(), llm_spec.normalize(A.EchoLLMHandlerArguments()))          # the registered `--llm echo` backend (BASELINE config C1's stub LLM)
         return s, t, llm
 
-    local = threading.local()
     results, lock = [], threading.Lock()
+    units: "_Queue" = _Queue()              # the pipeline units, built before the first arrival (as `serve` builds them at start-up); a turn borrows one
 
     def turn(session, t_arr, in_window):
-        if not hasattr(local, "h"):
-            local.h = make_handlers()
-        stt, tts, llm = local.h
-        n_part, n_part_ans = 0, 0
+        h = units.get()
+        try:
+            return turn_on(h, session, t_arr, in_window)
+        finally:
+            units.put(h)
+
+    def turn_on(h, session, t_arr, in_window):
+        stt, tts, llm = h
+        n_part, n_part_ans, part_lat = 0, 0, []
         full_audio = audios[session % len(audios)]
         for w in partial_windows:            # C5: progressive VADAudio while the user is still speaking (reference VAD handler: 0.5 s cadence)
             tgt = t_arr - utt_s + w
             now = time.perf_counter()
+            n_part += 1                      # every 0.5 s tick of the utterance is a partial the VAD SENT: a tick this unit could not take counts as unanswered
             if tgt > now:
                 time.sleep(tgt - now)
             elif now - tgt > 0.45:
-                continue                     # the previous partial is still running: this tick is skipped (the reference's try-lock-and-skip)
-            n_part += 1
+                continue                     # this unit's previous partial is still running (it holds the unit's STT thread): the tick is lost
             pa = VADAudio(audio=full_audio[: int(w * 16000)], mode="progressive", turn_id=f"s{session}", turn_revision=0, created_at_s=tgt)
-            n_part_ans += len(list(stt.process(pa)))
+            got = len(list(stt.process(pa)))
+            n_part_ans += got
+            if got:
+                part_lat.append(time.perf_counter() - tgt)
         now = time.perf_counter()
         if t_arr > now:
             time.sleep(t_arr - now)
@@ -456,9 +571,13 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
             n_blocks += 1
         with lock:
             results.append({"in_window": in_window, "stt": t_stt, "ttfa": None if t_first is None else t_first - t_arr, "done": time.perf_counter() - t_arr,
-                            "blocks": n_blocks, "late": late, "partials": n_part, "partials_answered": n_part_ans})
+                            "blocks": n_blocks, "late": late, "partials": n_part, "partials_answered": n_part_ans, "partial_lat": part_lat})
 
     rng = np.random.default_rng(seed)
+    t_build0 = time.perf_counter()
+    for _ in range(workers):
+        units.put(make_handlers())
+    t_build = time.perf_counter() - t_build0
     cpu0 = os.times()
     t_wall0 = time.perf_counter()
     t0 = time.perf_counter() + 0.2
@@ -491,6 +610,9 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     stats = dict(pool.stats)
     cpu1 = os.times()
     stats["host_cores_busy"] = round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(time.perf_counter() - t_wall0, 1e-9), 2)
+    with SessionPool._pools_lock:
+        if SessionPool._pools.get(dev_key) is pool:
+            del SessionPool._pools[dev_key]
     pool.shutdown(close_engines=False)      # fails whatever is still queued, stops the lanes, closes the lane replicas; the bench's engines stay open
     torch.cuda.synchronize(dev)
     win = [r for r in results if r["in_window"]]
@@ -506,10 +628,14 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
            "min_blocks_per_turn": blocks[0] if blocks else None, "median_blocks_per_turn": blocks[len(blocks) // 2] if blocks else None,
            "pool": {k: (round(stats[k], 2) if isinstance(stats[k], float) else stats[k]) for k in ("stt_batches", "max_stt_batch", "tts_batches", "tts_requests", "stt_busy_s",
                                                                                                     "tts_rounds", "tts_round_s", "tts_admit_s", "tts_row_rounds", "tts_nursery_rounds", "tts_nursery_s", "host_cores_busy") if k in stats},
-           "p50_ttfa_ms": None, "p95_ttfa_ms": None, "max_playback_lag_ms": None}
+           "p50_ttfa_ms": None, "p95_ttfa_ms": None, "max_playback_lag_ms": None,
+           "pipeline_units": {"built": workers, "how": "registry factories (register_mi355x_backends -> BackendSpec.create_handler -> setup())", "build_s": round(t_build, 2)}}
     if partial_windows and win:
-        res.update(partials_sent=int(sum(r["partials"] for r in win)), partials_answered=int(sum(r["partials_answered"] for r in win)),
-                   partial_passes_per_turn=len(partial_windows))
+        sent, ans = int(sum(r["partials"] for r in win)), int(sum(r["partials_answered"] for r in win))
+        lat = np.array([x for r in win for x in r["partial_lat"]]) * 1e3
+        res.update(partials_sent=sent, partials_answered=ans, partials_answered_frac=round(ans / max(sent, 1), 4), partial_passes_per_turn=len(partial_windows))
+        if len(lat):
+            res.update(p50_partial_ms=round(float(np.percentile(lat, 50)), 1), p95_partial_ms=round(float(np.percentile(lat, 95)), 1))      # tick -> PartialTranscription
     if win:
         stt_l = np.array([r["stt"] for r in win]) * 1e3
         res.update(p50_stt_ms=round(float(np.percentile(stt_l, 50)), 1), p95_stt_ms=round(float(np.percentile(stt_l, 95)), 1))      # arrival -> transcript
@@ -519,20 +645,32 @@ def boundary_probe(stt_engine, stt_model, tts_engine, front, dev, n_frames, utt_
     return res
 
 
-def sustained_search(probe, n_hint, bound_ms, max_probes=6, start=0.7):
-    """Largest N (bisected to about +-5 %) whose turns all complete - full-length replies - in real time with p95 TTFA <= bound.  Starts at
-    `start` x the closed-loop throughput of the timed region and moves by +-25 % / bisection."""
-    def ok(r):
-        return (r["turns_completed"] >= r["turns_arrived"] and r["p95_ttfa_ms"] is not None and r["p95_ttfa_ms"] <= bound_ms
-                and r["max_playback_lag_ms"] <= 0.0)
+MIN_PARTIALS_ANSWERED = 0.9      # C5: a probe is sustained only if at least this share of the live partials SENT (every 0.5 s tick) was answered
 
+
+def probe_sustained(r, bound_ms):
+    """The sustained-load criterion of one open-loop probe: every turn that arrived in the window completed with its full-length reply, no block
+    later than its playback instant, p95 time-to-first-audio within the bound and - with live partials (C5) - at least MIN_PARTIALS_ANSWERED of the
+    partials sent were answered (VERDICT r5 weak #4: rounds 4 - 5 looked at final turns only while a third of the partials was shed)."""
+    ok = (r["turns_completed"] >= r["turns_arrived"] and r["p95_ttfa_ms"] is not None and r["p95_ttfa_ms"] <= bound_ms and r["max_playback_lag_ms"] <= 0.0)
+    if "partials_sent" in r:
+        ok = ok and r["partials_answered"] >= MIN_PARTIALS_ANSWERED * r["partials_sent"]
+    return bool(ok)
+
+
+def sustained_search(probe, n_hint, bound_ms, max_probes=6, start=0.7, extra_probes=3):
+    """Largest N (bisected to about +-5 %) whose probe meets `probe_sustained`.  Starts at `start` x the closed-loop throughput of the timed region
+    and moves by +-25 % / bisection; while no probe has FAILED yet the search keeps stepping up (up to `extra_probes` more) so that the figure is a
+    knee, not just the largest load tried."""
     tried = []
     lo, hi = 0, None
     n = max(1, int(n_hint * start))
     best = None
-    for _ in range(max_probes):
+    k = 0
+    while k < max_probes or (hi is None and k < max_probes + extra_probes):
+        k += 1
         r = probe(n)
-        r["sustained"] = ok(r)
+        r["sustained"] = probe_sustained(r, bound_ms)
         tried.append(r)
         if r["sustained"]:
             lo, best = n, r
@@ -639,9 +777,9 @@ def main():
             return ids
         # VERDICT r4 #2b: what the bf16 serving engine's greedy ids are worth on THIS batch - a float32 engine (the bit-exact policy,
         # tests/test_full_depth_gpu.py) with the same weight values decodes the first sessions next to it; outside the timed region
-        if args.parity_sessions > 0 and rank == 0 and not args.probe_only:
+        if args.parity_sessions != 0 and rank == 0 and not args.probe_only:
             try:
-                n_par = min(int(args.parity_sessions), B)
+                n_par = B if args.parity_sessions < 0 else min(int(args.parity_sessions), B)
                 ref = WhisperEngine(wdims, None, torch.float32, max_batch=n_par, device=dev, engine_tensors={k: v.float() for k, v in stt._weights.items() if not k.endswith((".f", ".lf", ".lb", ".cs"))})      # (not the bf16 engine's derived decode layouts)
                 ref.encode(ref.features(audios[:n_par]))
                 want, _ = ref.decode(prompt[:n_par], eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
@@ -651,7 +789,7 @@ def main():
                 got, _ = stt.decode(prompt[:n_par], eos=eos, max_new_tokens=args.decode_tokens, suppress=[eos])
                 first = [next((k for k, (a, b) in enumerate(zip(g_, w_)) if a != b), len(w_)) for g_, w_ in zip(got, want)]
                 tot = sum(len(w_) for w_ in want)
-                parity = {"what": f"greedy ids of the bf16 engine vs a float32 engine with the same weight values, first {n_par} sessions of the batch, {args.decode_tokens} tokens each "
+                parity = {"what": f"greedy ids of the bf16 engine vs a float32 engine with the same weight values, {'all' if n_par == B else 'first'} {n_par} sessions of the batch, {args.decode_tokens} tokens each "
                                   "(random-init weights: near-ties are as frequent as the logit statistics of an untrained model make them; the float32 engine itself is "
                                   "bit-exact against the CPU oracle at this depth, tests/test_full_depth_gpu.py)",
                           "sessions": n_par, "tokens": tot, "sessions_identical": sum(int(f == len(w_)) for f, w_ in zip(first, want)),
@@ -680,15 +818,68 @@ def main():
                 stt_pass(n_dev, w)
             return stt_pass(ns, utt_s)
 
+        # the same in-line statement for the TDT path (C2 / C5) - every step (token incl. blanks, duration, frame) of the bf16 engine
+        # against a float32 engine with the same weight values (the float32 engine is step-exact against the CPU oracle, tests/test_full_depth_gpu.py)
+        if args.parity_sessions != 0 and rank == 0 and not args.probe_only:
+            try:
+                n_par = B if args.parity_sessions < 0 else min(int(args.parity_sessions), B)
+                ref = ParakeetEngine(pd, None, dtype=torch.float32, max_batch=n_par, max_seconds=utt_s, device=dev, engine_tensors={k: v.float() for k, v in stt._weights.items()})
+                f_r, nf_r, _ = ref.features(audios[:n_par])
+                ref.encode(f_r, nf_r)
+                want = list(zip(*ref.tdt_greedy()))
+                ref.close()
+                del ref
+                f_b, nf_b, _ = stt.features(audios[:n_par])
+                stt.encode(f_b, nf_b)
+                got = list(zip(*stt.tdt_greedy()))
+                steps_w = [list(zip(*w_)) for w_ in want]      # per session: [(token, duration, frame), ...]
+                steps_g = [list(zip(*g_)) for g_ in got]
+                first = [next((k for k, (a, b) in enumerate(zip(g_, w_)) if a != b), min(len(g_), len(w_))) for g_, w_ in zip(steps_g, steps_w)]
+                tot = sum(len(w_) for w_ in steps_w)
+                parity = {"what": f"TDT greedy steps (token incl. blanks, duration, frame) of the bf16 engine vs a float32 engine with the same weight values, {n_par} session(s) x "
+                                  f"{utt_s:g} s (random-init weights; the float32 engine is step-exact against the CPU oracle at this depth, tests/test_full_depth_gpu.py)",
+                          "sessions": n_par, "steps": tot, "sessions_identical": sum(int(g_ == w_) for g_, w_ in zip(steps_g, steps_w)),
+                          "steps_before_first_difference": sum(first), "agreement": round(sum(first) / max(tot, 1), 4)}
+                torch.cuda.empty_cache()
+            except Exception as ex:  # pragma: no cover
+                parity = {"error": repr(ex)}
+
     tts = None
     tts_replicas = []
     front = None
+    tts_parity = None
     if not args.stt_only:
         K = 1 if args.serial else max(1, args.tts_lanes if args.tts_lanes is not None else (2 if wl == "c3" else 3))      # (c3: 2 lanes x 256-row runs; small workloads: 3 as in round 3)
         tts = TTSEngine.from_random(tdims, torch.bfloat16, max_batch=TMB, max_prompt=128, max_frames=n_frames, max_codec_frames=CHUNK_FRAMES, device=dev, seed=rank)
         tts_replicas = [tts] + [tts.replica() for _ in range(K - 1)]
         g = torch.Generator().manual_seed(7)
         front = ByteTextFrontend((torch.randn(258, tdims.t_hidden, generator=g)).numpy())
+        # the in-line parity statement for the TTS frame loop - codec codes of the bf16 serving engine against a float32 engine with
+        # the same weight values (the float32 engine is bit-exact against the CPU oracle at this depth: 28 + 5 layers, tests/test_full_depth_gpu.py),
+        # free-running greedy decode of 16 frames x all code groups, outside the timed region
+        if args.parity_sessions != 0 and rank == 0 and not args.probe_only:
+            try:
+                n_tp, n_tf = min(8, B if args.parity_sessions < 0 else int(args.parity_sessions), B), min(16, n_frames)
+                texts = [f"parity prompt {k}: hello from the speech to speech benchmark" for k in range(n_tp)]
+                t_prompts = [TTSPrompt(front.embed(t_, 128)) for t_ in texts]
+                ref = TTSEngine(tdims, None, torch.float32, n_tp, 128, n_frames, CHUNK_FRAMES, None, dev,
+                                engine_tensors={k: (v.float() if v.dtype == torch.bfloat16 else v) for k, v in tts._weights.items() if not k.endswith(".f")})
+                ref.prefill(t_prompts)
+                want = ref.generate(n_tf, min_total_frames=n_tf)[0].cpu().long()
+                ref.close()
+                del ref
+                tts.prefill(t_prompts)
+                got = tts.generate(n_tf, min_total_frames=n_tf)[0].cpu().long()[:n_tp]
+                flat_g, flat_w = got.reshape(n_tp, -1), want.reshape(n_tp, -1)
+                first = [int((flat_g[b] != flat_w[b]).nonzero()[0]) if bool((flat_g[b] != flat_w[b]).any()) else flat_w.shape[1] for b in range(n_tp)]
+                tts_parity = {"what": f"codec codes of the bf16 engine vs a float32 engine with the same weight values: {n_tp} sessions x {n_tf} frames x {tdims.n_groups} groups, "
+                                      "free-running greedy decode (after a first differing code the two streams are different utterances)",
+                              "sessions": n_tp, "codes": int(flat_w.numel()), "sessions_identical": sum(int(f == flat_w.shape[1]) for f in first),
+                              "codes_before_first_difference": int(sum(first)), "agreement": round(sum(first) / max(flat_w.numel(), 1), 4),
+                              "positionwise_agreement": round(float((flat_g == flat_w).float().mean()), 4)}
+                torch.cuda.empty_cache()
+            except Exception as ex:  # pragma: no cover
+                tts_parity = {"error": repr(ex)}
     codec = IdTextCodec()
     stage = {"stt": 0.0, "tts_first_chunk": 0.0, "tts_total": 0.0}
     stage_lock = threading.Lock()
@@ -829,7 +1020,8 @@ def main():
                 return boundary_probe(stt, stt_model, tts, front, dev, n_frames, utt_s, n, window, lanes, audios, continuous=not args.turn_batches,
                                       stt_priority=args.stt_priority, stt_workers=args.stt_workers, lead_s=args.tts_lead_s, fill_first=args.tts_fill_first, lane_cus=args.tts_lane_cus, stt_max_batch=args.stt_max_batch,
                                       admit_wait_s=args.tts_admit_wait_s, seed=seed, stt_stages=args.stt_stages, partial_windows=tuple(partial_windows), nursery_slots=args.tts_nursery_slots, nursery_priority=args.tts_nursery_priority,
-                                      stt_slots=args.stt_slots, stt_slot_steps=args.stt_slot_steps)
+                                      stt_slots=args.stt_slots, stt_slot_steps=args.stt_slot_steps, whisper_key={"c3": "large-v3", "c1": "tiny.en"}.get(wl, "test-tiny"),
+                                      decode_tokens=args.decode_tokens)
 
             single = None if args.probe_only else probe(1, window=12.0)
             if B > 1 and not args.probe_sessions:
@@ -837,6 +1029,8 @@ def main():
             best, tried = (None, [])
             if args.probe_sessions:      # fixed probes (A/B runs), no search
                 tried = [probe(int(n)) for n in args.probe_sessions.split(",")]
+                for r in tried:
+                    r["sustained"] = probe_sustained(r, args.ttfa_bound_ms)
             elif B > 1:
                 # (start 0.6 x the closed-loop rate, <= 6 probes: lands within 3 % of the knee for closed-loop rates of 1.3 .. 2.2 x the knee -
                 # the driver's 20-step timed region amortises the pipeline tail and reports a higher closed-loop rate than an 8-step run)
@@ -851,8 +1045,7 @@ def main():
                     ok_all = True
                     for k in range(max(0, args.confirm_probes)):
                         rr = probe(int(cand["sessions"]), seed=101 + k)
-                        rr["sustained"] = (rr["turns_completed"] >= rr["turns_arrived"] and rr["p95_ttfa_ms"] is not None and rr["p95_ttfa_ms"] <= args.ttfa_bound_ms
-                                           and rr["max_playback_lag_ms"] <= 0.0)
+                        rr["sustained"] = probe_sustained(rr, args.ttfa_bound_ms)
                         rr["repeat_of"] = int(cand["sessions"])
                         repeats.append(rr)
                         ok_all = ok_all and rr["sustained"]
@@ -870,8 +1063,7 @@ def main():
                     n_low = int(0.7 * n_low)
                     pair = [probe(n_low, seed=sd) for sd in (0, 101)]
                     for rr in pair:
-                        rr["sustained"] = (rr["turns_completed"] >= rr["turns_arrived"] and rr["p95_ttfa_ms"] is not None and rr["p95_ttfa_ms"] <= args.ttfa_bound_ms
-                                           and rr["max_playback_lag_ms"] <= 0.0)
+                        rr["sustained"] = probe_sustained(rr, args.ttfa_bound_ms)
                         rr["repeat_of"] = n_low
                     repeats.extend(pair)
                     if all(rr["sustained"] for rr in pair):
@@ -899,7 +1091,8 @@ def main():
                         "at_sustained": best, "single_session": single, "probes": tried, "repeats": repeats,
                         "spread_at_sustained": spread,
                         "criteria": "every turn arriving in the window completes with its full-length reply, no block later than its playback instant (>= 1.0 xRT), "
-                                    f"p95 TTFA <= bound; bisected to about +-5 %, then confirmed by {args.confirm_probes} repeat(s) with other arrival phases (`repeats`)"}
+                                    + (f">= {MIN_PARTIALS_ANSWERED:.0%} of the live partials sent (one per 0.5 s tick of every utterance) answered with a PartialTranscription, " if partial_windows else "")
+                                    + f"p95 TTFA <= bound; bisected to about +-5 %, then confirmed by {args.confirm_probes} repeat(s) with other arrival phases (`repeats`)"}
         except Exception as ex:  # pragma: no cover
             boundary = {"error": repr(ex)}
             sum_over_ranks(0)
@@ -946,17 +1139,29 @@ def main():
         dom = max(fams, key=lambda k: fams[k]["kernel_ms_per_step"])
         roof = dict(fams[dom])
         roof["traffic"] = None
-        # HBM traffic of the dominant family from the PMC counters: FETCH_SIZE (x2 on gfx950 for 16 B/lane streaming reads) + WRITE_SIZE,
-        # separate rocprofv3 --pmc passes over a REDUCED step of this same bench (tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json);
-        # the measured / algorithmic ratio of that run is applied to this run's algorithmic bytes per launch
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
-        if pmc_path:
-            pm = json.load(open(pmc_path)).get(dom)
-            if pm:
-                per_launch = fams[dom]["algorithmic_gb_per_step"] * 1e9 / max(fams[dom]["launches_per_step"], 1)
-                roof["traffic"] = round(pm["hbm_over_algorithmic"] * per_launch)
-                roof["traffic_note"] = (f"bytes per launch = {pm['hbm_over_algorithmic']:.3f} x this run's algorithmic bytes per launch; ratio measured with rocprofv3 --pmc "
-                                        f"FETCH_SIZE / WRITE_SIZE (separate passes) over a reduced step of this bench ({pm.get('command', '')})")
+        # HBM traffic of the dominant family from the PMC counters, measured in THIS run: FETCH_SIZE (x2 on gfx950 for 16 B/lane streaming reads) +
+        # WRITE_SIZE, separate rocprofv3 --pmc passes over a REDUCED step of this same bench right after the timed region (live_hbm_traffic); the
+        # measured / algorithmic ratio of those passes is applied to this run's algorithmic bytes per launch.  Only when rocprofv3 cannot run
+        # (not installed, or bench.py is itself being profiled) the ratio stored under profiles/ by an earlier round is used - and labelled so.
+        pm_all, src = None, None
+        if not args.no_pmc and world == 1:
+            pm_all = live_hbm_traffic(wl, args.pmc_timeout)
+            src = "live: rocprofv3 --pmc passes run by this bench.py invocation"
+            if "error" in pm_all:
+                roof["traffic_live_error"] = pm_all["error"]
+                pm_all = None
+        if pm_all is None:
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
+            if pmc_path:
+                pm_all, src = json.load(open(pmc_path)), f"STORED ratio from {os.path.relpath(pmc_path, ROOT)} (no live counter pass in this run)"
+        pm = (pm_all or {}).get(dom)
+        if pm and pm.get("hbm_over_algorithmic"):
+            per_launch = fams[dom]["algorithmic_gb_per_step"] * 1e9 / max(fams[dom]["launches_per_step"], 1)
+            roof["traffic"] = round(pm["hbm_over_algorithmic"] * per_launch)
+            roof["traffic_source"] = src
+            roof["traffic_note"] = (f"bytes per launch = {pm['hbm_over_algorithmic']:.3f} x this run's algorithmic bytes per launch; ratio = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
+                                    f"summed over the family's {pm.get('dispatches')} dispatches of the reduced pass / its algorithmic bytes ({(pm_all or {}).get('command') or pm.get('command', '')})")
+            roof["traffic_families"] = {k: {kk: v.get(kk) for kk in ("dispatches", "hbm_bytes_per_launch", "hbm_over_algorithmic")} for k, v in pm_all.items() if isinstance(v, dict) and "dispatches" in v}
         roof["families"] = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "kernel_ms_per_step", "avg_kernel_us",
                                                      "algorithmic_gb_per_step", "algorithmic_tflop_per_step", "frac_predictor_weights_once_per_frame",
                                                      "predictor_weight_rereads_gb_per_step") if kk in v}
@@ -992,9 +1197,11 @@ def main():
     }
     if boundary is not None:
         line["boundary"] = boundary
-    if parity is not None:
-        line["parity"] = parity
-    if not args.no_cpu_baseline and world == 1:
+    if parity is not None or tts_parity is not None:
+        line["parity"] = dict(parity or {})
+        if tts_parity is not None:
+            line["parity"]["tts"] = tts_parity
+    if not args.no_cpu_baseline:       # (rank 0 of any world size: an N > 1 line carries the baseline too - VERDICT r5 #15)
         try:
             line["cpu_baseline"] = cpu_baseline_c1()
         except Exception as ex:  # pragma: no cover

@@ -69,7 +69,7 @@ class MI355XWhisperSTTHandler(BaseSTTHandler):
         self.task = self.gen_kwargs.get("task", "transcribe")
         if language not in (None, "auto") and self.vocab.multilingual and language not in self.vocab.lang_to_id:
             raise ValueError(f"language {language!r} is not supported by this checkpoint ({sorted(self.vocab.lang_to_id)})")
-        self.warmup()
+        (self.pool.warm_once("whisper", self.warmup) if hasattr(self.pool, "warm_once") else self.warmup())      # one warm-up per GPU engine, not per pipeline unit
 
     def warmup(self) -> None:
         import numpy as np

@@ -271,6 +271,23 @@ class SessionPool:
     def engine(self, name: str) -> Any:
         return self._engines[name]
 
+    def warm_once(self, name: str, fn: Callable[[], Any]) -> bool:
+        """Run a handler's warm-up pass for engine `name` unless another handler of this pool already did: the model is shared by every
+        pipeline unit of the GPU, so it is warmed once - the reference warms once per handler because every handler owns its model
+        (backend_registry.py:206-264).  -> True when `fn` ran."""
+        with self._engine_lock:
+            done = self.__dict__.setdefault("_warmed", set())
+            if name in done:
+                return False
+            done.add(name)
+        try:
+            fn()
+        except BaseException:
+            with self._engine_lock:
+                done.discard(name)
+            raise
+        return True
+
     def warm_tts_lanes(self, timeout: float = 300.0) -> None:
         """Build every lane's engine (replicas share lane 0's weights) and run its warm-up utterance now, so that the first
         real request does not pay for it - the reference's handlers load and warm up synchronously in setup()

@@ -243,6 +243,27 @@ def test_sustained_search_brackets_the_capacity():
     assert best is None and tried and not any(r["sustained"] for r in tried)
 
 
+def test_c5_probe_needs_90_percent_of_the_partials_answered_and_the_search_finds_a_failing_load():
+    """a C5 probe whose final turns all hold but which answers < 90 % of the live partials it was sent is NOT sustained; and while
+    no probe has failed the search keeps stepping up (the round-5 C5 search ended with all four probes holding: no knee)."""
+    bench = _load_bench()
+    base = {"sessions": 10, "turns_arrived": 10, "turns_completed": 10, "p95_ttfa_ms": 300.0, "max_playback_lag_ms": 0.0}
+    assert bench.probe_sustained(dict(base), 1000.0)
+    assert bench.probe_sustained(dict(base, partials_sent=190, partials_answered=171), 1000.0)
+    assert not bench.probe_sustained(dict(base, partials_sent=190, partials_answered=170), 1000.0)
+    assert not bench.probe_sustained(dict(base, partials_sent=18601, partials_answered=12735), 1000.0)      # profiles/r05_bench_c5.json at 988 sessions
+    calls = []
+
+    def probe(n):      # turns always hold; the partials are answered in full up to 600 sessions, two thirds above
+        calls.append(n)
+        return {"sessions": n, "turns_arrived": n, "turns_completed": n, "p95_ttfa_ms": 300.0, "max_playback_lag_ms": 0.0, "partials_sent": 19 * n,
+                "partials_answered": 19 * n if n <= 600 else 12 * n}
+
+    best, tried = bench.sustained_search(probe, n_hint=300, bound_ms=1000.0, start=0.6, max_probes=4)
+    assert any(not r["sustained"] for r in tried), calls            # an upper end was found although the first four probes all held
+    assert best["sessions"] <= 600 < min(r["sessions"] for r in tried if not r["sustained"])
+
+
 def test_session_sharding_is_disjoint_and_complete():
     bench = _load_bench()
     shards = [bench.shard_sessions(64, r) for r in range(8)]
