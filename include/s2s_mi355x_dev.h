@@ -44,6 +44,17 @@ int32_t s2s_op_gemm_dec_debug(void* dbg_dev);
  * (tools/tile5_phases.py) */
 int32_t s2s_op_gemm_tile_debug(void* dbg_dev);
 
+/* The decode-step attention of the Qwen3 stacks and the Whisper decoder's self-attention as an operator (csrc/attention.hip attn_step_kernel):
+ * per-head RMSNorm of q / k (qw / kw, null = none), rotary embedding at pos[b] (cos_t / sin_t [max_pos][D/2], null = none), append of the new
+ * K / V row at cache row pos[b], attention over cache[jlo, pos[b]) + the new row.  qkv row b = [H q heads | Hkv k heads | Hkv v heads] x D;
+ * K / V element (b, j, hk, d) at base + b*kv_bs + j*kv_rs + hk*D + d; O row b at O + b*o_bs (o_frag: fragment-major [B][H*D], gemm_dec layout).
+ * s2s_op_attn_step_tune(share): 1 = grouped heads (H / Hkv = 2 or 4) share one workgroup per KV head (round 6, default), 0 = one workgroup
+ * per query head (rounds 2 - 5), -1 = default / environment S2S_ATTN_STEP_GQA.  tests/test_attention_gpu.py checks the two bit for bit. */
+int32_t s2s_op_attn_step(void* stream, const void* qkv, int64_t qkv_rs, void* K, void* V, int64_t kv_bs, int64_t kv_rs, void* O, int64_t o_bs,
+                         const float* qw, const float* kw, float eps, const float* cos_t, const float* sin_t, const int32_t* pos_dev, int32_t B,
+                         int32_t H, int32_t Hkv, int32_t D, int32_t kv_cap, int32_t window, float scale, int32_t o_frag, int32_t dtype);
+int32_t s2s_op_attn_step_tune(int32_t share);
+
 /* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
  * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */
 int32_t s2s_graph_bench_begin(void** out_stream);

@@ -283,73 +283,87 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnRowsParams p) {
 // (head, session); the q heads of a GQA group each rebuild the (tiny) new K row, the group's first head stores it.
 // Same key split / chunk-lane layout as attn_decode_kernel.  Replaces rope_qknorm + kv_append + attn_decode launches.
 // ------------------------------------------------------------------------------------
-template <typename T, int D>
+// GQ > 1 (round 6): ONE workgroup per (KV head, session) serves the GQ query heads of the group - every K / V row is loaded once and
+// multiplied with all of them.  With one workgroup per QUERY head the two heads of a Qwen3-TTS group (16 Q / 8 KV) sat on different XCDs
+// (consecutive block ids go round-robin over the 8 L2s) and each streamed the group's cache rows from HBM: 2 x the traffic of the kernel that
+// bounds the talker step at 512 rows (0.35 GB per layer and step).  Per-head arithmetic - the key split over waves, the chunk-lane layout,
+// every reduction order - is exactly the GQ = 1 kernel's, so the outputs are bit-identical to it.  GQ = 1: one workgroup per query head, any
+// group size (runtime), as before.
+template <typename T, int D, int GQ>
 __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
     constexpr int EPL = 16 / (int)sizeof(T);
     constexpr int CH = D / EPL;
     constexpr int KPI = 64 / CH;
     constexpr int HALF = D / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sc = smem;                               // [kv_cap + 8]
-    float* red = smem + p.kv_cap + 8;               // [8] + [4][D]
-    float* sq = red + 8 + 4 * D;                    // [D] scaled, rotated query
-    float* sk = sq + D;                             // [D] new key (values as stored in the cache)
+    const int sc_ld = p.kv_cap + 8;
+    float* sc = smem;                               // [GQ][kv_cap + 8]
+    float* red = smem + GQ * sc_ld;                 // per head: [8] + [4][D]
+    constexpr int RED_LD = 8 + 4 * D;
+    float* sq = red + GQ * RED_LD;                  // [GQ][D] scaled, rotated queries
+    float* sk = sq + GQ * D;                        // [D] new key (values as stored in the cache)
     float* sv = sk + D;                             // [D] new value
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int group = p.H / p.Hkv, hk = h / group;
+    const int b = blockIdx.y;
+    const int group = p.H / p.Hkv;
+    const int hk = GQ > 1 ? (int)blockIdx.x : (int)blockIdx.x / group;
+    const int h0 = GQ > 1 ? hk * GQ : (int)blockIdx.x;            // first (GQ = 1: the only) query head of this workgroup
+    const bool owns_kv = GQ > 1 || h0 % group == 0;               // this workgroup appends the new K / V row to the cache
     const int pos = p.pos[b];
     const T* row = (const T*)p.qkv + (long)b * p.qkv_rs;
     T* Kc = (T*)p.K + (long)b * p.kv_bs + (long)hk * D;
     T* Vc = (T*)p.V + (long)b * p.kv_bs + (long)hk * D;
 
-    // ---- new row: wave 0 -> q, wave 1 -> k (same arithmetic as rope_qknorm_kernel), wave 2 -> v ----
-    if (wave < 2) {
-        const T* x = row + (wave == 0 ? (long)h * D : (long)(p.H + hk) * D);
-        const float* w = wave == 0 ? p.qw : p.kw;
-        float a = 0.f, c = 0.f;
-        if (lane < HALF) {
-            a = Elem<T>::ld(x + lane);
-            c = Elem<T>::ld(x + lane + HALF);
-        }
-        if (w) {
-            const float ss = wave_sum(a * a + c * c);
-            const float r = rsqrtf(ss / (float)D + p.eps);
+    // ---- new row: tasks 0 .. GQ-1 -> the queries, GQ -> k (same arithmetic as rope_qknorm_kernel), GQ + 1 -> v; one task per wave and round ----
+    for (int task = wave; task < GQ + 2; task += 4) {
+        if (task <= GQ) {
+            const bool is_q = task < GQ;
+            const T* x = row + (is_q ? (long)(h0 + task) * D : (long)(p.H + hk) * D);
+            const float* w = is_q ? p.qw : p.kw;
+            float a = 0.f, c = 0.f;
             if (lane < HALF) {
-                a = a * r * w[lane];
-                c = c * r * w[lane + HALF];
+                a = Elem<T>::ld(x + lane);
+                c = Elem<T>::ld(x + lane + HALF);
             }
-        }
-        if (lane < HALF) {
-            float r0 = a, r1 = c;
-            if (p.cosT) {
-                const float cs = p.cosT[(long)pos * HALF + lane], sn = p.sinT[(long)pos * HALF + lane];
-                r0 = a * cs - c * sn;
-                r1 = c * cs + a * sn;
-            }
-            // round through the storage type exactly like the unfused path (q was written back, k goes to the cache)
-            T t0, t1;
-            Elem<T>::st(&t0, r0);
-            Elem<T>::st(&t1, r1);
-            const float f0 = Elem<T>::ld(&t0), f1 = Elem<T>::ld(&t1);
-            if (wave == 0) {
-                sq[lane] = f0 * p.scale;
-                sq[lane + HALF] = f1 * p.scale;
-            } else {
-                sk[lane] = f0;
-                sk[lane + HALF] = f1;
-                if (h % group == 0) {
-                    Kc[(long)pos * p.kv_rs + lane] = t0;
-                    Kc[(long)pos * p.kv_rs + lane + HALF] = t1;
+            if (w) {
+                const float ss = wave_sum(a * a + c * c);
+                const float r = rsqrtf(ss / (float)D + p.eps);
+                if (lane < HALF) {
+                    a = a * r * w[lane];
+                    c = c * r * w[lane + HALF];
                 }
             }
-        }
-    } else if (wave == 2) {
-        const T* x = row + (long)(p.H + p.Hkv + hk) * D;
-        for (int d = lane; d < D; d += 64) {
-            const T t = x[d];
-            sv[d] = Elem<T>::ld(&t);
-            if (h % group == 0) Vc[(long)pos * p.kv_rs + d] = t;
+            if (lane < HALF) {
+                float r0 = a, r1 = c;
+                if (p.cosT) {
+                    const float cs = p.cosT[(long)pos * HALF + lane], sn = p.sinT[(long)pos * HALF + lane];
+                    r0 = a * cs - c * sn;
+                    r1 = c * cs + a * sn;
+                }
+                // round through the storage type exactly like the unfused path (q was written back, k goes to the cache)
+                T t0, t1;
+                Elem<T>::st(&t0, r0);
+                Elem<T>::st(&t1, r1);
+                const float f0 = Elem<T>::ld(&t0), f1 = Elem<T>::ld(&t1);
+                if (is_q) {
+                    sq[task * D + lane] = f0 * p.scale;
+                    sq[task * D + lane + HALF] = f1 * p.scale;
+                } else {
+                    sk[lane] = f0;
+                    sk[lane + HALF] = f1;
+                    if (owns_kv) {
+                        Kc[(long)pos * p.kv_rs + lane] = t0;
+                        Kc[(long)pos * p.kv_rs + lane + HALF] = t1;
+                    }
+                }
+            }
+        } else {
+            const T* x = row + (long)(p.H + p.Hkv + hk) * D;
+            for (int d = lane; d < D; d += 64) {
+                const T t = x[d];
+                sv[d] = Elem<T>::ld(&t);
+                if (owns_kv) Vc[(long)pos * p.kv_rs + d] = t;
+            }
         }
     }
     __syncthreads();
@@ -357,15 +371,19 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
     const int jlo = p.window > 0 ? max(0, pos - p.window + 1) : 0;
     const int nc = pos - jlo;                       // cached keys [jlo, pos); the new key is entry nc
     const int c = lane % CH, slot = lane / CH;
-    float q[EPL];
+    float q[GQ][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) q[e] = sq[c * EPL + e];
+    for (int g = 0; g < GQ; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[g][e] = sq[g * D + c * EPL + e];
     const T* Kb = Kc + c * EPL;
     const T* Vb = Vc + c * EPL;
     const int per = ((nc + 3) / 4 + KPI - 1) / KPI * KPI;
     const int w0 = jlo + wave * per, w1 = min(pos, w0 + per);
 
-    float mx = -INFINITY;
+    float mx[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) mx[g] = -INFINITY;
     constexpr int UN = 4;
     for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
         u32x4_t kvv[UN];
@@ -379,113 +397,156 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u * KPI + slot;
             const u32x4_t v = kvv[u];
-            float s = 0.f;
-            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s = fmaf(__uint_as_float(v[e] << 16), q[2 * e], s);
-                    s = fmaf(__uint_as_float(v[e] & 0xffff0000u), q[2 * e + 1], s);
+            for (int g = 0; g < GQ; ++g) {
+                float s = 0.f;
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s = fmaf(__uint_as_float(v[e] << 16), q[g][2 * e], s);
+                        s = fmaf(__uint_as_float(v[e] & 0xffff0000u), q[g][2 * e + 1], s);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(v[e]), q[g][e], s);
                 }
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(v[e]), q[e], s);
-            }
-#pragma unroll
-            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
-            if (j < w1) {
-                if (c == 0) sc[j - jlo] = s;
-                mx = fmaxf(mx, s);
+                for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
+                if (j < w1) {
+                    if (c == 0) sc[g * sc_ld + j - jlo] = s;
+                    mx[g] = fmaxf(mx[g], s);
+                }
             }
         }
     }
-    // the new key: every wave forms the same dot product from LDS (D <= 128: two elements per lane)
-    float sn = 0.f;
-    for (int d = lane; d < D; d += 64) sn = fmaf(sq[d], sk[d], sn);
-    sn = wave_sum(sn);
-    mx = fmaxf(wave_max(mx), sn);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int j = tid; j < nc; j += 256) {
-        const float e = expf(sc[j] - mx);
-        sc[j] = e;
-        sum += e;
-    }
-    const float pn = expf(sn - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    sum = ((red[4] + red[5]) + (red[6] + red[7])) + pn;
-    const float inv = 1.0f / sum;
-
-    float acc[EPL];
+    // the new key: every wave forms the same dot products from LDS (D <= 128: two elements per lane)
+    float sn[GQ];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int g = 0; g < GQ; ++g) {
+        float t = 0.f;
+        for (int d = lane; d < D; d += 64) t = fmaf(sq[g * D + d], sk[d], t);
+        sn[g] = wave_sum(t);
+        mx[g] = fmaxf(wave_max(mx[g]), sn[g]);
+        if (lane == 0) red[g * RED_LD + wave] = mx[g];
+    }
+    __syncthreads();
+    float inv[GQ], pn[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+        float* rg = red + g * RED_LD;
+        mx[g] = fmaxf(fmaxf(rg[0], rg[1]), fmaxf(rg[2], rg[3]));
+        float sum = 0.f;
+        for (int j = tid; j < nc; j += 256) {
+            const float e = expf(sc[g * sc_ld + j] - mx[g]);
+            sc[g * sc_ld + j] = e;
+            sum += e;
+        }
+        pn[g] = expf(sn[g] - mx[g]);
+        sum = wave_sum(sum);
+        if (lane == 0) rg[4 + wave] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+        const float* rg = red + g * RED_LD;
+        const float sum = ((rg[4] + rg[5]) + (rg[6] + rg[7])) + pn[g];
+        inv[g] = 1.0f / sum;
+    }
+
+    float acc[GQ][EPL];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[g][e] = 0.f;
     for (int j0 = w0; j0 < w1; j0 += UN * KPI) {
         u32x4_t kvv[UN];
-        float pj[UN];
+        float pj[GQ][UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u * KPI + slot;
             kvv[u] = (u32x4_t){0u, 0u, 0u, 0u};
-            pj[u] = 0.f;
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) pj[g][u] = 0.f;
             if (j < w1) {
                 kvv[u] = *reinterpret_cast<const u32x4_t*>(Vb + (long)j * p.kv_rs);
-                pj[u] = sc[j - jlo];
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) pj[g][u] = sc[g * sc_ld + j - jlo];
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const u32x4_t v = kvv[u];
-            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] = fmaf(pj[u], __uint_as_float(v[e] << 16), acc[2 * e]);
-                    acc[2 * e + 1] = fmaf(pj[u], __uint_as_float(v[e] & 0xffff0000u), acc[2 * e + 1]);
+            for (int g = 0; g < GQ; ++g) {
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[g][2 * e] = fmaf(pj[g][u], __uint_as_float(v[e] << 16), acc[g][2 * e]);
+                        acc[g][2 * e + 1] = fmaf(pj[g][u], __uint_as_float(v[e] & 0xffff0000u), acc[g][2 * e + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[g][e] = fmaf(pj[g][u], __uint_as_float(v[e]), acc[g][e]);
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pj[u], __uint_as_float(v[e]), acc[e]);
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e)
+    for (int g = 0; g < GQ; ++g) {
 #pragma unroll
-        for (int o = CH; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
-    float* part = red + 8;     // [4][D]
-    if (slot == 0) {
+        for (int e = 0; e < EPL; ++e)
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) part[wave * D + c * EPL + e] = acc[e];
+            for (int o = CH; o < 64; o <<= 1) acc[g][e] += __shfl_xor(acc[g][e], o, 64);
+        float* part = red + g * RED_LD + 8;     // [4][D]
+        if (slot == 0) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) part[wave * D + c * EPL + e] = acc[g][e];
+        }
     }
     __syncthreads();
-    T* o = (T*)p.O + (long)b * p.o_bs + (long)h * D;
     const int ksteps = (p.H * D) >> 5;
-    for (int d = tid; d < D; d += 256) {
-        const float v = (((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) + pn * sv[d]) * inv;
+    for (int i = tid; i < GQ * D; i += 256) {
+        const int g = i / D, d = i - g * D, h = h0 + g;
+        const float* part = red + g * RED_LD + 8;
+        const float v = (((part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d])) + pn[g] * sv[d]) * inv[g];
         if (p.o_frag) {   // fragment-major rows for the out-projection (gemm_dec.hip operand layout): row b, column h*D + d
             const int k = h * D + d;
             Elem<T>::st((T*)p.O + ((((long)(b >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (b & 15)) * 8 + (k & 7), v);
         } else {
-            Elem<T>::st(o + d, v);
+            Elem<T>::st((T*)p.O + (long)b * p.o_bs + (long)h * D + d, v);
         }
     }
 }
 
+static int g_attn_step_share = -1;               // s2s_op_attn_step_tune: -1 = environment / default, 0 / 1 = forced
+
 template <typename T>
 static int launch_attn_step(hipStream_t st, const AttnStepParams& p) {
-    dim3 grid(p.H, p.B);
+    static const bool share_env = [] {           // S2S_ATTN_STEP_GQA=0: one workgroup per query head also for grouped heads (rounds 2 - 5; A/B)
+        const char* e = getenv("S2S_ATTN_STEP_GQA");
+        return !e || atoi(e) != 0;
+    }();
+    const bool share = g_attn_step_share < 0 ? share_env : g_attn_step_share != 0;
+    const int group = p.H / p.Hkv;
+    const int gq = share && (group == 2 || group == 4) ? group : 1;
+    dim3 grid(gq > 1 ? p.Hkv : p.H, p.B);
     ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.kv_cap * p.D,
                    (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_cap * p.D * 2 + (double)p.H * p.D * 2));
-    const size_t lds = sizeof(float) * (size_t)(p.kv_cap + 8 + 8 + 4 * p.D + 3 * p.D);
+    const size_t lds = sizeof(float) * (size_t)(gq * (p.kv_cap + 8 + 8 + 4 * p.D + p.D) + 2 * p.D);
     S2S_REQUIRE(lds <= 64 * 1024, "attention step: cache capacity %d too long", p.kv_cap);
+#define S2S_STEP(DV)                                                                              \
+    do {                                                                                          \
+        if (gq == 2) launch_k(attn_step_kernel<T, DV, 2>, grid, dim3(256), lds, st, p);           \
+        else if (gq == 4) launch_k(attn_step_kernel<T, DV, 4>, grid, dim3(256), lds, st, p);      \
+        else launch_k(attn_step_kernel<T, DV, 1>, grid, dim3(256), lds, st, p);                   \
+    } while (0)
     switch (p.D) {
-        case 32: launch_k(attn_step_kernel<T, 32>, grid, dim3(256), lds, st, p); break;
-        case 64: launch_k(attn_step_kernel<T, 64>, grid, dim3(256), lds, st, p); break;
-        case 128: launch_k(attn_step_kernel<T, 128>, grid, dim3(256), lds, st, p); break;
+        case 32: S2S_STEP(32); break;
+        case 64: S2S_STEP(64); break;
+        case 128: S2S_STEP(128); break;
         default: return fail(S2S_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32/64/128)", p.D);
     }
+#undef S2S_STEP
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }
@@ -908,6 +969,23 @@ int transpose_v(hipStream_t st, const void* V, long v_bs, long v_rs, void* Vt, i
 }  // namespace s2s
 
 using namespace s2s;
+
+extern "C" int32_t s2s_op_attn_step_tune(int32_t share) {
+    g_attn_step_share = share < 0 ? -1 : (share != 0);
+    return S2S_OK;
+}
+
+extern "C" int32_t s2s_op_attn_step(void* stream, const void* qkv, int64_t qkv_rs, void* K, void* V, int64_t kv_bs, int64_t kv_rs, void* O, int64_t o_bs,
+                                    const float* qw, const float* kw, float eps, const float* cos_t, const float* sin_t, const int32_t* pos_dev,
+                                    int32_t B, int32_t H, int32_t Hkv, int32_t D, int32_t kv_cap, int32_t window, float scale, int32_t o_frag, int32_t dtype) {
+    S2S_REQUIRE(qkv && K && V && O && pos_dev, "attn_step: null argument");
+    S2S_REQUIRE(dtype == S2S_BF16 || dtype == S2S_F32, "attn_step: bad dtype");
+    AttnStepParams a{};
+    a.qkv = qkv; a.qkv_rs = qkv_rs; a.K = K; a.V = V; a.kv_bs = kv_bs; a.kv_rs = kv_rs; a.O = O; a.o_bs = o_bs;
+    a.qw = qw; a.kw = kw; a.eps = eps; a.cosT = cos_t; a.sinT = sin_t; a.pos = pos_dev;
+    a.B = B; a.H = H; a.Hkv = Hkv; a.D = D; a.kv_cap = kv_cap; a.window = window; a.scale = scale; a.o_frag = o_frag != 0;
+    return attn_step((hipStream_t)stream, a, dtype);
+}
 
 // Public op: self/cross attention over token-major buffers.
 //   q: [B][Tq][q_rs] with head h at columns h*D.. ; k, v: [B][Tk][kv_rs] likewise (Hkv heads);

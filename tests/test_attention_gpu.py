@@ -140,3 +140,74 @@ def test_causal_dilated_conv_as_gemm(dt, B, T, Cin, Cout, k, dil):
     err = (y.double().cpu() - ref).abs().max().item()
     print(f"causal conv {dt} B{B} T{T} {Cin}->{Cout} k{k} d{dil}: {err:.3e}")
     assert err < (3e-5 if dt == torch.float32 else 4e-2)
+
+
+# ---- decode-step attention: grouped heads share one workgroup per KV head (round 6) ---------------------------------------------------
+def _attn_step(share, qkv, K, V, pos, H, Hkv, D, kv_cap, qw, kw, cos, sin, window=0, o_frag=False):
+    lib = native.load()
+    B = qkv.shape[0]
+    Kc, Vc = K.clone(), V.clone()
+    O = torch.zeros((B, H * D), dtype=qkv.dtype, device=DEV)
+    native.check(lib.s2s_op_attn_step_tune(share), "tune")
+    try:
+        native.check(lib.s2s_op_attn_step(native.stream_handle(), native.ptr(qkv), qkv.stride(0), native.ptr(Kc), native.ptr(Vc), Kc.stride(0), Kc.stride(1),
+                                          native.ptr(O), O.stride(0), native.ptr(qw), native.ptr(kw), 1e-6, native.ptr(cos), native.ptr(sin), native.ptr(pos), B, H, Hkv, D,
+                                          kv_cap, window, D ** -0.5, int(o_frag), native.dtype_code(qkv.dtype)), "s2s_op_attn_step")
+        torch.cuda.synchronize()
+    finally:
+        lib.s2s_op_attn_step_tune(-1)
+    return O, Kc, Vc
+
+
+@pytest.mark.parametrize("H,Hkv,D,dt", [(16, 8, 128, torch.bfloat16), (16, 8, 128, torch.float32), (8, 2, 64, torch.bfloat16), (4, 4, 64, torch.float32)])
+def test_attn_step_grouped_heads_match_the_per_head_kernel_bit_for_bit_and_the_reference(H, Hkv, D, dt):
+    """One workgroup per (KV head, session) serving the group's 2 / 4 query heads (every K / V row loaded once) against one workgroup per
+    query head: same outputs BIT FOR BIT, same cache rows appended; and both against a float64 reference of the fused step (head RMSNorm,
+    rotary embedding, append, attention over the cache + the new row).  Ragged positions incl. an empty cache and a full one, sliding window."""
+    B, kv_cap = 37, 96
+    g = torch.Generator().manual_seed(H * 100 + D)
+    qkv = (torch.randn(B, (H + 2 * Hkv) * D, generator=g)).to(dt).to(DEV)
+    K = (torch.randn(B, kv_cap, Hkv * D, generator=g)).to(dt).to(DEV)
+    V = (torch.randn(B, kv_cap, Hkv * D, generator=g)).to(dt).to(DEV)
+    pos = torch.randint(0, kv_cap - 1, (B,), generator=g).to(torch.int32)
+    pos[0], pos[1] = 0, kv_cap - 1
+    qw, kw = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    ang = torch.arange(kv_cap)[:, None] * (10000.0 ** (-torch.arange(D // 2) / (D // 2)))[None, :]
+    cos, sin = ang.cos().float().contiguous().to(DEV), ang.sin().float().contiguous().to(DEV)
+    pos_d = pos.to(DEV)
+    for window in (0, 24):
+        o1, k1, v1 = _attn_step(1, qkv, K, V, pos_d, H, Hkv, D, kv_cap, qw, kw, cos, sin, window)
+        o0, k0, v0 = _attn_step(0, qkv, K, V, pos_d, H, Hkv, D, kv_cap, qw, kw, cos, sin, window)
+        assert torch.equal(o1, o0) and torch.equal(k1, k0) and torch.equal(v1, v0)
+        # float64 reference
+        x = qkv.double().cpu().view(B, H + 2 * Hkv, D)
+        q, k, v = x[:, :H], x[:, H:H + Hkv], x[:, H + Hkv:]
+
+        def norm_rope(t, w, p):
+            t = t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-6) * w.double().cpu()
+            a, c = t[..., : D // 2], t[..., D // 2:]
+            cs, sn = cos.double().cpu()[p][:, None], sin.double().cpu()[p][:, None]
+            return torch.cat([a * cs - c * sn, c * cs + a * sn], -1)
+
+        pl = pos.long()
+        qr, kr = norm_rope(q, qw, pl), norm_rope(k, kw, pl)
+        if dt == torch.bfloat16:       # the kernel rounds q and the new k through the storage type
+            qr, kr = qr.to(dt).double(), kr.to(dt).double()
+        Kd, Vd = K.double().cpu().view(B, kv_cap, Hkv, D).clone(), V.double().cpu().view(B, kv_cap, Hkv, D).clone()
+        want = torch.zeros(B, H, D, dtype=torch.float64)
+        for b in range(B):
+            Kd[b, pl[b]], Vd[b, pl[b]] = kr[b], v[b]
+            lo = max(0, int(pl[b]) - window + 1) if window > 0 else 0
+            for h in range(H):
+                hk = h // (H // Hkv)
+                s = (Kd[b, lo: pl[b] + 1, hk] @ qr[b, h]) * D ** -0.5
+                want[b, h] = torch.softmax(s, 0) @ Vd[b, lo: pl[b] + 1, hk]
+        err = (o1.double().cpu().view(B, H, D) - want).abs().max().item()
+        print(f"attn_step H={H} Hkv={Hkv} D={D} {dt} window={window}: grouped == per-head bit for bit; max err vs float64 {err:.2e}")
+        assert err < (2e-5 if dt == torch.float32 else 3e-2)
+        new_k = torch.stack([k1.view(B, kv_cap, Hkv, D)[b, pl[b]] for b in range(B)]).double().cpu()
+        assert (new_k - kr).abs().max().item() < (2e-5 if dt == torch.float32 else 3e-2)
+    # fragment-major output (the operand layout of the out-projection): the same values, permuted
+    of, _, _ = _attn_step(1, qkv, K, V, pos_d, H, Hkv, D, kv_cap, qw, kw, cos, sin, 0, o_frag=True)
+    of0, _, _ = _attn_step(0, qkv, K, V, pos_d, H, Hkv, D, kv_cap, qw, kw, cos, sin, 0, o_frag=True)
+    assert torch.equal(of[: (B // 16) * 16], of0[: (B // 16) * 16]) or torch.equal(of, of0)
