@@ -646,8 +646,17 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 // buffer: tile t + 1 is requested right after the barrier that opens tile t, has the whole tile's MFMA + softmax time to land, and the loop needs
 // ONE barrier per tile instead of two (register staging: load -> compute -> barrier -> ds_write -> barrier).  K rows past the valid length are
 // clamped to the last valid row (their scores are masked below), V^T is zero-padded by the transpose; same arithmetic in both variants.
-template <int D, bool DMA>
+//
+// VTR (round 6, DMA only): V is read where the qkv projection left it - rows [key][d] - and the tile sits in LDS row-major; the A operand of the
+// PV product (V^T[d = 16 dt + l15][8 keys]) comes out of two ds_read_b64_tr_b16 per (dt, 32-key half): the 16 lanes of a group hand in the
+// four 8-byte pieces of four key rows (lane i: row i >> 2, columns 4 (i & 3) .. + 3 of the 16-wide d block) and each receives ITS column of that
+// 4 x 16 block.  Swizzle (conflict-free for the two 32-lane halves the instruction is served in: 8 key rows x 32 bytes = all 64 banks): the
+// 32-byte group index of a row is XORed with (row >> 1) & 3 (D = 64: rows of equal parity share banks) / row & 7 (D = 128); with LDS-DMA the
+// XOR sits in the per-lane SOURCE chunk, inside the row's own 128-B / 256-B line.  Rows past the valid length re-read the last valid row (finite
+// values; their probabilities are exactly 0).  Removes transpose_v_kernel (6.4 ms per 64-session turn-batch) and its [B][H][D][Tp] scratch.
+template <int D, bool DMA, bool VTR>
 __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfmaParams p) {
+    static_assert(!VTR || DMA, "the direct-V variant is built on the LDS-DMA loop");
     constexpr int KT = 64;                       // keys per tile
     constexpr int KROWB = D * 2;                 // bytes per K row in LDS
     constexpr int KCH = KROWB / 16;              // 16-byte chunks per K row (8 or 16)
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfm
     float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
 
     const __hip_bfloat16* Kb = p.K + (long)b * p.k_bs + (long)h * D;
-    const __hip_bfloat16* Vb = p.Vt + ((long)(b * p.H + h) * D) * p.Tp;
+    const __hip_bfloat16* Vb = VTR ? p.V + (long)b * p.v_bs + (long)h * D : p.Vt + ((long)(b * p.H + h) * D) * p.Tp;
     const float* bias = p.bias ? p.bias + (long)b * p.bias_bs + (long)h * p.bias_hs : nullptr;
 
     u32x4_t gk[KPT], gv[VPT];
@@ -752,16 +761,38 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfm
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + blk * 1024), 16, 0, 0);
         }
+        if constexpr (VTR) {
 #pragma unroll
-        for (int i = 0; i < VI_PW; ++i) {
-            const int blk = wave * VI_PW + i;                                    // 8 rows (d) of the V^T tile
-            const int row = blk * 8 + (lane >> 3), pos = lane & 7;
-            const int ch = pos ^ (row & 7);
-            const __hip_bfloat16* src = Vb + (long)row * p.Tp + j0 + ch * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + KT * KROWB + blk * 1024), 16, 0, 0);
+            for (int i = 0; i < KI_PW; ++i) {
+                const int blk = wave * KI_PW + i;                                // 1 KiB block of the V tile: 1024 / KROWB key rows
+                const int row = blk * (1024 / KROWB) + lane / KCH, pos = lane % KCH;
+                const int swz = D == 64 ? ((row >> 1) & 3) : (row & 7);
+                const int ch = (((pos >> 1) ^ swz) << 1) | (pos & 1);            // the 32-byte group is swizzled, the 16-byte half inside it stays
+                const __hip_bfloat16* src = Vb + (long)min(j0 + row, kv - 1) * p.v_rs + ch * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + KT * KROWB + blk * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VI_PW; ++i) {
+                const int blk = wave * VI_PW + i;                                // 8 rows (d) of the V^T tile
+                const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+                const int ch = pos ^ (row & 7);
+                const __hip_bfloat16* src = Vb + (long)row * p.Tp + j0 + ch * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + KT * KROWB + blk * 1024), 16, 0, 0);
+            }
         }
     };
+    // direct-V reads: this lane's piece of the 4 x 16 blocks - key row lg * 4 + (l15 >> 2) of a 16-key group, 8 bytes at column 4 (l15 & 3) of
+    // the d block; the swizzle depends on the row modulo 8 only, so it is the same for every 16-key group
+    [[maybe_unused]] int vtr_off[DT];
+    if constexpr (VTR) {
+        const int r = lg * 4 + (l15 >> 2);
+        const int swz = D == 64 ? ((r >> 1) & 3) : (r & 7);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vtr_off[dt] = r * KROWB + ((dt ^ swz) << 5) + (l15 & 3) * 8;
+    }
     const int ntiles = (kv + KT - 1) / KT;
     if constexpr (DMA) {
         if (ntiles > 0) dma_tile(0, 0);
@@ -893,6 +924,22 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfm
             }
         }
         // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
+        if constexpr (VTR) {
+            typedef short v4s_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    // MFMA k index lg*8+e  <->  key k2*32 + (e<4 ? lg*4+e : 16+lg*4+e-4): one transposing read per 16-key group
+                    const unsigned char* a0 = sV + vtr_off[dt] + k2 * 32 * KROWB;
+                    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a0));
+                    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a0 + 16 * KROWB));
+                    const bf16x8_t va = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[0][k2], oacc[0][dt], 0, 0, 0);
+                    oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[1][k2], oacc[1][dt], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int row = dt * 16 + l15;
@@ -935,8 +982,20 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_mfma_kernel(AttnMfm
     }
 }
 
+bool attn_mfma_direct_v() {                      // S2S_ATTN_VTR=0: transpose_v + the V^T kernel of rounds 2 - 5 (A/B); needs the DMA loop
+    static const bool on = [] {
+        const char* e = getenv("S2S_ATTN_VTR");
+        const char* d = getenv("S2S_ATTN_DMA");
+        return (!e || atoi(e) != 0) && (!d || atoi(d) != 0);
+    }();
+    return on;
+}
+
 int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
-    S2S_REQUIRE(p.Tp % 64 == 0 && p.Tp >= p.Tk, "attention: Tp=%d must be a multiple of 64 and >= Tk=%d", p.Tp, p.Tk);
+    const bool direct = p.Vt == nullptr;
+    S2S_REQUIRE(direct ? (p.V != nullptr && p.v_rs % 8 == 0 && p.v_bs % 8 == 0 && ((uintptr_t)p.V & 15) == 0)
+                       : (p.Tp % 64 == 0 && p.Tp >= p.Tk),
+                "attention: needs V rows (16-byte aligned, strides multiples of 8) or V^T with Tp=%d a multiple of 64 and >= Tk=%d", p.Tp, p.Tk);
     dim3 grid(cdiv(p.Tq, 128), p.H, p.B);
     ProfScope prof(st, S2S_PROF_ATTN_MFMA, 4.0 * p.B * p.H * (double)p.Tq * p.Tk * D,
                    2.0 * p.B * p.H * ((double)p.Tq * D * 2 + (double)p.Tk * D * 2));
@@ -944,10 +1003,13 @@ int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D) {
         const char* e = getenv("S2S_ATTN_DMA");
         return !e || atoi(e) != 0;
     }();
-    if (D == 64 && dma) launch_k(attn_mfma_kernel<64, true>, grid, dim3(256), 0, st, p);
-    else if (D == 128 && dma) launch_k(attn_mfma_kernel<128, true>, grid, dim3(256), 0, st, p);
-    else if (D == 64) launch_k(attn_mfma_kernel<64, false>, grid, dim3(256), 0, st, p);
-    else if (D == 128) launch_k(attn_mfma_kernel<128, false>, grid, dim3(256), 0, st, p);
+    if (direct && D == 64) launch_k(attn_mfma_kernel<64, true, true>, grid, dim3(256), 0, st, p);
+    else if (direct && D == 128) launch_k(attn_mfma_kernel<128, true, true>, grid, dim3(256), 0, st, p);
+    else if (direct) return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);
+    else if (D == 64 && dma) launch_k(attn_mfma_kernel<64, true, false>, grid, dim3(256), 0, st, p);
+    else if (D == 128 && dma) launch_k(attn_mfma_kernel<128, true, false>, grid, dim3(256), 0, st, p);
+    else if (D == 64) launch_k(attn_mfma_kernel<64, false, false>, grid, dim3(256), 0, st, p);
+    else if (D == 128) launch_k(attn_mfma_kernel<128, false, false>, grid, dim3(256), 0, st, p);
     else return fail(S2S_ERR_UNSUPPORTED, "attention: MFMA path supports head_dim 64/128, got %d", D);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
@@ -999,12 +1061,16 @@ extern "C" int32_t s2s_op_attention(void* stream, const void* q, int64_t q_rs, c
     if (use_mfma) {
         S2S_REQUIRE(dtype == S2S_BF16 && H == Hkv && !causal && window <= 0 && vt_scratch, "attention: MFMA path preconditions");
         const int Tp = cdiv(Tk, 64) * 64;
-        int rc = transpose_v(st, v, (long)Tk * kv_rs, kv_rs, vt_scratch, B, H, D, Tk, Tp, dtype);
-        if (rc) return rc;
+        const bool direct = attn_mfma_direct_v() && kv_rs % 8 == 0 && ((uintptr_t)v & 15) == 0;
+        if (!direct) {
+            int rc = transpose_v(st, v, (long)Tk * kv_rs, kv_rs, vt_scratch, B, H, D, Tk, Tp, dtype);
+            if (rc) return rc;
+        }
         AttnMfmaParams p{};
         p.Q = (const __hip_bfloat16*)q; p.q_bs = (long)Tq * q_rs; p.q_rs = q_rs;
         p.K = (const __hip_bfloat16*)k; p.k_bs = (long)Tk * kv_rs; p.k_rs = kv_rs;
-        p.Vt = (const __hip_bfloat16*)vt_scratch;
+        p.Vt = direct ? nullptr : (const __hip_bfloat16*)vt_scratch;
+        p.V = (const __hip_bfloat16*)v; p.v_bs = (long)Tk * kv_rs; p.v_rs = kv_rs;
         p.O = (__hip_bfloat16*)o; p.o_bs = (long)Tq * H * D; p.o_rs = (long)H * D;
         p.bias = bias; p.bias_bs = (long)H * Tq * (2 * Tk - 1); p.bias_hs = (long)Tq * (2 * Tk - 1);
         p.bias_rs = 2 * Tk - 1; p.bias_shift = Tk - 1;

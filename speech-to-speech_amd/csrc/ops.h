@@ -107,7 +107,9 @@ struct AttnRowsParams {
 struct AttnMfmaParams {
     const __hip_bfloat16* Q; long q_bs, q_rs;
     const __hip_bfloat16* K; long k_bs, k_rs;
-    const __hip_bfloat16* Vt;          // [B][H][D][Tp]
+    const __hip_bfloat16* Vt;          // [B][H][D][Tp] (pre-transposed by transpose_v: rounds 2 - 5, S2S_ATTN_VTR=0), or null:
+    const __hip_bfloat16* V; long v_bs, v_rs;   // V rows as they come out of the qkv projection, (b, key, h, d) at V + b*v_bs + key*v_rs + h*D + d -
+                                       // the kernel transposes in its LDS read (ds_read_b64_tr_b16), no separate pass (round 6)
     __hip_bfloat16* O; long o_bs, o_rs;
     const float* bias; long bias_bs, bias_hs, bias_rs; int bias_shift;
     const int* kv_len; int Tk, Tp, Tq, H, B;
@@ -129,6 +131,7 @@ struct AttnStepParams {
 int attn_step(hipStream_t st, const AttnStepParams& p, int dtype);
 int attn_rows(hipStream_t st, const AttnRowsParams& p, int dtype);
 int attn_mfma(hipStream_t st, const AttnMfmaParams& p, int D);
+bool attn_mfma_direct_v();             // true: callers hand V (not V^T) to attn_mfma and skip transpose_v
 int transpose_v(hipStream_t st, const void* V, long v_bs, long v_rs, void* Vt, int B, int H, int D, int Tk,
                 int Tp, int dtype);
 // misc.hip

@@ -232,11 +232,13 @@ static int encode(Parakeet* m, hipStream_t st, const void* feats, const int* n_f
             if ((rc = gemm_ex(st, g))) return rc;
         }
         if (dt == S2S_BF16 && (D == 64 || D == 128)) {
-            if ((rc = transpose_v(st, at(m->qkv, (size_t)2 * d * e), (long)T3 * 3 * d, 3 * d, m->vt, B, H, D, T3, Tp, dt))) return rc;
+            const bool direct_v = attn_mfma_direct_v() && d % 8 == 0;      // V rows straight from the qkv projection (round 6): no transpose pass
+            if (!direct_v && (rc = transpose_v(st, at(m->qkv, (size_t)2 * d * e), (long)T3 * 3 * d, 3 * d, m->vt, B, H, D, T3, Tp, dt))) return rc;
             AttnMfmaParams p{};
             p.Q = (const __hip_bfloat16*)m->qkv; p.q_bs = (long)T3 * 3 * d; p.q_rs = 3 * d;
             p.K = (const __hip_bfloat16*)at(m->qkv, (size_t)d * e); p.k_bs = p.q_bs; p.k_rs = 3 * d;
-            p.Vt = (const __hip_bfloat16*)m->vt;
+            p.Vt = direct_v ? nullptr : (const __hip_bfloat16*)m->vt;
+            p.V = (const __hip_bfloat16*)at(m->qkv, (size_t)2 * d * e); p.v_bs = p.q_bs; p.v_rs = 3 * d;
             p.O = (__hip_bfloat16*)m->att; p.o_bs = (long)T3 * d; p.o_rs = d;
             p.bias = m->bd; p.bias_bs = (long)H * T3 * bd_rs; p.bias_hs = (long)T3 * bd_rs; p.bias_rs = bd_rs; p.bias_shift = T3 - 1;
             p.kv_len = m->enc_len; p.Tk = T3; p.Tp = Tp; p.Tq = T3; p.H = H; p.B = B;

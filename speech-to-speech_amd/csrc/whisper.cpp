@@ -275,11 +275,13 @@ static int encode(Whisper* m, hipStream_t st, const void* feats, int B, int slot
         if ((rc = layernorm(st, m->x, PF(m, lname("enc", l, "ln1.g")), PF(m, lname("enc", l, "ln1.b")), m->h, M, d, 1e-5f, dt))) return rc;
         if ((rc = gemm(st, m->h, d, P(m, lname("enc", l, "qkv.w")), PF(m, lname("enc", l, "qkv.b")), nullptr, m->qkv, 3 * d, M, 3 * d, d, dt, dt, S2S_ACT_NONE, false))) return rc;
         if (dt == S2S_BF16 && (D == 64 || D == 128)) {
-            if ((rc = transpose_v(st, at(m->qkv, (size_t)2 * d * e), (long)ENC_T * 3 * d, 3 * d, m->vt, B, H, D, ENC_T, Tp, dt))) return rc;
+            const bool direct_v = attn_mfma_direct_v() && d % 8 == 0;      // V rows straight from the qkv projection (round 6): no transpose pass
+            if (!direct_v && (rc = transpose_v(st, at(m->qkv, (size_t)2 * d * e), (long)ENC_T * 3 * d, 3 * d, m->vt, B, H, D, ENC_T, Tp, dt))) return rc;
             AttnMfmaParams p{};
             p.Q = (const __hip_bfloat16*)m->qkv; p.q_bs = (long)ENC_T * 3 * d; p.q_rs = 3 * d;
             p.K = (const __hip_bfloat16*)at(m->qkv, (size_t)d * e); p.k_bs = p.q_bs; p.k_rs = 3 * d;
-            p.Vt = (const __hip_bfloat16*)m->vt;
+            p.Vt = direct_v ? nullptr : (const __hip_bfloat16*)m->vt;
+            p.V = (const __hip_bfloat16*)at(m->qkv, (size_t)2 * d * e); p.v_bs = p.q_bs; p.v_rs = 3 * d;
             p.O = (__hip_bfloat16*)m->att; p.o_bs = (long)ENC_T * d; p.o_rs = d;
             p.Tk = ENC_T; p.Tp = Tp; p.Tq = ENC_T; p.H = H; p.B = B;
             p.scale_log2e = scale * 1.4426950408889634f;
