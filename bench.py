@@ -866,17 +866,36 @@ def main():
                                 engine_tensors={k: (v.float() if v.dtype == torch.bfloat16 else v) for k, v in tts._weights.items() if not k.endswith(".f")})
                 ref.prefill(t_prompts)
                 want = ref.generate(n_tf, min_total_frames=n_tf)[0].cpu().long()
+                # the SAME code sequence teacher-forced through both engines: logits position by position, no cascade after a near-tie
+                ref.prefill(t_prompts)
+                forced = want.to(torch.int32).to(dev)
+                lg_ref = ref.generate_forced(forced, min_total_frames=n_tf)[1][..., : tdims.codebook].cpu()
                 ref.close()
                 del ref
                 tts.prefill(t_prompts)
                 got = tts.generate(n_tf, min_total_frames=n_tf)[0].cpu().long()[:n_tp]
+                tts.prefill(t_prompts)
+                lg_b = tts.generate_forced(forced, min_total_frames=n_tf)[1][:n_tp, ..., : tdims.codebook].cpu()
+                sig = lg_ref.std(-1)
+                err = ((lg_b - lg_ref).abs().amax(-1) / sig)
+                top2 = lg_ref.topk(2, -1).values
+                margin = (top2[..., 0] - top2[..., 1]) / sig
+                agree = lg_b.argmax(-1) == lg_ref.argmax(-1)
+                clear = margin > 0.16                                   # twice the 0.08-sigma logit bar of tests/test_full_depth_gpu.py
                 flat_g, flat_w = got.reshape(n_tp, -1), want.reshape(n_tp, -1)
                 first = [int((flat_g[b] != flat_w[b]).nonzero()[0]) if bool((flat_g[b] != flat_w[b]).any()) else flat_w.shape[1] for b in range(n_tp)]
-                tts_parity = {"what": f"codec codes of the bf16 engine vs a float32 engine with the same weight values: {n_tp} sessions x {n_tf} frames x {tdims.n_groups} groups, "
-                                      "free-running greedy decode (after a first differing code the two streams are different utterances)",
-                              "sessions": n_tp, "codes": int(flat_w.numel()), "sessions_identical": sum(int(f == flat_w.shape[1]) for f in first),
-                              "codes_before_first_difference": int(sum(first)), "agreement": round(sum(first) / max(flat_w.numel(), 1), 4),
-                              "positionwise_agreement": round(float((flat_g == flat_w).float().mean()), 4)}
+                tts_parity = {"what": f"codec codes of the bf16 engine vs a float32 engine with the same weight values: {n_tp} sessions x {n_tf} frames x {tdims.n_groups} groups.  "
+                                      "`free_running`: greedy decode of both (after a first differing code the two streams are different utterances - with random-init "
+                                      "weights the code logits are nearly flat, so near-ties are frequent).  `teacher_forced`: the float32 engine's codes forced through "
+                                      "both, logits compared position by position (error and top-2 margin in units of the logit row's standard deviation; a `clear` "
+                                      "pick has a float32 margin > 0.16 sigma = twice the bf16 logit bar of tests/test_full_depth_gpu.py)",
+                              "sessions": n_tp, "codes": int(flat_w.numel()),
+                              "free_running": {"sessions_identical": sum(int(f == flat_w.shape[1]) for f in first), "codes_before_first_difference": int(sum(first)),
+                                               "agreement": round(sum(first) / max(flat_w.numel(), 1), 4), "positionwise_agreement": round(float((flat_g == flat_w).float().mean()), 4)},
+                              "teacher_forced": {"positions": int(agree.numel()), "argmax_agreement": round(float(agree.float().mean()), 4),
+                                                 "max_logit_error_sigma": round(float(err.max()), 4), "mean_logit_error_sigma": round(float(err.mean()), 4),
+                                                 "clear_margin_picks": int(clear.sum()), "flips_on_clear_margin_picks": int((clear & ~agree).sum()),
+                                                 "largest_margin_of_a_flipped_pick_sigma": round(float(margin[~agree].max()), 4) if bool((~agree).any()) else 0.0}}
                 torch.cuda.empty_cache()
             except Exception as ex:  # pragma: no cover
                 tts_parity = {"error": repr(ex)}

@@ -254,6 +254,119 @@ __global__ void tdt_commit_kernel(float* const* __restrict__ dst, const float* c
         for (int i = threadIdx.x; i < Hd; i += blockDim.x) dst[a][(long)b * Hd + i] = src[a][(long)b * Hd + i];
 }
 
+// ---- fused step kernels (round 6): 8 launches per TDT step instead of 14 - the same arithmetic, element for element -------------------
+// The step is a chain of latency-bound launches (C2: ~560 steps x 14 launches = 39 of the 41 ms of a 30 s utterance's STT), so the launches
+// that only move rows between two GEMMs ride along with their neighbours:
+//   select  + lstm_in of layer 0          (the pick IS the embedding index; h0 is the committed state)
+//   cell l  + lstm_in of layer l + 1      (its x is the h this cell just produced) / + the model-dtype cast in front of dec.dproj (last layer)
+//   commit  + joint_in of the NEXT step   (frame[b] was advanced by this step's select; dec is the value this thread just committed or kept)
+//             + the reset of the active-row counter (was a memset node per step)
+template <typename T>
+__global__ __launch_bounds__(256) void tdt_select_in_kernel(const float* __restrict__ logits, int ld, int V, int ND, int blank,
+                                                            const int* __restrict__ enc_len, TdtState s, int* __restrict__ out_tok,
+                                                            int* __restrict__ out_dur, int* __restrict__ out_frame, int max_steps,
+                                                            const int* __restrict__ dyn, const T* __restrict__ emb, const float* __restrict__ h0,
+                                                            T* __restrict__ X, int Hd) {
+    if (dyn) max_steps = dyn[1];
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_tok;
+    const int b = blockIdx.x;
+    const float* row = logits + (long)b * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float x = row[v];
+        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        int dur = 0;
+        float db = row[V];
+        for (int k = 1; k < ND; ++k)
+            if (row[V + k] > db) { db = row[V + k]; dur = k; }
+        const bool is_blank = bi == blank;
+        if (is_blank && dur == 0) dur = 1;
+        const int fin = s.finished[b];
+        if (!fin) {
+            const int n = s.n_steps[b];
+            if (n < max_steps) {
+                out_tok[(long)b * max_steps + n] = bi;
+                out_dur[(long)b * max_steps + n] = dur;
+                out_frame[(long)b * max_steps + n] = s.frame[b];
+                s.n_steps[b] = n + 1;
+            }
+        }
+        const int fr = s.frame[b] + dur;
+        s.frame[b] = fr;
+        const int nf = fin | (fr >= enc_len[b]);
+        s.finished[b] = nf;
+        s.tok[b] = bi;
+        s.adv[b] = is_blank ? 0 : 1;
+        if (!nf) atomicAdd(s.n_active, 1);
+        s_tok = bi;
+    }
+    __syncthreads();
+    const int tok = s_tok;
+    for (int i = threadIdx.x; i < Hd; i += 256) {      // lstm_in_kernel of layer 0
+        X[(long)b * 2 * Hd + i] = emb[(long)tok * Hd + i];
+        Elem<T>::st(X + (long)b * 2 * Hd + Hd + i, h0[(long)b * Hd + i]);
+    }
+}
+
+// lstm_cell_kernel + what the next GEMM reads: Xn[b] = [h_new[b] | h_next[b]] (h_next: the next layer's committed state) or, for the last
+// layer (h_next == nullptr), Xn[b] = h_new[b] in the model dtype (the input of dec.dproj)
+template <typename T>
+__global__ void lstm_cell_out_kernel(const float* __restrict__ gates, const float* __restrict__ c, float* __restrict__ h_new,
+                                     float* __restrict__ c_new, int Hd, T* __restrict__ Xn, const float* __restrict__ h_next) {
+    const int b = blockIdx.x;
+    const float* g = gates + (long)b * 4 * Hd;
+    const long xs = h_next ? 2 * (long)Hd : (long)Hd;
+    for (int i = threadIdx.x; i < Hd; i += blockDim.x) {
+        const float ig = 1.0f / (1.0f + expf(-g[i]));
+        const float fg = 1.0f / (1.0f + expf(-g[Hd + i]));
+        const float gg = tanhf(g[2 * Hd + i]);
+        const float og = 1.0f / (1.0f + expf(-g[3 * Hd + i]));
+        const float cn = fg * c[(long)b * Hd + i] + ig * gg;
+        const float hn = og * tanhf(cn);
+        c_new[(long)b * Hd + i] = cn;
+        h_new[(long)b * Hd + i] = hn;
+        Elem<T>::st(Xn + (long)b * xs + i, hn);
+        if (h_next) Elem<T>::st(Xn + (long)b * xs + Hd + i, h_next[(long)b * Hd + i]);
+    }
+}
+
+// tdt_commit_kernel + tdt_joint_in_kernel of the next step + reset of the active-row counter; the LAST array of dst / src is dec / dec_new
+template <typename T>
+__global__ void tdt_commit_joint_kernel(float* const* __restrict__ dst, const float* const* __restrict__ src, int n_arrays,
+                                        const int* __restrict__ adv, int force, int Hd, const float* __restrict__ encp,
+                                        const int* __restrict__ frame, T* __restrict__ A, int Tn, const int* __restrict__ dyn, int* n_active) {
+    const int b = blockIdx.x;
+    if (dyn) Tn = dyn[0];
+    const bool take = force || adv[b];
+    const int f = min(frame[b], Tn - 1);
+    if (b == 0 && threadIdx.x == 0) *n_active = 0;
+    for (int i = threadIdx.x; i < Hd; i += blockDim.x) {
+        if (take)
+            for (int a = 0; a + 1 < n_arrays; ++a) dst[a][(long)b * Hd + i] = src[a][(long)b * Hd + i];
+        float d = dst[n_arrays - 1][(long)b * Hd + i];
+        if (take) {
+            d = src[n_arrays - 1][(long)b * Hd + i];
+            dst[n_arrays - 1][(long)b * Hd + i] = d;
+        }
+        Elem<T>::st(A + (long)b * Hd + i, fmaxf(encp[((long)b * Tn + f) * Hd + i] + d, 0.f));
+    }
+}
+
 // ---- host launchers -------------------------------------------------------------------------
 #define S2S_DT(TT_, ...)                                        \
     do {                                                        \
@@ -327,6 +440,26 @@ int lstm_in(hipStream_t st, const void* emb, const int* tok, const float* xin, c
 
 int lstm_cell(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd) {
     lstm_cell_kernel<<<B, 256, 0, st>>>(gates, c, h_new, c_new, Hd);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int tdt_select_in(hipStream_t st, const float* logits, int ld, int V, int ND, int blank, const int* enc_len, const TdtState& s, int* out_tok, int* out_dur,
+                  int* out_frame, int max_steps, int B, const int* dyn, const void* emb, const float* h0, void* X, int Hd, int dtype) {
+    S2S_DT(TT, (tdt_select_in_kernel<TT><<<B, 256, 0, st>>>(logits, ld, V, ND, blank, enc_len, s, out_tok, out_dur, out_frame, max_steps, dyn, (const TT*)emb, h0, (TT*)X, Hd)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int lstm_cell_out(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd, void* Xn, const float* h_next, int dtype) {
+    S2S_DT(TT, (lstm_cell_out_kernel<TT><<<B, 256, 0, st>>>(gates, c, h_new, c_new, Hd, (TT*)Xn, h_next)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+int tdt_commit_joint(hipStream_t st, float* const* dst, const float* const* src, int n_arrays, const int* adv, int force, int B, int Hd, const float* encp,
+                     const int* frame, void* A, int Tn, const int* dyn, int* n_active, int dtype) {
+    S2S_DT(TT, (tdt_commit_joint_kernel<TT><<<B, 256, 0, st>>>(dst, src, n_arrays, adv, force, Hd, encp, frame, (TT*)A, Tn, dyn, n_active)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

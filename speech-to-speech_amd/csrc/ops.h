@@ -184,5 +184,11 @@ int tdt_select(hipStream_t st, const float* logits, int ld, int V, int ND, int b
 int lstm_in(hipStream_t st, const void* emb, const int* tok, const float* xin, const float* h, void* X, int B, int Hd, int dtype);
 int lstm_cell(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd);
 int tdt_commit(hipStream_t st, float* const* dst, const float* const* src, int n_arrays, const int* adv, int force, int B, int Hd);
+// fused step kernels (conformer.hip, round 6): select + layer-0 LSTM input; LSTM cell + the next GEMM's input; commit + the next step's joint input
+int tdt_select_in(hipStream_t st, const float* logits, int ld, int V, int ND, int blank, const int* enc_len, const TdtState& s, int* out_tok, int* out_dur,
+                  int* out_frame, int max_steps, int B, const int* dyn, const void* emb, const float* h0, void* X, int Hd, int dtype);
+int lstm_cell_out(hipStream_t st, const float* gates, const float* c, float* h_new, float* c_new, int B, int Hd, void* Xn, const float* h_next, int dtype);
+int tdt_commit_joint(hipStream_t st, float* const* dst, const float* const* src, int n_arrays, const int* adv, int force, int B, int Hd, const float* encp,
+                     const int* frame, void* A, int Tn, const int* dyn, int* n_active, int dtype);
 
 }  // namespace s2s

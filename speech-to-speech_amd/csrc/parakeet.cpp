@@ -285,6 +285,25 @@ static int prednet(Parakeet* m, hipStream_t st, int B) {
     return gemm(st, m->jin, Hd, PP(m, "dec.dproj.w"), PPF(m, "dec.dproj.b"), nullptr, m->dec_new, Hd, B, Hd, Hd, dt, S2S_F32, S2S_ACT_NONE, false);
 }
 
+// the prediction network inside the fused step: lx already holds layer 0's input (tdt_select_in), every cell writes the next GEMM's input
+static int prednet_fused(Parakeet* m, hipStream_t st, int B) {
+    const auto& c = m->cfg;
+    const int Hd = c.dec_hidden, dt = c.dtype;
+    int rc;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const std::string n = "dec.lstm." + std::to_string(l);
+        const bool last = l + 1 == c.dec_layers;
+        if ((rc = gemm(st, m->lx, 2 * Hd, PP(m, n + ".w"), PPF(m, n + ".b"), nullptr, m->gates, 4 * Hd, B, 4 * Hd, 2 * Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if ((rc = lstm_cell_out(st, m->gates, m->cst[l], m->hnew[l], m->cnew[l], B, Hd, last ? m->jin : m->lx, last ? nullptr : m->hst[l + 1], dt))) return rc;
+    }
+    return gemm(st, m->jin, Hd, PP(m, "dec.dproj.w"), PPF(m, "dec.dproj.b"), nullptr, m->dec_new, Hd, B, Hd, Hd, dt, S2S_F32, S2S_ACT_NONE, false);
+}
+
+static bool tdt_fused() {       // S2S_TDT_FUSED=0: the 14-launch step of rounds 1 - 5 (A/B)
+    static const bool on = getenv("S2S_TDT_FUSED") == nullptr || atoi(getenv("S2S_TDT_FUSED")) != 0;
+    return on;
+}
+
 __global__ void fill_int_kernel(int* p, int v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -301,6 +320,12 @@ static int tdt_step_body(Parakeet* m, hipStream_t st, int B, int T, int max_step
     const auto& c = m->cfg;
     const int Hd = c.dec_hidden, dt = c.dtype, V = c.vocab, ND = c.n_durations, NA = 2 * c.dec_layers + 1;
     int rc;
+    if (tdt_fused()) {      // 8 launches: the joint input of this step was written by the previous step's commit (or the prologue's)
+        if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if ((rc = tdt_select_in(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B, dyn, PP(m, "dec.emb"), m->hst[0], m->lx, Hd, dt))) return rc;
+        if ((rc = prednet_fused(m, st, B))) return rc;
+        return tdt_commit_joint(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd, m->encp, m->frame, m->jin, T, dyn, m->n_active, dt);
+    }
     if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt, dyn))) return rc;
     if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
     if (dyn) {
@@ -358,7 +383,10 @@ static int tdt_greedy(Parakeet* m, hipStream_t st, int max_steps, int* out_tok, 
     fill_int_kernel<<<cdiv(B, 64), 64, 0, st>>>(m->tok, c.vocab - 1, B);
     S2S_LAUNCH_CHECK();
     if ((rc = prednet(m, st, B))) return rc;
-    if ((rc = tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, /*force=*/1, B, Hd))) return rc;
+    const bool fused = tdt_fused();
+    if (fused) {            // + the joint input of step 0 (frame 0) and a zeroed active-row counter
+        if ((rc = tdt_commit_joint(st, m->d_dst, m->d_src, NA, m->adv, /*force=*/1, B, Hd, m->encp, m->frame, m->jin, T, nullptr, m->n_active, dt))) return rc;
+    } else if ((rc = tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, /*force=*/1, B, Hd))) return rc;
     TdtState s{m->frame, m->finished, m->tok, m->adv, m->n_steps, m->n_active};
     hipGraphExec_t exec = nullptr;
     bool graph_ok = tdt_graph_enabled() && graphs_enabled() && !prof_active();
@@ -382,17 +410,27 @@ static int tdt_greedy(Parakeet* m, hipStream_t st, int max_steps, int* out_tok, 
             }
             continue;
         }
-        if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt))) return rc;
-        if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
-        S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
-        if ((rc = tdt_select(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B))) return rc;
+        if (fused) {
+            if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+            if ((rc = tdt_select_in(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B, nullptr, PP(m, "dec.emb"), m->hst[0], m->lx, Hd, dt))) return rc;
+        } else {
+            if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt))) return rc;
+            if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+            S2S_HIP_CHECK(hipMemsetAsync(m->n_active, 0, sizeof(int), st));
+            if ((rc = tdt_select(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B))) return rc;
+        }
         if ((step & 15) == 15 || step + 1 == max_steps) {
             S2S_HIP_CHECK(hipMemcpyAsync(m->host_flag, m->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
             S2S_HIP_CHECK(hipStreamSynchronize(st));
             if (*m->host_flag == 0) break;
         }
-        if ((rc = prednet(m, st, B))) return rc;
-        if ((rc = tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd))) return rc;
+        if (fused) {
+            if ((rc = prednet_fused(m, st, B))) return rc;
+            if ((rc = tdt_commit_joint(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd, m->encp, m->frame, m->jin, T, nullptr, m->n_active, dt))) return rc;
+        } else {
+            if ((rc = prednet(m, st, B))) return rc;
+            if ((rc = tdt_commit(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd))) return rc;
+        }
     }
     const size_t ob = sizeof(int) * (size_t)B * max_steps;
     S2S_HIP_CHECK(hipMemcpyAsync(out_tok, m->o_tok, ob, hipMemcpyDeviceToDevice, st));
