@@ -354,7 +354,7 @@ __global__ void tdt_commit_joint_kernel(float* const* __restrict__ dst, const fl
     if (dyn) Tn = dyn[0];
     const bool take = force || adv[b];
     const int f = min(frame[b], Tn - 1);
-    if (b == 0 && threadIdx.x == 0) *n_active = 0;
+    if (n_active && b == 0 && threadIdx.x == 0) *n_active = 0;      // (null in the captured step: the host reads the counter AFTER the whole replay)
     for (int i = threadIdx.x; i < Hd; i += blockDim.x) {
         if (take)
             for (int a = 0; a + 1 < n_arrays; ++a) dst[a][(long)b * Hd + i] = src[a][(long)b * Hd + i];

@@ -322,9 +322,13 @@ static int tdt_step_body(Parakeet* m, hipStream_t st, int B, int T, int max_step
     int rc;
     if (tdt_fused()) {      // 8 launches: the joint input of this step was written by the previous step's commit (or the prologue's)
         if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;
+        if (dyn) {      // captured step: the host polls the active-row counter after a whole replay, so it is reset in FRONT of the pick, not behind the commit
+            fill_int_kernel<<<1, 64, 0, st>>>(m->n_active, 0, 1);
+            S2S_LAUNCH_CHECK();
+        }
         if ((rc = tdt_select_in(st, m->logits, V + ND, V, ND, c.vocab - 1, m->enc_len, s, m->o_tok, m->o_dur, m->o_frame, max_steps, B, dyn, PP(m, "dec.emb"), m->hst[0], m->lx, Hd, dt))) return rc;
         if ((rc = prednet_fused(m, st, B))) return rc;
-        return tdt_commit_joint(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd, m->encp, m->frame, m->jin, T, dyn, m->n_active, dt);
+        return tdt_commit_joint(st, m->d_dst, m->d_src, NA, m->adv, 0, B, Hd, m->encp, m->frame, m->jin, T, dyn, dyn ? nullptr : m->n_active, dt);
     }
     if ((rc = tdt_joint_in(st, m->encp, m->dec, m->frame, m->jin, B, T, Hd, dt, dyn))) return rc;
     if ((rc = gemm(st, m->jin, Hd, PP(m, "dec.joint.w"), PPF(m, "dec.joint.b"), nullptr, m->logits, V + ND, B, V + ND, Hd, dt, S2S_F32, S2S_ACT_NONE, false))) return rc;

@@ -89,3 +89,36 @@ def test_bf16_engine_matches_within_margin(ref):
     print(f"bf16 parakeet agreed on {agree}/{total} steps")
     assert agree >= total // 3
     eng.close()
+
+
+def test_tdt_step_variants_agree_step_for_step():
+    """The fused 8-launch TDT step (default), the 14-launch step of rounds 1 - 5 (S2S_TDT_FUSED=0) and the captured step (S2S_TDT_GRAPH=1, with
+    and without fusion) emit the same (token, duration, frame) steps for the same float32 engine - the switches are read once per process, so
+    every variant runs in its own interpreter."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import json, sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from speech_to_speech_amd.parakeet import ParakeetEngine\n"
+        "from speech_to_speech_amd.synth import synth_audio\n"
+        "from speech_to_speech_amd.synth_weights import ParakeetDims, parakeet_state_dict\n"
+        "d = ParakeetDims.test_tiny()\n"
+        "e = ParakeetEngine(d, parakeet_state_dict(d, seed=12, gain=1.5), dtype=torch.float32, max_batch=3, max_seconds=8.0)\n"
+        "f, nf, _ = e.features([synth_audio(n, 40 + i) for i, n in enumerate((96000, 40000, 70000))])\n"
+        "e.encode(f, nf)\n"
+        "print(json.dumps([list(x) for x in e.tdt_greedy()]))\n")
+    outs = {}
+    for name, env in (("fused", {}), ("unfused", {"S2S_TDT_FUSED": "0"}), ("graph", {"S2S_TDT_GRAPH": "1"}), ("graph-unfused", {"S2S_TDT_GRAPH": "1", "S2S_TDT_FUSED": "0"})):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    n_steps = [len(t) for t in outs["fused"][0]]
+    print(f"TDT step variants: {n_steps} steps per session, all four variants identical")
+    assert min(n_steps) > 8
+    for name in ("unfused", "graph", "graph-unfused"):
+        assert outs[name] == outs["fused"], name
