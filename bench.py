@@ -114,8 +114,9 @@ def parse(argv=None):
     ap.add_argument("--tts-lead-s", type=float, default=0.5, help="pacing of the pool's continuous TTS lanes: continuation rounds run when a session's audio lead drops below this")
     ap.add_argument("--tts-fill-first", type=int, default=0, help="lane admission: 0 = least-loaded lanes take new sessions; T = fill first (lane k only once the lanes below hold T live sessions)")
     ap.add_argument("--tts-lane-cus", type=int, default=8, help="CU mask of the pool's TTS lane streams: lanes run on N of every 8 compute units (8 = all)")
-    ap.add_argument("--stt-max-batch", type=int, default=32, help="largest final-STT batch of the pool in the open-loop probe (0: the engine's max_batch); a cap keeps a "
-                    "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once")
+    ap.add_argument("--stt-max-batch", type=int, default=None, help="largest STT batch of the pool in the open-loop probe (0: the engine's max_batch; default 32 for c3 - a cap keeps a "
+                    "momentary backlog from locking the pool into long STT batches whose sessions then start their TTS all at once -, 64 for c5: live partials are short windows "
+                    "and their passes are launch-bound, profiles/r06_open_loop_ab.txt: at 800 sessions 100 %% of the partials answered at p50 100 ms with 64 against 93 %% at 529 ms with 32)")
     ap.add_argument("--stt-slots", type=int, default=0, help="> 0: the pool's Whisper token loop runs continuously with this many slots (SessionPool stt_slots; unmeasured, off)")
     ap.add_argument("--stt-slot-steps", type=int, default=4, help="greedy steps per round of the continuous token loop")
     ap.add_argument("--tts-nursery-slots", type=int, default=0, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
@@ -752,7 +753,9 @@ def main():
     sessions = shard_sessions(B, rank)
     # engine capacity: the turn-batches of the timed region stay at B sessions; the open-loop probe's SessionPool may batch more
     # of the queued sessions per pass (measured on C3: 549 sustained sessions with batches of up to 128 vs 416 with 64)
-    MB = min(128, max(B, args.pool_max_batch or (128 if wl == "c3" else B)))      # STT engine rows (whisper.cpp: <= 128)
+    if args.stt_max_batch is None:
+        args.stt_max_batch = 64 if wl == "c5" else 32
+    MB = min(128, max(B, args.stt_max_batch, args.pool_max_batch or (128 if wl == "c3" else B)))      # STT engine rows (whisper.cpp / parakeet.cpp: <= 128)
     merge = max(1, int(args.tts_merge if args.tts_merge is not None else (4 if wl == "c3" and not args.serial else 1)))
     TMB = max(MB, merge * B, int(args.tts_slots or (512 if wl in ("c3", "c5") else B)))        # TTS engine slots (tts.cpp: <= 512); a PACED reply holds its slot for its whole duration
     if TMB > 512 or B > 128:
