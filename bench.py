@@ -1062,6 +1062,7 @@ def main():
             repeats = []
             if best is not None and not args.probe_sessions:
                 held = sorted((r for r in tried if r.get("sustained")), key=lambda r: r["sessions"])
+                refined = 0
                 while held:
                     cand = held[-1]
                     ok_all = True
@@ -1071,10 +1072,21 @@ def main():
                         rr["repeat_of"] = int(cand["sessions"])
                         repeats.append(rr)
                         ok_all = ok_all and rr["sustained"]
+                        if not ok_all:
+                            break                        # (one failed window settles it: the next repeat would not change the outcome)
                     if ok_all:
                         best = cand
                         break
                     held.pop()
+                    # the candidate did not hold and the next smaller probe that did is far below it (the search steps by 25 %): one probe half
+                    # way, so that the figure is not stepped down by a quarter because of the search's own grid (at most twice per run)
+                    if held and refined < 2 and int(cand["sessions"]) > 1.15 * int(held[-1]["sessions"]):
+                        refined += 1
+                        mid = probe((int(cand["sessions"]) + int(held[-1]["sessions"])) // 2)
+                        mid["sustained"] = probe_sustained(mid, args.ttfa_bound_ms)
+                        tried.append(mid)
+                        if mid["sustained"]:
+                            held.append(mid)
                     best = held[-1] if held else None
                 # nothing held (a bistable schedule: see profiles/r04_open_loop_ab.txt): step down from the smallest probe tried, two more attempts,
                 # each with both arrival seeds, so that the line reports a sustained figure rather than falling back to the closed-loop one
