@@ -54,6 +54,10 @@ int32_t s2s_op_attn_step(void* stream, const void* qkv, int64_t qkv_rs, void* K,
                          const float* qw, const float* kw, float eps, const float* cos_t, const float* sin_t, const int32_t* pos_dev, int32_t B,
                          int32_t H, int32_t Hkv, int32_t D, int32_t kv_cap, int32_t window, float scale, int32_t o_frag, int32_t dtype);
 int32_t s2s_op_attn_step_tune(int32_t share);
+/* The codec's k = 7 dilated convolutions (s2s_op_conv1d_causal_tm shapes with 256-row-aligned items): 1 = tap-reuse kernel (round 6: the tall
+ * input tile is staged once per channel chunk and the seven taps read it at row offsets), 0 = the tap-by-tap GEMM of rounds 1 - 5, -1 = default /
+ * environment S2S_CONV7.  tests/test_attention_gpu.py compares the two. */
+int32_t s2s_op_conv7_tune(int32_t on);
 
 /* Microbenchmark aid: capture whatever is enqueued on *out_stream between begin and end into a hipGraph, replay it
  * `warm` + `reps` times and return the average device time of one replay (kernel cost INSIDE a graph, no host launch). */

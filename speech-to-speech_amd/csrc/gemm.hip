@@ -785,6 +785,206 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     }
 }
 
+// ---- k = 7 dilated causal convolution with TAP REUSE (round 6) -------------------------------------------------------------------------
+// The codec decoder's residual-unit convolutions (C -> C, kernel 7, dilation 1 / 3 / 9; tts.cpp) ran as a GEMM over K = 7 C whose A rows are
+// re-staged global -> LDS once per TAP: 7 x the fill bytes of the rows a tile actually needs, on a kernel whose main loop is bound by exactly that
+// fill path (profiles/r06_bench_conv.txt: 12.7 - 21.1 GB of LDS fill per launch at 512 live rows against 0.4 - 2 GB of HBM traffic; 0.18 - 0.35 of
+// the MFMA peak).  Here the K loop runs [channel chunk][tap]: a TALL tile - the 256 output rows plus the 6 x dilation history rows in front of
+// them, BKC channels wide - is staged ONCE per channel chunk (double buffered) and the seven taps read their A fragments from it at row offsets
+// tap x dilation; only the weight slabs (128 columns x BKC channels of one tap) still stream through a 3-stage ring.  Fill bytes per 256 x 128
+// tile and chunk: (256 + 6 d) rows + 7 x 128 weight rows instead of 7 x (256 + 128).  Same 256 x 128 tile, 8 waves of 64 x 64, LDS-DMA with the
+// XOR swizzle in the source address, counted waits, one barrier per (chunk, tap); epilogue = gemm_tile3's (bias, SnakeBeta, 16-byte row stores).
+// Preconditions (launch_gemm checks them, anything else keeps the tap-by-tap GEMM): bf16, 7 taps, lda == tap_len == C, C % BKC == 0,
+// tap_stride = d x C with 6 d <= 64, every item's rows a multiple of 256 (a tile never straddles two sessions), no residual / second output.
+// The accumulation order over K differs from the GEMM's ([chunk][tap] instead of [tap][channel]): same products, f32 sums in another order.
+template <int BKC> struct Cv7 {
+    static constexpr int ROWB_ = BKC * 2;                 // bytes per LDS row
+    static constexpr int RPP = 1024 / ROWB_;              // rows per 1 KiB DMA piece (one wave instruction)
+    static constexpr int CPR = ROWB_ / 16;                // 16-byte chunks per row
+    static constexpr int NA = BKC == 64 ? 5 : 3;          // tall-tile pieces per wave (8 waves): 320 rows (BKC 64) / 384 rows (BKC 32) >= 256 + 54
+    static constexpr int NW = (128 / RPP) / 8;            // weight-slab pieces per wave: 2 / 1
+    static constexpr int TALL_ROWS = NA * 8 * RPP;
+    static constexpr int TALLB = TALL_ROWS * ROWB_;
+    static constexpr int WSTB = 128 * ROWB_;
+    static constexpr int KK = BKC / 32;
+    __device__ static __forceinline__ int swz(int row) { return BKC == 64 ? (row & 7) : ((row >> 2) & 3); }
+};
+constexpr int CV7_LDS = 8 * 64 * 68 * 4;                  // the epilogue's staging (8 waves x 64 x 68 floats) is the largest user: 136 KiB
+
+template <typename CT, int BKC>
+__global__ __launch_bounds__(512) void conv7_tile_kernel(const __hip_bfloat16* __restrict__ A, const __hip_bfloat16* __restrict__ W,
+                                                          const float* __restrict__ bias, CT* C, long ldc, int M, int N, int Cin, int dil, int act,
+                                                          int tiles_m, RowMap rm) {
+    using V = Cv7<BKC>;
+    constexpr int ROWB_ = V::ROWB_, RPP = V::RPP, CPR = V::CPR, NA = V::NA, NW = V::NW, KK = V::KK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsc[];
+    unsigned char* const tall0 = ldsc;
+    unsigned char* const wring = ldsc + 2 * V::TALLB;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(wg, tiles_m, (int)gridDim.x / tiles_m, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int ncc = Cin / BKC;
+    const int tall_valid = 256 + 6 * dil;                  // rows of the tall tile that exist (and are read); the rest re-read the last one
+    // the tile's rows belong to ONE item (G % 256 == 0): input row j of the tall tile = A + item * a_bs + (r0 + j) * C
+    const __hip_bfloat16* Abase = A + (long)(m0 / rm.G) * rm.a_bs + (long)(m0 % rm.G) * Cin;
+
+    const __hip_bfloat16* pa[NA];
+    const __hip_bfloat16* pw[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (wave * NA + i) * RPP + lane / CPR, slot = lane % CPR;
+        pa[i] = Abase + (long)min(row, tall_valid - 1) * Cin + ((slot ^ V::swz(row)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int row = (wave * NW + i) * RPP + lane / CPR, slot = lane % CPR;
+        pw[i] = W + (long)min(n0 + row, N - 1) * rm.ldw + ((slot ^ V::swz(row)) << 3);
+    }
+    auto issue_a = [&](int cc) {
+        unsigned char* base = tall0 + (cc & 1) * V::TALLB + wave * (NA * 1024);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + cc * BKC),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    };
+    // weight slabs in loop order: slab s = (chunk s / 7, tap s % 7) -> ring stage s % 3; slabs past the end re-read the last one (never consumed),
+    // so that every wait of the loop is the same instruction
+    int w_cc = 0, w_tap = 0, w_stage = 0;
+    auto issue_w = [&]() {
+        unsigned char* base = wring + w_stage * V::WSTB + wave * (NW * 1024);
+        const long off = (long)w_tap * Cin + w_cc * BKC;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + off),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+        w_stage = w_stage == 2 ? 0 : w_stage + 1;
+        if (w_cc + 1 < ncc || w_tap < 6) {
+            if (++w_tap == 7) { w_tap = 0; ++w_cc; }
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue_a(0);
+    issue_w();
+    issue_w();
+    int stage = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+        const bool more = cc + 1 < ncc;
+        const unsigned char* sA = tall0 + (cc & 1) * V::TALLB;
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) {
+            // slab (cc, tap) has landed when at most the loads issued AFTER it are outstanding: the next slab (NW), plus - behind tap 0 of a chunk
+            // that has a successor - the next chunk's tall tile (NA), which was issued between this slab's request and the next one's
+            if ((tap == 1 || tap == 2) && more) S2S_WAIT_VMCNT(NW + NA);
+            else S2S_WAIT_VMCNT(NW);
+            __builtin_amdgcn_s_barrier();          // ... for every wave; and every wave is done with slab s - 1 (its ring stage, and at tap 0 the other tall buffer)
+            issue_w();                             // slab s + 2 into the stage slab s - 1 used
+            if (tap == 0 && more) issue_a(cc + 1);
+            const unsigned char* sW = wring + stage * V::WSTB;
+            const int shift = tap * dil;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                bf16x8_t fa[4], fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm + i * 16 + l15 + shift;
+                    fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * ROWB_ + (((kk * 4 + lg) ^ V::swz(ra)) << 4));
+                    const int rw = wn + i * 16 + l15;
+                    fw[i] = *reinterpret_cast<const bf16x8_t*>(sW + rw * ROWB_ + (((kk * 4 + lg) ^ V::swz(rw)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+            }
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    }
+    S2S_WAIT_VMCNT(0);                           // the redundant tail loads still target the ring
+    __builtin_amdgcn_s_barrier();                // every wave is done reading; the staging below reuses the LDS
+
+    // ---- epilogue: gemm_tile3's, without residuals / second output (bias, activation or SnakeBeta, 16-byte row-contiguous stores) ----
+    constexpr int VEC = 16 / (int)sizeof(CT), LPR = 64 / VEC, RPI = 64 / LPR, NIT = 64 / RPI, PITCH = 68;
+    const int cc_ = (lane % LPR) * VEC;
+    const int n = n0 + wn + cc_;
+    const bool full = n + VEC <= N;
+    float* stg = reinterpret_cast<float*>(ldsc) + wave * (64 * PITCH);
+    {
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = n0 + wn + j * 16 + l15;
+            bv[j] = (bias && nc < N) ? bias[nc] : 0.f;
+        }
+        with_act(act, [&](auto actc) {
+            constexpr int ACTC = decltype(actc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stg[(i * 16 + lg * 4 + r) * PITCH + j * 16 + l15] = apply_act_c<CT, ACTC>(acc[i][j][r] + bv[j]) * rm.alpha;
+        });
+    }
+    S2S_WAVE_LDS_HANDOVER();
+    const int chmod = rm.sn_mod > 0 ? rm.sn_mod : (1 << 30);
+    float s1a[VEC], s1b[VEC];
+    {
+        int ch = n < N ? n % chmod : 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bool in = n + e < N;
+            s1a[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_a[ch] : 0.f;
+            s1b[e] = (in && act == S2S_ACT_SNAKE) ? rm.sn_ib[ch] : 0.f;
+            if (++ch == chmod) ch = 0;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lane / LPR;
+        const int m = m0 + wm + row;
+        if (m >= M || n >= N) continue;
+        const int mb = m / rm.G, mr = m - mb * rm.G;
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(stg + row * PITCH + cc_ + q * 4);
+            v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
+        }
+        if (act == S2S_ACT_SNAKE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = snake_f<CT>(v[e], s1a[e], s1b[e]);
+        }
+        CT* cp = C + (long)mb * rm.c_bs + (long)mr * ldc + n;
+        if (full && ((uintptr_t)cp & 15) == 0) {
+            if constexpr (sizeof(CT) == 4) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                u32x4_t pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2_hw(v[2 * q], v[2 * q + 1]);
+                *reinterpret_cast<u32x4_t*>(cp) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (n + e < N) Elem<CT>::st(cp + e, v[e]);
+        }
+    }
+}
+
 // ---- 256x256 tile GEMM: 8 waves of 128x64 (or 4 of 128x128), 4-stage ring of 32-wide K slabs (bf16) ----------------------------
 // Validated in round 3 (tools/proto/tile4_check.py, profiles/r03_tile4_check.txt; tests/test_ops_gpu.py runs the encoder shapes through
 // it): the 8-wave variant is the default for the encoder-sized projections.
@@ -1745,6 +1945,29 @@ static bool tile5_ok(const GemmArgs& g, int M, int N, int K, int nz, bool ext) {
     return K >= 2 * T5_BK && M >= 2048 && N >= 512 && (long)cdiv(M, T5_M) * cdiv(N, T5_N) * nz >= 192;
 }
 
+// the tap-reuse convolution kernel takes the codec's residual-unit convolutions (conv7_tile_kernel above); S2S_CONV7=0 / s2s_op_conv7_tune(0): off
+static int g_conv7 = -1;
+void conv7_set(int on) { g_conv7 = on < 0 ? -1 : (on != 0); }
+static bool conv7_enabled() {
+    static const bool env = [] {
+        const char* e = getenv("S2S_CONV7");
+        return !e || atoi(e) != 0;
+    }();
+    return g_conv7 < 0 ? env : g_conv7 != 0;
+}
+template <typename T>
+static bool conv7_ok(const GemmArgs& g, const RowMap& rm, int M, int N, int K, int nz) {
+    if (sizeof(T) != 2 || !conv7_enabled() || g.tap_len <= 0 || nz != 1) return false;
+    const int Cin = g.tap_len;
+    if (K != 7 * Cin || g.lda != Cin || Cin % 32 != 0 || g.tap_stride % Cin != 0) return false;
+    const long dil = g.tap_stride / Cin;
+    if (dil < 1 || 6 * dil > 64) return false;
+    if (rm.G <= 0 || rm.G % 256 != 0 || M % 256 != 0 || rm.ldw < K) return false;
+    if (g.residual || g.res_c || g.C2 || (g.alpha_set && g.alpha != 1.0f)) return false;
+    if (g.act != S2S_ACT_NONE && g.act != S2S_ACT_SNAKE && g.act != S2S_ACT_GELU && g.act != S2S_ACT_SILU && g.act != S2S_ACT_RELU) return false;
+    return (long)(M / 256) * cdiv(N, 128) >= 128;      // enough tiles to fill the chip; small launches keep the GEMM path
+}
+
 static bool gemm_trace() {
     static const bool on = getenv("S2S_GEMM_TRACE") != nullptr;
     return on;
@@ -1780,7 +2003,7 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
         static std::mutex mu;
         static std::set<std::string> seen;
         char key[256];
-        const char* path = M <= 128 && !(g.glu && M > 64) && !ext ? "skinny" : tile5_ok<T>(g, M, N, K, nz, ext) ? "tile5" : tile4_ok<T>(g, M, N, K, nz, ext) ? "tile4" : "tile3/tile";
+        const char* path = M <= 128 && !(g.glu && M > 64) && !ext ? "skinny" : conv7_ok<T>(g, rm, M, N, K, nz) ? "conv7" : tile5_ok<T>(g, M, N, K, nz, ext) ? "tile5" : tile4_ok<T>(g, M, N, K, nz, ext) ? "tile4" : "tile3/tile";
         snprintf(key, sizeof key, "gemm %s M=%d N=%d K=%d nz=%d G=%d tap=%d act=%d res=%d ext=%d%d%d in=%zu out=%zu", path, M, N, K, nz, rm.G, g.tap_len, g.act,
                  g.residual != nullptr, g.act == S2S_ACT_SNAKE, g.res_c != nullptr, g.C2 != nullptr, sizeof(T), sizeof(CT));
         std::lock_guard<std::mutex> lk(mu);
@@ -1834,6 +2057,26 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
 #undef S2S_SK_MT
 #undef S2S_SK
 #undef S2S_SK1
+    } else if (conv7_ok<T>(g, rm, M, N, K, nz)) {
+        if constexpr (sizeof(T) == 2) {
+            const int Cin = g.tap_len, dil = (int)(g.tap_stride / g.tap_len);
+            const int tiles_m = M / 256, tiles_n = cdiv(N, 128);
+            static bool attr7[64] = {};
+            int dev = 0;
+            S2S_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr7[dev]) {
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)conv7_tile_kernel<CT, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, CV7_LDS));
+                S2S_HIP_CHECK(hipFuncSetAttribute((const void*)conv7_tile_kernel<CT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CV7_LDS));
+                if (dev >= 0 && dev < 64) attr7[dev] = true;
+            }
+            ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K, (double)N * K * sizeof(T) + (double)M * Cin * sizeof(T) + (double)M * N * sizeof(CT));
+            if (Cin % 64 == 0)
+                launch_k(conv7_tile_kernel<CT, 64>, dim3(tiles_m * tiles_n), dim3(512), CV7_LDS, st, (const __hip_bfloat16*)g.A, (const __hip_bfloat16*)g.W, g.bias,
+                         (CT*)g.C, g.ldc, M, N, Cin, dil, g.act, tiles_m, rm);
+            else
+                launch_k(conv7_tile_kernel<CT, 32>, dim3(tiles_m * tiles_n), dim3(512), CV7_LDS, st, (const __hip_bfloat16*)g.A, (const __hip_bfloat16*)g.W, g.bias,
+                         (CT*)g.C, g.ldc, M, N, Cin, dil, g.act, tiles_m, rm);
+        }
     } else if (tile5_ok<T>(g, M, N, K, nz, ext)) {
         if constexpr (sizeof(T) == 2) {
             const int tiles_m = cdiv(M, T5_M), tiles_n = cdiv(N, T5_N);
@@ -2019,5 +2262,11 @@ extern "C" int32_t s2s_op_conv1d_causal_tm(void* stream, const void* x, const vo
 /* Development hook (include/s2s_mi355x_dev.h): phase timestamps of every following gemm_tile5_kernel launch, 6 x u64 per tile, or null. */
 extern "C" int32_t s2s_op_gemm_tile_debug(void* dbg_dev) {
     s2s::tile5_set_debug(reinterpret_cast<unsigned long long*>(dbg_dev));
+    return S2S_OK;
+}
+
+/* development: the k = 7 convolutions of the codec on the tap-reuse kernel (1, default) or on the tap-by-tap GEMM of rounds 1 - 5 (0); -1 = default */
+extern "C" int32_t s2s_op_conv7_tune(int32_t on) {
+    s2s::conv7_set(on);
     return S2S_OK;
 }

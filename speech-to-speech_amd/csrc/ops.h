@@ -31,6 +31,7 @@ struct GemmArgs {
     void* C2; const float* snake2_a; const float* snake2_ib;
 };
 int gemm_ex(hipStream_t st, const GemmArgs& g);
+void conv7_set(int on);                  // tap-reuse convolution kernel: 1 / 0 = forced on / off, -1 = default (environment S2S_CONV7)
 int gemm(hipStream_t st, const void* A, long lda, const void* W, const float* bias,
          const float* residual, void* C, long ldc, int M, int N, int K, int ab_dtype, int c_dtype,
          int act, bool allow_splitk);

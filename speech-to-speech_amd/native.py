@@ -150,6 +150,7 @@ _DEV_SIGNATURES = {
     "s2s_guard_check": [C.c_char_p, _i32],
     "s2s_op_attn_step": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32],
     "s2s_op_attn_step_tune": [_i32],
+    "s2s_op_conv7_tune": [_i32],
 }
 _RESTYPES = {"s2s_last_error": C.c_char_p, "s2s_whisper_workspace_bytes": C.c_int64,
              "s2s_parakeet_workspace_bytes": C.c_int64, "s2s_tts_workspace_bytes": C.c_int64,

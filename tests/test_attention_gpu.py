@@ -142,6 +142,42 @@ def test_causal_dilated_conv_as_gemm(dt, B, T, Cin, Cout, k, dil):
     assert err < (3e-5 if dt == torch.float32 else 4e-2)
 
 
+@pytest.mark.parametrize("B,T,C,Cout,dil", [(8, 4096, 96, 96, 9), (8, 4096, 96, 96, 1), (4, 5120, 192, 192, 3), (16, 1280, 384, 384, 9), (128, 256, 768, 768, 1),
+                                            (8, 4096, 64, 200, 3), (8, 4096, 96, 1, 1)])
+def test_tap_reuse_conv7_matches_reference_and_the_tap_by_tap_gemm(B, T, C, Cout, dil):
+    """The codec's k = 7 dilated convolutions on the tap-reuse kernel (csrc/gemm.hip conv7_tile_kernel: the tall input tile staged once per channel
+    chunk, seven taps read from LDS at row offsets; items of 256-row multiples) against a float64 reference and against the tap-by-tap GEMM of
+    rounds 1 - 5 (s2s_op_conv7_tune(0)): non-zero history rows, every dilation of the decoder, 64- and 32-channel chunks (C = 96), ragged /
+    single output columns, the lpad > 6 d offset of the engines (56 rows)."""
+    lib = native.load()
+    k, lpad, dt = 7, 56, torch.bfloat16
+    g = torch.Generator().manual_seed(T + C + dil)
+    x = torch.randn(B, C, T, generator=g).to(dt)
+    hist = torch.randn(B, C, lpad, generator=g).to(dt)
+    w = (torch.randn(Cout, C, k, generator=g) / math.sqrt(C * k)).to(dt)
+    b = torch.randn(Cout, generator=g)
+    xd = torch.cat([hist, x], dim=2).permute(0, 2, 1).contiguous().to(DEV)
+    wd, bd = w.permute(0, 2, 1).contiguous().to(DEV), b.to(DEV)
+    outs = {}
+    for on in (1, 0):
+        y = torch.zeros(B, T, Cout, dtype=dt, device=DEV)
+        native.check(lib.s2s_op_conv7_tune(on))
+        try:
+            native.check(lib.s2s_op_conv1d_causal_tm(native.stream_handle(), native.ptr(xd), native.ptr(wd), native.ptr(bd), native.ptr(y), B, T, C, Cout, k, dil, lpad,
+                                                     native.S2S_BF16, native.S2S_BF16, native.ACT_NONE))
+            torch.cuda.synchronize()
+        finally:
+            lib.s2s_op_conv7_tune(-1)
+        outs[on] = y.double().cpu()
+    full = torch.cat([hist, x], dim=2).double()
+    ref = torch.nn.functional.conv1d(full, w.double(), b.double(), dilation=dil)[:, :, lpad - (k - 1) * dil:].permute(0, 2, 1)
+    e1, e0 = (outs[1] - ref).abs().max().item(), (outs[0] - ref).abs().max().item()
+    d10 = (outs[1] - outs[0]).abs().max().item()
+    print(f"conv7 B{B} T{T} {C}->{Cout} d{dil}: tap-reuse err {e1:.3e}, tap-by-tap GEMM err {e0:.3e}, between them {d10:.3e}")
+    assert e1 < 4e-2 and e0 < 4e-2 and d10 < 4e-2
+    assert e1 < 1.5 * e0 + 1e-3                 # same products, another f32 summation order: the same error class
+
+
 # ---- decode-step attention: grouped heads share one workgroup per KV head (round 6) ---------------------------------------------------
 def _attn_step(share, qkv, K, V, pos, H, Hkv, D, kv_cap, qw, kw, cos, sin, window=0, o_frag=False):
     lib = native.load()
