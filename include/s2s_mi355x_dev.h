@@ -47,8 +47,8 @@ int32_t s2s_op_gemm_tile_debug(void* dbg_dev);
 /* The decode-step attention of the Qwen3 stacks and the Whisper decoder's self-attention as an operator (csrc/attention.hip attn_step_kernel):
  * per-head RMSNorm of q / k (qw / kw, null = none), rotary embedding at pos[b] (cos_t / sin_t [max_pos][D/2], null = none), append of the new
  * K / V row at cache row pos[b], attention over cache[jlo, pos[b]) + the new row.  qkv row b = [H q heads | Hkv k heads | Hkv v heads] x D;
- * K / V element (b, j, hk, d) at base + b*kv_bs + j*kv_rs + hk*D + d; O row b at O + b*o_bs (o_frag: fragment-major [B][H*D], gemm_dec layout).
- * s2s_op_attn_step_tune(share): 1 = grouped heads (H / Hkv = 2 or 4) share one workgroup per KV head (round 6, default), 0 = one workgroup
+ * K / V element (b, j, hk, d) at base + b*kv_bs + j*kv_rs + hk*D + d; O row b at O + b*o_bs (o_frag: fragment-major [roundup(B, 16)][H*D], gemm_dec layout).
+ * s2s_op_attn_step_tune(bits): bit 1 = caches of <= 32 positions on one WAVE per item (attn_step_small_kernel; default for bf16), bit 0 / value 1 = grouped heads (H / Hkv = 2 or 4) share one workgroup per KV head (round 6, default), 0 = one workgroup
  * per query head (rounds 2 - 5), -1 = default / environment S2S_ATTN_STEP_GQA.  tests/test_attention_gpu.py checks the two bit for bit. */
 int32_t s2s_op_attn_step(void* stream, const void* qkv, int64_t qkv_rs, void* K, void* V, int64_t kv_bs, int64_t kv_rs, void* O, int64_t o_bs,
                          const float* qw, const float* kw, float eps, const float* cos_t, const float* sin_t, const int32_t* pos_dev, int32_t B,

@@ -518,6 +518,205 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepParams p) {
     }
 }
 
+// ---- decode-step attention over a SHORT cache (round 6): one WAVE per (KV head, session) ----------------------------------------------
+// The code predictor runs 15 x 5 attention steps per frame over a cache of at most 17 positions.  attn_step_kernel spends a 256-thread
+// workgroup, four block barriers and two LDS round trips on each (head group, session): 26.7 us per launch at 512 rows for 19 MB of cache rows
+// (0.7 TB/s) - 1.3 ms of the 9 ms frame at 256 rows.  Here one wave does the whole item - row preparation (head norms, RoPE, cache append) of
+// the group's queries, the new key and value; scores of all cached keys (the chunk-lane layout of the big kernel: CH lanes per key row, KPI keys
+// per wave instruction) kept in registers; softmax; PV - with wave shuffles only, no block barrier, and 4 items per workgroup, so all items of a
+// launch are resident at once.  Same arithmetic per element as attn_step_kernel except for the summation ORDER of the softmax denominator and of
+// PV (one wave owns all keys instead of four waves owning a quarter each): used for the bf16 serving engines when kv_cap <= 32; the float32
+// parity engines keep attn_step_kernel (S2S_ATTN_STEP_SMALL=0 / s2s_op_attn_step_tune bit 1 switch it off).
+template <typename T, int D, int GQ>
+__global__ __launch_bounds__(256) void attn_step_small_kernel(AttnStepParams p, int units) {
+    constexpr int EPL = 16 / (int)sizeof(T);
+    constexpr int CH = D / EPL;
+    constexpr int KPI = 64 / CH;
+    constexpr int HALF = D / 2;
+    constexpr int MAXIT = 32 / KPI;                 // register-resident scores: caches of up to 32 positions
+    __shared__ float smw[4][(GQ + 2) * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= units * p.B) return;                // (no block-level synchronisation below)
+    const int u = item % units, b = item / units;
+    const int group = p.H / p.Hkv;
+    const int hk = GQ > 1 ? u : u / group;
+    const int h0 = GQ > 1 ? hk * GQ : u;
+    const bool owns_kv = GQ > 1 || h0 % group == 0;
+    const int pos = p.pos[b];
+    float* sq = smw[wave];                          // [GQ][D] scaled, rotated queries
+    float* sk = sq + GQ * D;                        // [D] new key
+    float* sv = sk + D;                             // [D] new value
+    const T* row = (const T*)p.qkv + (long)b * p.qkv_rs;
+    T* Kc = (T*)p.K + (long)b * p.kv_bs + (long)hk * D;
+    T* Vc = (T*)p.V + (long)b * p.kv_bs + (long)hk * D;
+#pragma unroll
+    for (int task = 0; task <= GQ; ++task) {        // queries, then the new key: the arithmetic of attn_step_kernel / rope_qknorm_kernel
+        const bool is_q = task < GQ;
+        const T* x = row + (is_q ? (long)(h0 + task) * D : (long)(p.H + hk) * D);
+        const float* w = is_q ? p.qw : p.kw;
+        for (int i0 = 0; i0 < HALF; i0 += 64) {     // (D = 128: one pass; D = 256 would take two - the sum below is then per pass: D <= 128 only)
+            const int i = i0 + lane;
+            float a = 0.f, c = 0.f;
+            if (i < HALF) {
+                a = Elem<T>::ld(x + i);
+                c = Elem<T>::ld(x + i + HALF);
+            }
+            if (w) {
+                const float ss = wave_sum(a * a + c * c);
+                const float r = rsqrtf(ss / (float)D + p.eps);
+                if (i < HALF) {
+                    a = a * r * w[i];
+                    c = c * r * w[i + HALF];
+                }
+            }
+            if (i < HALF) {
+                float r0 = a, r1 = c;
+                if (p.cosT) {
+                    const float cs = p.cosT[(long)pos * HALF + i], sn = p.sinT[(long)pos * HALF + i];
+                    r0 = a * cs - c * sn;
+                    r1 = c * cs + a * sn;
+                }
+                T t0, t1;
+                Elem<T>::st(&t0, r0);
+                Elem<T>::st(&t1, r1);
+                const float f0 = Elem<T>::ld(&t0), f1 = Elem<T>::ld(&t1);
+                if (is_q) {
+                    sq[task * D + i] = f0 * p.scale;
+                    sq[task * D + i + HALF] = f1 * p.scale;
+                } else {
+                    sk[i] = f0;
+                    sk[i + HALF] = f1;
+                    if (owns_kv) {
+                        Kc[(long)pos * p.kv_rs + i] = t0;
+                        Kc[(long)pos * p.kv_rs + i + HALF] = t1;
+                    }
+                }
+            }
+        }
+    }
+    {
+        const T* x = row + (long)(p.H + p.Hkv + hk) * D;
+        for (int d = lane; d < D; d += 64) {
+            const T t = x[d];
+            sv[d] = Elem<T>::ld(&t);
+            if (owns_kv) Vc[(long)pos * p.kv_rs + d] = t;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                // (LDS traffic of one wave is in order; this only pins the compiler's order)
+
+    const int jlo = p.window > 0 ? max(0, pos - p.window + 1) : 0;
+    const int nc = pos - jlo;                       // cached keys [jlo, pos), at most 31; the new key is handled apart
+    const int c = lane % CH, slot = lane / CH;
+    float q[GQ][EPL], kn[EPL], vn[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        kn[e] = sk[c * EPL + e];
+        vn[e] = sv[c * EPL + e];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) q[g][e] = sq[g * D + c * EPL + e];
+    }
+    const T* Kb = Kc + c * EPL;
+    const T* Vb = Vc + c * EPL;
+    u32x4_t kk[MAXIT], vv[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {            // every cache row this wave needs, K and V, requested up front
+        const int j = jlo + it * KPI + slot;
+        kk[it] = (u32x4_t){0u, 0u, 0u, 0u};
+        vv[it] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (it * KPI < nc && j < pos) {
+            kk[it] = *reinterpret_cast<const u32x4_t*>(Kb + (long)j * p.kv_rs);
+            vv[it] = *reinterpret_cast<const u32x4_t*>(Vb + (long)j * p.kv_rs);
+        }
+    }
+    float sc[GQ][MAXIT], mx[GQ], sn[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) t = fmaf(q[g][e], kn[e], t);
+#pragma unroll
+        for (int o = 1; o < CH; o <<= 1) t += __shfl_xor(t, o, 64);
+        sn[g] = t;
+        mx[g] = t;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int j = jlo + it * KPI + slot;
+        const bool valid = it * KPI < nc && j < pos;
+        const u32x4_t v = kk[it];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            float s_ = 0.f;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s_ = fmaf(__uint_as_float(v[e] << 16), q[g][2 * e], s_);
+                    s_ = fmaf(__uint_as_float(v[e] & 0xffff0000u), q[g][2 * e + 1], s_);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_ = fmaf(__uint_as_float(v[e]), q[g][e], s_);
+            }
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+            sc[g][it] = valid ? s_ : -INFINITY;
+            mx[g] = fmaxf(mx[g], sc[g][it]);
+        }
+    }
+    float inv[GQ], pn[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) mx[g] = fmaxf(mx[g], __shfl_xor(mx[g], o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            sc[g][it] = expf(sc[g][it] - mx[g]);    // (-inf -> 0 for the slots past the cache)
+            sum += sc[g][it];
+        }
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        pn[g] = expf(sn[g] - mx[g]);
+        inv[g] = 1.0f / (sum + pn[g]);
+    }
+    const int ksteps = (p.H * D) >> 5;
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+        float acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const u32x4_t v = vv[it];
+            const float pj = sc[g][it];
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] = fmaf(pj, __uint_as_float(v[e] << 16), acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(pj, __uint_as_float(v[e] & 0xffff0000u), acc[2 * e + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pj, __uint_as_float(v[e]), acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+            for (int o = CH; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+            acc[e] = (acc[e] + pn[g] * vn[e]) * inv[g];
+        }
+        if (slot == 0) {
+            const int h = h0 + g, k = h * D + c * EPL;
+            T* dst = p.o_frag ? (T*)p.O + ((((long)(b >> 4) * ksteps + (k >> 5)) * 4 + ((k >> 3) & 3)) * 16 + (b & 15)) * 8 + (k & 7)
+                              : (T*)p.O + (long)b * p.o_bs + k;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) Elem<T>::st(dst + e, acc[e]);
+        }
+    }
+}
+
 static int g_attn_step_share = -1;               // s2s_op_attn_step_tune: -1 = environment / default, 0 / 1 = forced
 
 template <typename T>
@@ -526,9 +725,34 @@ static int launch_attn_step(hipStream_t st, const AttnStepParams& p) {
         const char* e = getenv("S2S_ATTN_STEP_GQA");
         return !e || atoi(e) != 0;
     }();
-    const bool share = g_attn_step_share < 0 ? share_env : g_attn_step_share != 0;
+    const bool share = g_attn_step_share < 0 ? share_env : (g_attn_step_share & 1) != 0;
     const int group = p.H / p.Hkv;
     const int gq = share && (group == 2 || group == 4) ? group : 1;
+    static const bool small_env = [] {           // S2S_ATTN_STEP_SMALL=0: short caches on attn_step_kernel too (rounds 2 - 5)
+        const char* e = getenv("S2S_ATTN_STEP_SMALL");
+        return !e || atoi(e) != 0;
+    }();
+    // one wave per item for caches of at most 32 positions (the code predictor): bf16 engines by default; tune bit 1 forces it for any dtype,
+    // tune value 0 / 1 without bit 1 switches it off (tests compare the kernels)
+    const bool small_ok = p.kv_cap <= 32 && (p.D == 64 || p.D == 128) && (sizeof(T) == 2 || sizeof(T) == 4);
+    const bool small = small_ok && (g_attn_step_share < 0 ? (small_env && sizeof(T) == 2) : (g_attn_step_share & 2) != 0);
+    if (small) {
+        const int units = gq > 1 ? p.Hkv : p.H;
+        dim3 sgrid(cdiv(units * p.B, 4));
+        ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.kv_cap * p.D,
+                       (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_cap * p.D * 2 + (double)p.H * p.D * 2));
+#define S2S_STEP_SMALL(DV)                                                                             \
+    do {                                                                                               \
+        if (gq == 2) launch_k(attn_step_small_kernel<T, DV, 2>, sgrid, dim3(256), 0, st, p, units);    \
+        else if (gq == 4) launch_k(attn_step_small_kernel<T, DV, 4>, sgrid, dim3(256), 0, st, p, units); \
+        else launch_k(attn_step_small_kernel<T, DV, 1>, sgrid, dim3(256), 0, st, p, units);            \
+    } while (0)
+        if (p.D == 64) S2S_STEP_SMALL(64);
+        else S2S_STEP_SMALL(128);
+#undef S2S_STEP_SMALL
+        S2S_LAUNCH_CHECK();
+        return S2S_OK;
+    }
     dim3 grid(gq > 1 ? p.Hkv : p.H, p.B);
     ProfScope prof(st, S2S_PROF_ATTN_ROWS, 4.0 * p.B * p.H * (double)p.kv_cap * p.D,
                    (double)sizeof(T) * p.B * ((double)p.Hkv * p.kv_cap * p.D * 2 + (double)p.H * p.D * 2));
@@ -1033,7 +1257,7 @@ int transpose_v(hipStream_t st, const void* V, long v_bs, long v_rs, void* Vt, i
 using namespace s2s;
 
 extern "C" int32_t s2s_op_attn_step_tune(int32_t share) {
-    g_attn_step_share = share < 0 ? -1 : (share != 0);
+    g_attn_step_share = share < 0 ? -1 : (share & 3);      // bit 0: grouped heads share a workgroup; bit 1: one wave per item for caches <= 32 positions
     return S2S_OK;
 }
 

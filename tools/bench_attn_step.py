@@ -24,7 +24,7 @@ for name, H, Hkv, D, cap, layers in (("talker", 16, 8, 128, 256, 28), ("predicto
     pos = torch.full((B,), pos_v, dtype=torch.int32, device=dev)
     qw = torch.ones(D, device=dev)
     cos, sin = torch.ones(cap, D // 2, device=dev), torch.zeros(cap, D // 2, device=dev)
-    for share in (0, 1, 0, 1):
+    for share in ((0, 1, 0, 1) if name == "talker" else (1, 3, 1, 3)):      # predictor: workgroup kernel (1) vs one wave per item (3)
         native.check(lib.s2s_op_attn_step_tune(share))
         st = C.c_void_p()
         native.check(lib.s2s_graph_bench_begin(C.byref(st)), "begin")

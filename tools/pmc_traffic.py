@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = {"gemm_dec": ("gemm_dec_kernel", "gemm_dec2_kernel", "gemm_decw_kernel", "gemm_skinny_kernel"), "gemm_tile": ("gemm_tile3_kernel", "gemm_tile4_kernel", "gemm_tile5_kernel", "gemm_tile_kernel", "conv7_tile_kernel"), "attn_mfma": ("attn_mfma_kernel",),
-            "attn_rows": ("attn_step_kernel", "attn_decode_kernel", "attn_rows_kernel")}
+            "attn_rows": ("attn_step_kernel", "attn_step_small_kernel", "attn_decode_kernel", "attn_rows_kernel")}
 
 
 def collect(d, counter):

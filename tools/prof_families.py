@@ -6,7 +6,7 @@ import json
 import sys
 
 FAMILIES = {"gemm_dec": ("gemm_dec_kernel", "gemm_dec2_kernel", "gemm_decw_kernel", "gemm_skinny_kernel"), "gemm_tile": ("gemm_tile3_kernel", "gemm_tile4_kernel", "gemm_tile5_kernel", "gemm_tile_kernel", "conv7_tile_kernel"), "attn_mfma": ("attn_mfma_kernel",),
-            "attn_rows": ("attn_step_kernel", "attn_decode_kernel", "attn_rows_kernel")}
+            "attn_rows": ("attn_step_kernel", "attn_step_small_kernel", "attn_decode_kernel", "attn_rows_kernel")}
 rows = list(csv.DictReader(open(sys.argv[1])))
 nb = int(sys.argv[2])
 line = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
