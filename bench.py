@@ -691,6 +691,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    t_main0 = time.perf_counter()
+    marks = {}                                   # wall seconds of the run's phases (reported as `wall_s`)
+
+    def mark(name):
+        marks[name] = round(time.perf_counter() - t_main0 - sum(marks.values()), 1)
     import numpy as np
     import torch
 
@@ -1001,6 +1006,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mark("imports_engines_parity")
     run_steps(args.warmup)
     for k in stage:
         stage[k] = 0.0
@@ -1010,6 +1016,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timed_stage = dict(stage)
+    mark("warmup_and_timed_region")
 
     # ---- roofline sample: args.prof_steps more steps of the SAME workload, every launch of the four kernel families timed by
     # its own begin/end timestamps (hipExtLaunchKernelGGL events = rocprofv3 kernel durations), plain stream launches, serial
@@ -1025,6 +1032,7 @@ def main():
         native.prof_enable()
         n_prof *= merge                      # per-step figures below: one step = one turn-batch of B sessions
     stage.update(timed_stage)
+    mark("roofline_sample")
     dt = reduce_step_time(dt)
     step_s = dt / args.steps
     turn_audio_s = utt_s + (0.0 if args.stt_only else n_frames * FRAME_S)
@@ -1130,6 +1138,7 @@ def main():
         except Exception as ex:  # pragma: no cover
             boundary = {"error": repr(ex)}
             sum_over_ranks(0)
+    mark("open_loop_probes")
     if rank != 0:
         return
     sustained = (boundary or {}).get("sustained_sessions")
@@ -1235,11 +1244,14 @@ def main():
         line["parity"] = dict(parity or {})
         if tts_parity is not None:
             line["parity"]["tts"] = tts_parity
+    mark("pmc_traffic_passes")
     if not args.no_cpu_baseline:       # (rank 0 of any world size: an N > 1 line carries the baseline too - VERDICT r5 #15)
         try:
             line["cpu_baseline"] = cpu_baseline_c1()
         except Exception as ex:  # pragma: no cover
             line["cpu_baseline"] = {"error": repr(ex)}
+    mark("cpu_baseline")
+    line["wall_s"] = dict(marks, total=round(time.perf_counter() - t_main0, 1))
     print(json.dumps(line))
 
 
