@@ -32,7 +32,7 @@ extern "C" {
 #define S2S_ERR_STATE (-3)
 #define S2S_ERR_UNSUPPORTED (-4)
 
-#define S2S_ABI_VERSION 4 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots; 4: s2s_logmel_parakeet_cached */
+#define S2S_ABI_VERSION 5 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots; 4: s2s_logmel_parakeet_cached; 5: s2s_tts_set_trailing */
 
 /* element types of device buffers */
 #define S2S_F32 0
@@ -405,6 +405,14 @@ int32_t s2s_tts_generate(void* model, void* stream, int32_t n_frames, int32_t mi
 int32_t s2s_tts_admit(void* model, void* stream, const float* prompt_embeds_dev, const int32_t* prompt_len_dev, int32_t n, int32_t Tp,
                       int32_t slot0, const int32_t* min_frames_dev, const int32_t* budget_dev, int32_t min_frames, int32_t max_new_frames,
                       int32_t utterance_id0);
+/* Streaming-text mode (ABI v5; reference `non_streaming_mode = False`, arguments_classes/qwen3_tts_arguments.py:103-108: the text is NOT fully
+ * pre-filled): for the sessions just admitted into the slots [slot0, slot0 + n) the prompt handed to s2s_tts_admit / s2s_tts_prefill ends with the
+ * FIRST text token; the remaining text rows and the text-side eos row are given here and consumed one per generated frame - the input of the
+ * step that produces frame f + 1 is the sum of frame f's code embeddings + trailing row f, and `talker.pad_embed` once they are used up
+ * (the talker of the architectural sibling, modeling_qwen3_omni_moe.py:3744-3801 prompt split, :3169-3174 per-step rule).
+ * rows_dev f32 [n][Tr][t_hidden] (right-padded), n_rows_dev int32[n], 1 <= Tr <= max_prompt.  Admission resets a slot to the pre-filled-text mode
+ * (no trailing rows), so call this after the admission and before the next s2s_tts_step; s2s_tts_migrate carries the rows along. */
+int32_t s2s_tts_set_trailing(void* model, void* stream, int32_t slot0, int32_t n, const float* rows_dev, const int32_t* n_rows_dev, int32_t Tr);
 int32_t s2s_tts_step(void* model, void* stream, int32_t rows, int32_t n_frames);
 int32_t s2s_tts_read_codes(void* model, void* stream, int32_t slot0, int32_t n, int32_t frame0, int32_t n_frames, int32_t* codes_dev,
                            int32_t* n_frames_dev, int32_t chunk_samples, int32_t* valid_samples_dev);

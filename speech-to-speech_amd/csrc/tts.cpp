@@ -29,7 +29,8 @@ int add_int(hipStream_t st, int* p, int v, int n);
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_b, const int* min_b, const int* utt_b, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
-                const PickDebug& dbg, const SampleParams& sp);
+                const PickDebug& dbg, const SampleParams& sp, const void* trail, const int* n_trail, int max_trail);
+int trail_set(hipStream_t st, const float* rows, const int* n_rows, int n, int Tr, int E, void* trail, int* n_trail, int max_trail, int slot0, int dtype);
 int pred_pick(hipStream_t st, const float* logits, int V, long logits_rs, const int* frame_b, const int* utt_b, const int* finished, int* codes_out, int max_frames, int G,
               int g, const void* emb, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype, const PickDebug& dbg,
               const SampleParams& sp);
@@ -104,6 +105,9 @@ struct Tts {
     // per-SLOT frame state (device): frame index, eos gate threshold, frame budget, utterance id (sampler key).  A slot is one row of
     // the frame loop; sessions are admitted into / released from slots while the others keep generating (s2s_tts_admit / _release)
     int *frame_b = nullptr, *min_b = nullptr, *budget_b = nullptr, *utt_b = nullptr;
+    // streaming-text mode (s2s_tts_set_trailing): per slot the text rows that were NOT pre-filled, consumed one per frame in place of pad_embed
+    void* trail = nullptr;             // [B][max_prompt][E] model dtype
+    int* n_trail = nullptr;            // [B] rows valid per slot (0: every frame adds pad_embed - the pre-filled-text mode)
     int next_utt = 1;                  // utterance ids handed out by the legacy prefill
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> frame_graphs;
@@ -276,6 +280,8 @@ static int finalize(Tts* m) {
     T(B * act_elems * e);                      // 23 ca
     T(B * act_elems * e);                      // 24 cb
     T(B * act_elems * e);                      // 25 cc
+    T(B * (size_t)c.max_prompt * E * e);       // 26 trail (streaming-text rows per slot)
+    T(B * 4 + 64);                             // 27 n_trail
     m->arena_bytes = a.off;
     if ((rc = a.commit(&m->arena, "tts"))) return rc;
     char* b0 = m->arena;
@@ -292,6 +298,8 @@ static int finalize(Tts* m) {
     m->pred.kc = b0 + o[18]; m->pred.vc = b0 + o[19];
     m->codec.kc = b0 + o[20]; m->codec.vc = b0 + o[21];
     m->cx = (float*)(b0 + o[22]); m->ca = b0 + o[23]; m->cb_ = b0 + o[24]; m->cc = b0 + o[25];
+    m->trail = b0 + o[26]; m->n_trail = (int*)(b0 + o[27]);
+    S2S_HIP_CHECK(hipMemset(m->n_trail, 0, sizeof(int) * B));
     // suppress mask: every codec special token except eos can never be emitted as codebook-0
     std::vector<unsigned char> sup(c.codec_vocab, 0);
     for (int i = c.codebook; i < c.codec_vocab; ++i) sup[i] = (i == c.codec_eos) ? 0 : 1;
@@ -543,7 +551,8 @@ static int talker_head(Tts* m, hipStream_t st, int B) {
     // x's hidden rows are consumed (hn); the pick writes the next talker input over them
     return talker_pick(st, m->logits, c.codec_vocab, m->sup_mask, (const unsigned char*)TP(m, "talker.eos_mask"), c.codec_eos, m->frame_b,
                        m->min_b, m->utt_b, m->code0, m->finished, m->n_frames, m->codes_out, c.max_frames, c.n_groups, TP(m, "talker.emb"),
-                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg, m->sp_talker);
+                       TP(m, "talker.pad_embed"), m->hn, m->x, m->pin, m->pin_t, E, dec_fusion_ok(m, m->pred, 2 * B) && c.p_hidden != E, B, dt, m->dbg, m->sp_talker,
+                       m->trail, m->n_trail, c.max_prompt);
 }
 
 // run the code predictor for the current frame; the residual groups' embeddings accumulate into the next talker input (m->x)
@@ -723,6 +732,7 @@ static int tts_admit_impl(Tts* m, hipStream_t st, const float* prompt_embeds_dev
     S2S_HIP_CHECK(hipMemcpyAsync(m->xnext, m->x, sizeof(float) * (size_t)m->max_batch * E, hipMemcpyDeviceToDevice, st));
     S2S_HIP_CHECK(hipMemcpyAsync(m->x, prompt_embeds_dev, sizeof(float) * (size_t)n * Tp * E, hipMemcpyDeviceToDevice, st));
     S2S_HIP_CHECK(hipMemsetAsync(m->codes_out + (size_t)slot0 * c.max_frames * G, 0xff, sizeof(int) * (size_t)n * c.max_frames * G, st));
+    S2S_HIP_CHECK(hipMemsetAsync(m->n_trail + slot0, 0, sizeof(int) * (size_t)n, st));      // pre-filled-text mode until s2s_tts_set_trailing says otherwise
     // the same stack, its cache rows shifted to the first admitted slot (row b of the prefill batch = slot slot0 + b)
     Stack pre = m->talker;
     const size_t slot_bytes = (size_t)pre.c.max_pos * pre.c.kv_heads * pre.c.head_dim * e;
@@ -779,6 +789,20 @@ extern "C" int32_t s2s_tts_admit(void* model, void* stream, const float* prompt_
                           utterance_id0);
 }
 
+/* Streaming-text mode of the sessions just admitted into the slots [slot0, slot0 + n) (reference `non_streaming_mode = False`,
+ * arguments_classes/qwen3_tts_arguments.py:103-108; sibling modeling_qwen3_omni_moe.py:3744-3801,3169-3174): the prompt that was pre-filled ends
+ * with the FIRST text token, the remaining text rows (and the text-side eos row) arrive one per generated frame - the input of the step that
+ * produces frame f + 1 is the sum of frame f's code embeddings + trailing row f, and pad_embed once the rows are used up.
+ * rows_dev f32 [n][Tr][E] (right-padded), n_rows_dev int32[n] (<= Tr <= max_prompt).  Call after s2s_tts_admit / s2s_tts_prefill (which reset
+ * the slots to the pre-filled-text mode) and before the next s2s_tts_step. */
+extern "C" int32_t s2s_tts_set_trailing(void* model, void* stream, int32_t slot0, int32_t n, const float* rows_dev, const int32_t* n_rows_dev, int32_t Tr) {
+    Tts* m = (Tts*)model;
+    S2S_REQUIRE(m && m->finalized, "tts_set_trailing: model not finalized");
+    S2S_REQUIRE(n > 0 && slot0 >= 0 && slot0 + n <= m->max_batch && rows_dev && n_rows_dev && Tr >= 1 && Tr <= m->cfg.max_prompt,
+                "tts_set_trailing: bad arguments (slots %d..%d of %d, %d rows, at most %d)", slot0, slot0 + n, m->max_batch, Tr, m->cfg.max_prompt);
+    return trail_set((hipStream_t)stream, rows_dev, n_rows_dev, n, Tr, m->cfg.t_hidden, m->trail, m->n_trail, m->cfg.max_prompt, slot0, m->cfg.dtype);
+}
+
 /* Move n live sessions from the slots [src_slot0, ..) of ONE engine into the slots [dst_slot0, ..) of ANOTHER engine of the same model
  * (replicas sharing the weights; same max_prompt / max_frames): everything a slot owns - the talker cache rows of its first n_pos
  * positions, its next input row, frame index / eos gate / budget / sampler key, the codes emitted so far, the codec decoder's history rows
@@ -792,7 +816,7 @@ extern "C" int32_t s2s_tts_migrate(void* dst_model, void* src_model, void* strea
     S2S_REQUIRE(d && s && d != s && d->finalized && s->finalized, "tts_migrate: two finalized engines");
     const auto &a = d->cfg, &b = s->cfg;
     S2S_REQUIRE(a.dtype == b.dtype && a.t_hidden == b.t_hidden && a.t_layers == b.t_layers && a.t_kv_heads == b.t_kv_heads && a.t_head_dim == b.t_head_dim &&
-                    a.max_pos == b.max_pos && a.max_frames == b.max_frames && a.n_groups == b.n_groups && a.c_hidden == b.c_hidden && a.c_layers == b.c_layers &&
+                    a.max_pos == b.max_pos && a.max_prompt == b.max_prompt && a.max_frames == b.max_frames && a.n_groups == b.n_groups && a.c_hidden == b.c_hidden && a.c_layers == b.c_layers &&
                     a.c_heads == b.c_heads && a.c_decoder_dim == b.c_decoder_dim && a.n_dec_blocks == b.n_dec_blocks && d->codec.c.max_pos == s->codec.c.max_pos,
                 "tts_migrate: the engines must be replicas of one model with the same max_prompt / max_frames");
     S2S_REQUIRE(n > 0 && src_slot0 >= 0 && src_slot0 + n <= s->max_batch && dst_slot0 >= 0 && dst_slot0 + n <= d->max_batch && n_pos >= 0 && n_pos <= a.max_pos &&
@@ -824,6 +848,12 @@ extern "C" int32_t s2s_tts_migrate(void* dst_model, void* src_model, void* strea
     int* const dsti[] = {d->pos_t, d->frame_b, d->min_b, d->budget_b, d->utt_b, d->n_frames, d->code0};
     int* const srci[] = {s->pos_t, s->frame_b, s->min_b, s->budget_b, s->utt_b, s->n_frames, s->code0};
     for (int k = 0; k < 7; ++k) S2S_HIP_CHECK(hipMemcpyAsync(dsti[k] + dst_slot0, srci[k] + src_slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    // streaming-text rows still to be consumed travel with the session (both engines: same max_prompt)
+    S2S_HIP_CHECK(hipMemcpyAsync(d->n_trail + dst_slot0, s->n_trail + src_slot0, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    {
+        const size_t tb = (size_t)a.max_prompt * E * e;
+        S2S_HIP_CHECK(hipMemcpyAsync((char*)d->trail + dst_slot0 * tb, (const char*)s->trail + src_slot0 * tb, tb * n, hipMemcpyDeviceToDevice, st));
+    }
     S2S_HIP_CHECK(hipMemsetAsync(d->finished + dst_slot0, 0, sizeof(int) * n, st));       // live in the destination (the source parks its slots as finished)
     const size_t cw = (size_t)a.max_frames * a.n_groups;
     S2S_HIP_CHECK(hipMemcpyAsync(d->codes_out + dst_slot0 * cw, s->codes_out + src_slot0 * cw, sizeof(int) * cw * n, hipMemcpyDeviceToDevice, st));

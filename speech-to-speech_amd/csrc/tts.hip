@@ -344,6 +344,8 @@ __device__ int block_sample_256(const float* __restrict__ row, int V, const unsi
 // Talker pick (one block per session): code 0 = argmax over the codec vocabulary (specials suppressed; eos too while
 // frame < min_frames), eos / frame bookkeeping, then the inputs that depend on it:
 //   xnext[b] = talker_emb[code0] + pad_embed          (next talker input, residual-group embeddings are added later)
+//              ... + trail[b][frame] instead of pad_embed while frame < n_trail[b]: streaming-text mode (the reference's
+//              non_streaming_mode = False; sibling modeling_qwen3_omni_moe.py:3169-3174: the text that was not pre-filled arrives one row per frame)
 //   pin[b][0] = hn[b], pin[b][1] = talker_emb[code0]  (code predictor prefill rows; f32 and model-dtype copies)
 template <typename T>
 __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restrict__ logits, int V, const unsigned char* __restrict__ sup_mask,
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
                                                           int* __restrict__ codes_out, int max_frames, int G,
                                                           const T* __restrict__ emb, const T* __restrict__ pad, const float* __restrict__ hn,
                                                           float* __restrict__ xnext, float* __restrict__ pin, T* __restrict__ pin_t, int E,
-                                                          int pin_frag, PickDebug dbg, SampleParams sp) {
+                                                          int pin_frag, PickDebug dbg, SampleParams sp, const T* __restrict__ trail,
+                                                          const int* __restrict__ n_trail, int max_trail) {
     const int b = blockIdx.x;
     const int frame = frame_b[b];       // this SLOT's frame index: sessions admitted at different times share the launch
     const bool gate = frame < min_b[b];
@@ -377,10 +380,11 @@ __global__ __launch_bounds__(256) void talker_pick_kernel(const float* __restric
         }
     }
     const T* row = emb + (long)code * E;
+    const T* text = (trail && frame < n_trail[b]) ? trail + ((long)b * max_trail + frame) * E : pad;      // the text-side row of the next input
     for (int i = threadIdx.x; i < E; i += 256) {
         const float e = Elem<T>::ld(row + i);
         const float h = hn[(long)b * E + i];
-        xnext[(long)b * E + i] = e + Elem<T>::ld(pad + i);
+        xnext[(long)b * E + i] = e + Elem<T>::ld(text + i);
         pin[((long)b * 2) * E + i] = h;
         pin[((long)b * 2 + 1) * E + i] = e;
         Elem<T>::st(pin_t + (pin_frag ? frag_index_d(b * 2, i, E >> 5) : ((long)b * 2) * E + i), h);
@@ -464,12 +468,28 @@ __global__ void tts_read_codes_kernel(const int* __restrict__ codes_out, int max
 int talker_pick(hipStream_t st, const float* logits, int V, const unsigned char* sup_mask, const unsigned char* eos_mask, int eos,
                 const int* frame_b, const int* min_b, const int* utt_b, int* code0, int* finished, int* n_frames, int* codes_out, int max_frames, int G,
                 const void* emb, const void* pad, const float* hn, float* xnext, float* pin, void* pin_t, int E, bool pin_frag, int B, int dtype,
-                const PickDebug& dbg, const SampleParams& sp) {
+                const PickDebug& dbg, const SampleParams& sp, const void* trail, const int* n_trail, int max_trail) {
     S2S_REQUIRE(sp.temperature <= 0.f || V <= 4096, "talker_pick: sampling supports vocabularies up to 4096 entries");
     const size_t lds = sp.temperature > 0.f ? sizeof(float) * (V + 8) : 0;
     S2S_DT(TT, (talker_pick_kernel<TT><<<B, 256, lds, st>>>(logits, V, sup_mask, eos_mask, eos, frame_b, min_b, utt_b, code0, finished, n_frames,
                                                            codes_out, max_frames, G, (const TT*)emb, (const TT*)pad, hn, xnext, pin, (TT*)pin_t, E,
-                                                           pin_frag ? 1 : 0, dbg, sp)));
+                                                           pin_frag ? 1 : 0, dbg, sp, (const TT*)trail, n_trail, max_trail)));
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// trailing text rows of n admitted sessions: rows f32 [n][Tr][E] -> trail[slot0 + i][0 .. Tr) in the model dtype, n_trail[slot0 + i] = n_rows[i]
+template <typename T>
+__global__ void trail_set_kernel(const float* __restrict__ rows, const int* __restrict__ n_rows, int Tr, int E, T* __restrict__ trail, int* __restrict__ n_trail,
+                                 int max_trail, int slot0) {
+    const int i = blockIdx.y, t = blockIdx.x;
+    const int nr = min(n_rows[i], min(Tr, max_trail));
+    if (t == 0 && threadIdx.x == 0) n_trail[slot0 + i] = nr;
+    if (t >= nr) return;
+    for (int k = threadIdx.x; k < E; k += blockDim.x) Elem<T>::st(trail + ((long)(slot0 + i) * max_trail + t) * E + k, rows[((long)i * Tr + t) * E + k]);
+}
+int trail_set(hipStream_t st, const float* rows, const int* n_rows, int n, int Tr, int E, void* trail, int* n_trail, int max_trail, int slot0, int dtype) {
+    S2S_DT(TT, (trail_set_kernel<TT><<<dim3(Tr, n), 256, 0, st>>>(rows, n_rows, Tr, E, (TT*)trail, n_trail, max_trail, slot0)));
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

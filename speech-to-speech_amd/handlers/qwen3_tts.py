@@ -185,11 +185,11 @@ class MI355XQwen3TTSHandler(BaseHandler):
         self.should_listen = should_listen          # owned by the reference runtime; never touched here
         self.model_name = model_name
         self.ref_audio, self.ref_spk, self.ref_rvq, self.ref_text, self.xvec_only = ref_audio, ref_spk, ref_rvq, ref_text, bool(xvec_only)
-        # non_streaming_mode (reference arguments :103-108: "pre-fill the full target text before decode") is the only mode this engine
-        # has - the whole text is in the prefill; False cannot be honoured and is said so once
-        if non_streaming_mode is False:
-            logger.warning("mi355x-qwen3 always pre-fills the full text (non_streaming_mode=True); ignoring non_streaming_mode=False")
-        self.non_streaming_mode = True
+        # non_streaming_mode (reference arguments :103-108): True (the reference's default) pre-fills the full target text before decode; False =
+        # streaming-text mode: the prefill ends with the first text token and the rest of the text reaches the talker one row per frame
+        # (engine: TTSPrompt.trailing -> s2s_tts_set_trailing; the split and the per-step rule are the architectural sibling's,
+        # modeling_qwen3_omni_moe.py:3744-3801,3169-3174 - the pinned backend's own layout is not available offline)
+        self.non_streaming_mode = True if non_streaming_mode is None else bool(non_streaming_mode)
         self._model_type_override = model_type
         self.cancel_scope, self.speculative_turns = cancel_scope, speculative_turns
         self.streaming_chunk_size, self.max_new_tokens, self.blocksize = int(streaming_chunk_size), int(max_new_tokens), int(blocksize)
@@ -412,6 +412,9 @@ class MI355XQwen3TTSHandler(BaseHandler):
             else:
                 raise ValueError("Qwen3-TTS Base model requires a voice-clone reference. Provide qwen3_tts_ref_audio or qwen3_tts_ref_spk, "
                                  "or use a CustomVoice/VoiceDesign model.")
+        if not getattr(self, "non_streaming_mode", True):
+            rows, trailing = fe.embed(text, eng.max_prompt, streaming=True, **kw)
+            return TTSPrompt(rows, trailing)
         return TTSPrompt(fe.embed(text, eng.max_prompt, **kw))
 
     def _build_prompts(self, text: str) -> list[tuple[str, TTSPrompt]]:

@@ -118,6 +118,7 @@ _SIGNATURES = {
     "s2s_codec_decode_rows_at": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32],
     "s2s_op_sample_tokens": [_vp, _vp, _i32, _i32, _f32, _i32, _f32, _f32, C.c_uint64, _vp, _i32, _vp],
     "s2s_tts_set_sampling": [_vp, _i32, _f32, _i32, _f32, _f32, C.c_uint64],
+    "s2s_tts_set_trailing": [_vp, _vp, _i32, _i32, _vp, _vp, _i32],
     "s2s_tts_generate_forced": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "s2s_codec_decode": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32],
     "s2s_codec_samples": [_vp, _i32],

@@ -280,7 +280,7 @@ class TableTextFrontend:
         return rows.astype(np.float32)
 
     def embed(self, text: str, max_tokens: int, speaker: str | None = None, language: str | None = None, instruct: str | None = None,
-              speaker_row: np.ndarray | None = None, ref_text: str | None = None, ref_rows: np.ndarray | None = None) -> np.ndarray:
+              speaker_row: np.ndarray | None = None, ref_text: str | None = None, ref_rows: np.ndarray | None = None, streaming: bool = False):
         """Prefill rows, row i = text_side[i] + codec_side[i] (TTSPromptLayout):
             [codec control rows: codec_prefix, then the language token and the speaker token when given - or `speaker_row`, an explicit
              speaker embedding (voice clone: the x-vector projected to the talker width) in the speaker token's place; text side = text_pad]
@@ -289,7 +289,10 @@ class TableTextFrontend:
             [codec_bos row; text side = text_pad]
             [reference codec frames (voice clone in-context rows, `code_rows`); text side = text_pad]
         An unknown speaker / language name is an error (never a silent default voice).  The control-row order and the in-context
-        placement are this repo's assumption about the absent qwen_tts prompt builder."""
+        placement are this repo's assumption about the absent qwen_tts prompt builder.
+        streaming = True (reference non_streaming_mode = False): -> (prefill rows, trailing rows) - the text block of the prefill ends with the
+        FIRST text token, the remaining text rows and text_eos are the trailing rows the frame loop consumes one per frame (the split of the
+        sibling's talker, modeling_qwen3_omni_moe.py:3744-3801: "First text" in the prefill, `trailing_text_hidden` = the rest + eos)."""
         lay = self.layout
         ctrl = list(lay.codec_prefix)
         if language and language != "auto":
@@ -313,10 +316,15 @@ class TableTextFrontend:
             from .text import PromptTooLong
 
             raise PromptTooLong(f"TTS input of {len(ids)} text tokens exceeds the prompt budget of {budget}; split the text into shorter sentences")
+        n_text = len(ids)
         ids = ([lay.text_bos] if lay.text_bos is not None else []) + ids + ([lay.text_eos] if lay.text_eos is not None else [])
         rows = self._text_rows(ins + ids)
+        trailing = None
+        if streaming:
+            k = len(ins) + (lay.text_bos is not None) + min(1, n_text)
+            rows, trailing = rows[:k], rows[k:].astype(np.float32)
         if not ctrl and not tail and speaker_row is None and not n_ref:
-            return rows
+            return (rows, trailing) if streaming else rows
         E = rows.shape[1]
         pad = self._text_rows([lay.text_pad])[0] if lay.text_pad is not None else np.zeros(E, np.float32)
         if (ctrl or tail) and self.codec_table.shape[1] != E:
@@ -329,4 +337,5 @@ class TableTextFrontend:
             head = np.concatenate([head, (sr + pad)[None]])
         foot = self.codec_table[np.asarray(tail, dtype=np.int64)] + pad if tail else np.zeros((0, E), np.float32)
         ref = (np.asarray(ref_rows, np.float32).reshape(-1, E) + pad) if n_ref else np.zeros((0, E), np.float32)
-        return np.concatenate([head, rows, foot, ref]).astype(np.float32)
+        full = np.concatenate([head, rows, foot, ref]).astype(np.float32)
+        return (full, trailing) if streaming else full

@@ -176,7 +176,7 @@ class ByteTextFrontend:
         self.table = table.astype(np.float32)
 
     def embed(self, text: str, max_tokens: int, instruct: str | None = None, speaker_row: np.ndarray | None = None, ref_text: str | None = None,
-              ref_rows: np.ndarray | None = None) -> np.ndarray:
+              ref_rows: np.ndarray | None = None, streaming: bool = False):
         """[speaker row] [bos instruct eos] [bos (ref_text) text eos] [reference code rows] - the synthetic stand-in of the voice modes'
         prompt (voice design: instruct; voice clone: speaker row, reference text and, unless x-vector only, reference code rows)."""
         raw = list(((ref_text.strip() + " ") if ref_text else "").encode("utf-8")) + list(text.encode("utf-8"))
@@ -190,4 +190,9 @@ class ByteTextFrontend:
         E = rows.shape[1]
         head = np.asarray(speaker_row, np.float32).reshape(1, E) if speaker_row is not None else np.zeros((0, E), np.float32)
         tail = np.asarray(ref_rows, np.float32).reshape(-1, E) if ref_rows is not None else np.zeros((0, E), np.float32)
+        if streaming:
+            # streaming-text mode (reference non_streaming_mode = False): the prefill ends with the FIRST text token, the rest of the text and the
+            # eos row are handed to the frame loop one row per frame (-> (prefill rows, trailing rows); sibling modeling_qwen3_omni_moe.py:3744-3801)
+            k = len(ins) + 1 + min(1, len(raw))
+            return np.concatenate([head, rows[:k], tail]).astype(np.float32), rows[k:].astype(np.float32)
         return np.concatenate([head, rows, tail]) if len(head) or len(tail) else rows

@@ -21,7 +21,7 @@ WEIGHT LAYOUT handed to ``s2s_tts_set_tensor`` (``W`` = model dtype; norms / bia
 Prompt layout: the real Qwen3-TTS chat template / speaker table / language tags live in the unavailable qwen_tts
 package (SURVEY.md 8a'); prompts are therefore assembled from explicit (text-side, codec-side) embedding rows behind
 ``TTSPrompt`` and exercised with synthetic prompts.  ``non_streaming_mode=True`` semantics: the whole text is prefilled,
-every generated frame adds ``tts_pad_embed``.
+every generated frame adds ``tts_pad_embed``; ``False`` (streaming text): ``TTSPrompt.trailing`` rows replace the pad row frame by frame.
 """
 
 from __future__ import annotations
@@ -236,9 +236,13 @@ def resample_fir_2_3(dtype=np.float32) -> np.ndarray:
 
 @dataclass
 class TTSPrompt:
-    """Prefill rows of one utterance: float32 [P, t_hidden] (text-side + codec-side embeddings already summed)."""
+    """Prefill rows of one utterance: float32 [P, t_hidden] (text-side + codec-side embeddings already summed).
+    `trailing` (optional, float32 [n, t_hidden]): streaming-text mode - the text rows that are NOT pre-filled (the prompt then ends with the
+    first text token); the frame loop adds row f to the input of the step that produces frame f + 1 and `pad_embed` afterwards
+    (reference `non_streaming_mode = False`; C ABI s2s_tts_set_trailing)."""
 
     embeds: np.ndarray
+    trailing: np.ndarray | None = None
 
 
 class AudioBlocker:
@@ -364,6 +368,27 @@ class TTSEngine:
             native.check(self._lib.s2s_tts_prefill(self._h, native.stream_handle(), native.ptr(emb), native.ptr(ln), B, Tp), "s2s_tts_prefill")
         self._B = B
         self._keep = (emb, ln)
+        self._set_trailing(prompts, 0)
+
+    def _set_trailing(self, prompts: Sequence[TTSPrompt], slot0: int) -> None:
+        """Streaming-text rows of the prompts just admitted into the slots [slot0, ...): one call for the group (sessions without rows get 0)."""
+        rows = [None if p.trailing is None or len(p.trailing) == 0 else np.ascontiguousarray(p.trailing, dtype=np.float32) for p in prompts]
+        if all(r is None for r in rows):
+            return
+        E = self.dims.t_hidden
+        Tr = max(r.shape[0] for r in rows if r is not None)
+        if Tr > self.max_prompt:
+            raise ValueError(f"{Tr} trailing text rows exceed the engine's max_prompt {self.max_prompt}")
+        host = torch.zeros((len(prompts), Tr, E), dtype=torch.float32)
+        for i, r in enumerate(rows):
+            if r is not None:
+                host[i, : r.shape[0]] = torch.from_numpy(r)
+        dev_rows = host.to(self.device)
+        n_rows = torch.tensor([0 if r is None else r.shape[0] for r in rows], dtype=torch.int32).to(self.device)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.s2s_tts_set_trailing(self._h, native.stream_handle(), int(slot0), len(prompts), native.ptr(dev_rows), native.ptr(n_rows), Tr),
+                         "s2s_tts_set_trailing")
+        self._keep_trailing = (dev_rows, n_rows)
 
     def generate(self, n_frames: int, min_total_frames: int = 0, check_done: bool = True):
         """-> (codes int32 [B][n_frames][G] on the GPU, valid frames so far per session (numpy), all_done)."""
@@ -422,6 +447,7 @@ class TTSEngine:
                                                  int(utterance_id0)), "s2s_tts_admit")
         self._B = max(self._B, slot0 + n)
         self._keep_admit = (emb, ln, mn, bd)
+        self._set_trailing(prompts, slot0)
 
     ADMIT_GROUP = 64                 # most prompts per s2s_tts_admit call (bounds the pinned staging ring: 2 x 64 x max_prompt x E floats)
 

@@ -10,7 +10,7 @@ from speech_to_speech_amd import native
 
 def test_library_loads_and_reports_version():
     lib = native.load()
-    assert lib.s2s_abi_version() == 4
+    assert lib.s2s_abi_version() == 5
     assert lib.s2s_device_count() >= 0
 
 

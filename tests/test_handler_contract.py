@@ -56,6 +56,7 @@ class FakeTTS:
 
     def stream(self, prompts, max_new_tokens, chunk_size=8, ctx_frames=25, min_frames=0):
         self.prompts.extend(p.embeds for p in prompts)
+        self.trailing = getattr(self, "trailing", []) + [p.trailing for p in prompts]
         yield [np.full(1100, 4000, np.int16) for _ in prompts]
 
     def close(self):
@@ -117,6 +118,35 @@ def test_voice_design_uses_instruct_and_no_speaker_row(pool):
     h = _tts(pool, fe, instruct="a calm low voice")
     assert list(h.process(TTSInput(text="Hello there.")))
     assert np.array_equal(pool.engine("tts").prompts[0], fe.embed("Hello there.", 96, instruct="a calm low voice"))
+
+
+def test_streaming_text_mode_prefills_up_to_the_first_text_token_and_trails_the_rest(pool):
+    """Reference arguments `qwen3_tts_non_streaming_mode = False` (:103-108): the prefill ends with the first text token (then the rows that
+    follow the text block: codec_bos), the remaining text rows + text_eos are handed to the engine as trailing rows, one per frame.
+    Prefill text rows + trailing rows = the text block of the non-streaming prompt, in order, nothing lost or duplicated."""
+    fe = _layout_frontend("custom_voice", {"vivian": 8})
+    text = "Hello there."
+    h = _tts(pool, fe, speaker="vivian", language="en", instruct="calm", non_streaming_mode=False)
+    assert list(h.process(TTSInput(text=text)))
+    eng = pool.engine("tts")
+    rows, trail = eng.prompts[0], eng.trailing[0]
+    full = fe.embed(text, 96, speaker="vivian", language="english", instruct="calm")
+    n_head, n_ins = 3, len("calm")
+    k = n_head + n_ins + 2                                  # control rows, instruct, text_bos, FIRST text token
+    assert trail.dtype == np.float32 and len(trail) == len(text) - 1 + 1          # the rest of the text + text_eos
+    assert len(rows) == k + 1 and len(rows) + len(trail) == len(full)
+    assert np.array_equal(rows[:k], full[:k]) and np.array_equal(rows[k], full[-1])          # ... then the codec_bos row
+    assert np.array_equal(trail, full[k:-1])               # text rows carry no codec side: the trailing rows are the prompt's own
+    # the default (None / True) still pre-fills the whole text and hands over no trailing rows
+    h2 = _tts(pool, fe, speaker="vivian", language="en", non_streaming_mode=True)
+    assert list(h2.process(TTSInput(text=text)))
+    assert eng.trailing[-1] is None and np.array_equal(eng.prompts[-1], fe.embed(text, 96, speaker="vivian", language="english"))
+    # byte frontend (synthetic models): same split; a one-token text trails only the eos row
+    bfe = ByteTextFrontend(np.arange(258 * 4, dtype=np.float32).reshape(258, 4))
+    pre, tr = bfe.embed("abc", 32, streaming=True)
+    assert np.array_equal(np.concatenate([pre, tr]), bfe.embed("abc", 32)) and len(pre) == 2 and len(tr) == 3
+    pre, tr = bfe.embed("a", 32, streaming=True)
+    assert len(pre) == 2 and len(tr) == 1 and np.array_equal(tr[0], bfe.embed("a", 32)[-1])
 
 
 def test_base_model_without_reference_yields_no_audio_and_says_why(pool, caplog):

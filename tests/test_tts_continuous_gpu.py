@@ -252,3 +252,50 @@ def test_first_chunk_in_a_nursery_loop_then_migration_is_exact(world):
         assert d.max() <= 2, f"session {i}: audio differs from its solo stream (max diff {d.max()})"
     neng.close()
     main.close()
+
+
+def test_streaming_text_rows_follow_a_session_through_the_nursery_and_the_migration(world):
+    """Streaming-text mode (reference non_streaming_mode = False, s2s_tts_set_trailing) under continuous batching: a session's trailing text
+    rows are consumed by frame index wherever the session runs - first chunk in the nursery, the rest after s2s_tts_migrate in another slot of
+    the wide loop - and a slot reused by a session WITHOUT rows is back in the pre-filled mode.  Codes bit-exact vs the oracle run alone."""
+    dims, sd, prompts, budgets, pad, ref_codes = world
+    g = torch.Generator().manual_seed(23)
+    trails = {0: torch.randn(10, dims.t_hidden, generator=g), 2: torch.randn(2, dims.t_hidden, generator=g), 4: torch.randn(7, dims.t_hidden, generator=g)}
+    sup = [i for i in range(dims.codebook, dims.codec_vocab) if i != dims.codec_eos]
+    want = []
+    with torch.no_grad():
+        for i in range(5):
+            if i not in trails:
+                want.append(ref_codes[i])
+                continue
+            t = torch.cat([trails[i], pad[None].expand(budgets[i], -1)])[None]
+            c, _ = OT.talker_generate(sd, dims.talker_cfg(), dims.predictor_cfg(), prompts[i][None], dims.n_groups, budgets[i], dims.codec_eos, suppress=sup,
+                                      trailing=t, pad_embed=pad, min_frames=budgets[i])
+            want.append(c[0].numpy())
+            assert not np.array_equal(want[i], ref_codes[i])
+    main = TTSEngine(dims, sd, dtype=torch.float32, max_batch=8, max_prompt=16, max_frames=16, max_codec_frames=8, pad_embed=pad)
+    neng = main.replica(max_batch=2)
+    cb, nb = ContinuousTTS(main, chunk_size=CHUNK), NurseryTTS(neng, chunk_size=CHUNK)
+    cb.record_codes = nb.record_codes = True
+    assert cb._take(1) == (0, 1)
+    jobs = [TTSJob(TTSPrompt(prompts[i].numpy(), trails[i].numpy() if i in trails else None), budgets[i], min_frames=budgets[i]) for i in range(5)]
+    sink, ended = {}, {}
+    pending = list(jobs)
+    left = []
+    while pending or nb.live or cb.live or left:
+        if pending and nb.free_slots:
+            n = min(nb.free_slots, len(pending))          # nursery slots are reused: 0 (rows), 1 (none) -> 2 (rows), 3 (none) -> 4 (rows)
+            assert nb.admit(pending[:n]) == []
+            pending = pending[n:]
+        if nb.live:
+            _collect(nb.step(), sink, ended)
+        left = cb.adopt(left + nb.take_graduates(), nb)
+        nb.reclaim()
+        if cb.live:
+            _collect(cb.step(), sink, ended)
+    assert all(ended.get(id(j)) for j in jobs)
+    for i, j in enumerate(jobs):
+        got = np.concatenate(j.codes)[: budgets[i]]
+        assert np.array_equal(got, want[i]), f"session {i}: codes differ from the oracle run of that session alone"
+    neng.close()
+    main.close()

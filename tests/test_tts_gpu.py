@@ -164,3 +164,43 @@ def test_resample_and_blocking_match_reference_post_processing(ref):
         flat = np.concatenate(blocks)
         assert np.array_equal(flat[: len(y16[b]) - start], y16[b][start:])
     eng.close()
+
+
+def test_streaming_text_mode_codes_match_the_oracle(ref):
+    """Streaming-text mode (reference `non_streaming_mode = False`; C ABI s2s_tts_set_trailing, ABI v5): the prompt ends with the first text
+    token, the remaining text rows are added one per frame to the next talker input in place of `pad_embed` (sibling
+    modeling_qwen3_omni_moe.py:3169-3174).  float32 engine, ragged trailing lengths (12 rows > the 10 frames generated, 4 rows, none): every code
+    equals the oracle's `talker_generate(..., trailing=...)`; a slot admitted later WITHOUT rows into a slot that had them is back in the
+    pre-filled-text mode; continuous admission (s2s_tts_admit) carries the rows too."""
+    dims, sd, prompts, pad, n_frames, codes_plain, _ = ref
+    g = torch.Generator().manual_seed(11)
+    trails = [torch.randn(12, dims.t_hidden, generator=g), torch.randn(4, dims.t_hidden, generator=g), None]
+    sup = [i for i in range(dims.codebook, dims.codec_vocab) if i != dims.codec_eos]
+    want = []
+    with torch.no_grad():
+        for p, t in zip(prompts, trails):
+            c, _ = OT.talker_generate(sd, dims.talker_cfg(), dims.predictor_cfg(), p[None], dims.n_groups, n_frames, dims.codec_eos, suppress=sup,
+                                      trailing=None if t is None else torch.cat([t, pad[None].expand(n_frames, -1)])[None], pad_embed=pad, min_frames=n_frames)
+            want.append(c[0])
+    want = torch.stack(want)
+    assert not torch.equal(want[0], codes_plain[0]) and torch.equal(want[2], codes_plain[2])      # the rows change the stream; no rows = the plain mode
+    eng = _engine(ref, torch.float32)
+    mk = lambda: [TTSPrompt(p.numpy(), None if t is None else t.numpy()) for p, t in zip(prompts, trails)]      # noqa: E731
+    eng.prefill(mk())
+    got, _, _ = eng.generate(n_frames, min_total_frames=n_frames)
+    assert torch.equal(got.cpu().long(), want)
+    # the same slots again without rows: admission resets them to the pre-filled-text mode
+    eng.prefill([TTSPrompt(p.numpy()) for p in prompts])
+    got, _, _ = eng.generate(n_frames, min_total_frames=n_frames)
+    assert torch.equal(got.cpu().long(), codes_plain)
+    # continuous batching: session 1 (4 rows) joins slot 3 while slots 0 - 2 are live
+    eng.release(0, 4)
+    eng.admit(mk(), 0, 2 + n_frames, min_frames=n_frames)
+    eng.step(3, 2)
+    eng.admit([TTSPrompt(prompts[1].numpy(), trails[1].numpy())], 3, n_frames, min_frames=n_frames)
+    eng.step(4, n_frames)
+    late, _, _ = eng.read_codes(3, 1, 0, n_frames)
+    assert torch.equal(late.cpu().long()[0], want[1])
+    first, _, _ = eng.read_codes(0, 3, 0, n_frames)
+    assert torch.equal(first.cpu().long(), want)
+    eng.close()
