@@ -122,7 +122,8 @@ def parse(argv=None):
     ap.add_argument("--tts-nursery-slots", type=int, default=0, help="> 0: first chunks in a small eager frame loop of this many slots, continuation in the wide paced loop (SessionPool tts_nursery_slots)")
     ap.add_argument("--tts-nursery-priority", type=int, default=-1, choices=[0, -1], help="HIP stream priority of the nursery loop")
     ap.add_argument("--stt-stages", type=int, default=1, help="STT pipeline of the pool: 2 = encoder of batch k + 1 on one stream while the token loop of batch k runs on another (engine replicas); 1 = one stage")
-    ap.add_argument("--stt-workers", type=int, default=1, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe")
+    ap.add_argument("--stt-workers", type=int, default=None, help="STT workers (thread + stream + engine replica) of the pool in the open-loop probe (default: 3 for c5 - its live-partial "
+                    "passes are launch-bound and overlap, profiles/r06_open_loop_ab.txt -, else 1)")
     ap.add_argument("--gil-switch-ms", type=float, default=5.0, help="CPython thread switch interval during the open-loop probe (sys.setswitchinterval; CPython's default is 5 ms)")
     ap.add_argument("--max-probes", type=int, default=6, help="open-loop probes of the sustained-sessions bisection")
     ap.add_argument("--turn-batches", action="store_true", help="open-loop probe with round-2 turn-batch TTS lanes instead of continuous batching (A/B)")
@@ -760,6 +761,8 @@ def main():
     # of the queued sessions per pass (measured on C3: 549 sustained sessions with batches of up to 128 vs 416 with 64)
     if args.stt_max_batch is None:
         args.stt_max_batch = 64 if wl == "c5" else 32
+    if args.stt_workers is None:
+        args.stt_workers = 3 if wl == "c5" else 1
     MB = min(128, max(B, args.stt_max_batch, args.pool_max_batch or (128 if wl == "c3" else B)))      # STT engine rows (whisper.cpp / parakeet.cpp: <= 128)
     merge = max(1, int(args.tts_merge if args.tts_merge is not None else (4 if wl == "c3" and not args.serial else 1)))
     TMB = max(MB, merge * B, int(args.tts_slots or (512 if wl in ("c3", "c5") else B)))        # TTS engine slots (tts.cpp: <= 512); a PACED reply holds its slot for its whole duration
@@ -1121,7 +1124,7 @@ def main():
                           "p50_ttfa_ms": {"min": min(p50), "max": max(p50)} if p50 else None, "p95_ttfa_ms": {"min": min(p95), "max": max(p95)} if p95 else None}
             total = sum_over_ranks(mine)         # gloo, host scalar: the sum of the ranks' sustained session counts
             boundary = {"path": "pipeline units -> MI355X STT/TTS handlers (process()) -> SessionPool (batch window 4 ms, STT batches of up to "
-                                f"{args.stt_max_batch or MB} sessions, {lanes} TTS lane(s) x {TMB} slots, " + ("turn-batches" if args.turn_batches else
+                                f"{args.stt_max_batch or MB} sessions, {args.stt_workers} STT worker(s), {lanes} TTS lane(s) x {TMB} slots, " + ("turn-batches" if args.turn_batches else
                                 (f"first chunks in an eager {args.tts_nursery_slots}-slot nursery loop (high-priority stream), continuation after s2s_tts_migrate in the wide loop, whose rounds run when a session's audio lead < {args.tts_lead_s:g} s"
                                  if args.tts_nursery_slots > 0 else
                                  f"continuous batching at chunk boundaries, paced: a round runs when a session's audio lead < {args.tts_lead_s:g} s or a request has waited {args.tts_admit_wait_s * 1e3:g} ms")

@@ -184,7 +184,7 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
     def setup(self, model_name: str = "synthetic:test-tiny", device: str = "cuda:0", compute_type: str = "bfloat16", language: str | None = "en",
               max_batch: int = 64, batch_window_ms: float = 4.0, max_seconds: float = 30.0, enable_live_transcription: bool = False,
               live_transcription_update_interval: float = 0.5, gen_kwargs: dict | None = None, pool: SessionPool | None = None, batch_cap: int = 0,
-              language_detector: Any = "lingua", **_ignored: Any) -> None:
+              language_detector: Any = "lingua", stt_workers: int = 0, **_ignored: Any) -> None:
         # language state exactly as the reference keeps it (STT/parakeet_tdt_handler.py:150-156): a fixed start language is reported as is,
         # "auto" / None -> language ID on the transcript text, falling back to the last language seen
         self.start_language = language
@@ -202,6 +202,8 @@ class MI355XParakeetSTTHandler(BaseSTTHandler):
         if int(batch_cap) > 0:
             self.pool.configure(stt_max_batch=int(batch_cap))
         self.pool.ensure_engine("parakeet", lambda: build_parakeet_engine(model_name, device, compute_type, max_batch, max_seconds))
+        if int(stt_workers) > 1:               # STT workers of the pool (thread + stream + engine replica each; 3 measured best with live partials)
+            self.pool.ensure_stt_workers(int(stt_workers))
         self._live_model = PooledParakeetModel(self.pool, self.tokenizer, best_effort=True)
         self._windows: dict[Any, SentenceWindow] = {}
 

@@ -169,6 +169,12 @@ class ParakeetEngine:
         self.frontend = LogMelFrontend("parakeet", dims.n_mels, max_batch=self.max_batch, device=self.device)
         self._B = 0
 
+    def replica(self, max_batch: int | None = None) -> "ParakeetEngine":
+        """A second engine instance on the same GPU sharing this one's weight tensors (no copy of what was uploaded); it owns its workspace
+        (activations, TDT state, derived layouts) and front-end - one per extra STT worker of the session pool (SessionPool stt_workers)."""
+        return ParakeetEngine(self.dims, None, self.dtype, int(max_batch or self.max_batch), (self.max_feat_frames - 1) / 100.0, self.device,
+                              engine_tensors=self._weights)
+
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.s2s_parakeet_workspace_bytes(self._h))

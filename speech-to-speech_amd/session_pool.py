@@ -240,6 +240,22 @@ class SessionPool:
             t.start()
         self._ensure_lanes(self.tts_lanes)
 
+    def ensure_stt_workers(self, n: int) -> None:
+        """Grow the pool to `n` STT workers (a handler that knows its load asks for them after the pool exists: live Parakeet partials are
+        launch-bound passes, three workers overlap them - profiles/r06_open_loop_ab.txt).  Never shrinks; replicas of engines that already
+        exist are built here, not in serving time."""
+        with self._pools_lock:
+            old, n = self.stt_workers, max(1, int(n))
+            if n <= old:
+                return
+            self.stt_workers = n
+            new = [threading.Thread(target=self._run_stt_extra, args=(k,), name=f"s2s-pool-{self.device}-stt{k}", daemon=True) for k in range(old, n)]
+            self._stt_extra.extend(new)
+        for model in list(self._engines):
+            self._stt_extra_build(model)
+        for t in new:
+            t.start()
+
     def _ensure_lanes(self, n: int) -> None:
         while len(self._lanes) < max(1, n):
             i = len(self._lanes)

@@ -443,6 +443,40 @@ def test_extra_stt_workers_never_see_what_only_the_first_worker_serves():
         p.shutdown()
 
 
+def test_a_pool_grows_to_the_stt_workers_a_handler_asks_for():
+    """`ensure_stt_workers` (MI355XParakeetSTTHandler(stt_workers = 3): live partials): the pool starts the extra workers after it exists, builds
+    their replicas of the engines that are already there, never shrinks; while the first worker is stuck in a batch the others serve the queue."""
+    p = SessionPool("fake:grow", max_batch=4, batch_window_ms=1.0, tts_lanes=1)
+    try:
+        reps = []
+
+        class Rep(_GatedSTT):
+            def replica(self):
+                r = _GatedSTT()
+                r.gate.set()
+                reps.append(r)
+                return r
+
+        eng = Rep()
+        p._engines["rep"] = eng
+        assert p.stt_workers == 1 and p._stt_route(SimpleNamespace(model="rep", live=True)) is p._stt_pq
+        p.ensure_stt_workers(3)
+        p.ensure_stt_workers(2)
+        assert p.stt_workers == 3 and len(p._stt_extra) == 2 and len(reps) == 2 and all(t.is_alive() for t in p._stt_extra)
+        # requests until the FIRST worker holds one (its engine blocks on the gate); whatever the other workers took is answered at once
+        for k in range(1, 200):
+            threading.Thread(target=lambda k=k: p.transcribe("rep", _tagged(k)), daemon=True).start()
+            if eng.entered.wait(0.05):
+                break
+        assert eng.entered.is_set()
+        t = time.time()
+        assert [p.transcribe("rep", _tagged(k), live=True)["ids"] for k in (1002, 1003, 1004)] == [[1002], [1003], [1004]]
+        assert time.time() - t < 5.0 and not eng.gate.is_set()           # served by the replicas while the first worker is still stuck
+    finally:
+        eng.gate.set()
+        p.shutdown()
+
+
 def test_parakeet_partial_is_skipped_only_while_this_units_own_partial_runs():
     """Reference STT/parakeet_tdt_handler.py:264-295: `with self._compute_lock_context(timeout=0.01)` - the lock is the handler's own (:129).
     A deep POOL backlog (other units' work) does not skip a partial; a held lock of this unit does."""
