@@ -32,7 +32,7 @@ extern "C" {
 #define S2S_ERR_STATE (-3)
 #define S2S_ERR_UNSUPPORTED (-4)
 
-#define S2S_ABI_VERSION 5 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots; 4: s2s_logmel_parakeet_cached; 5: s2s_tts_set_trailing */
+#define S2S_ABI_VERSION 5 /* 2: continuous-batching entry points, wide (<= 512 slot) frame loops, per-row codec positions; 3: Whisper token-loop slots; 4: s2s_logmel_parakeet_cached; 5: s2s_tts_set_trailing, s2s_logmel_parakeet_cached_rows */
 
 /* element types of device buffers */
 #define S2S_F32 0
@@ -117,6 +117,17 @@ int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float* pcm_dev,
 int32_t s2s_logmel_parakeet_cached(void* frontend, void* stream, const float* pcm_dev, int64_t pcm_stride,
                                    const int32_t* n_samples_dev, const int32_t* first_frame_dev, int32_t B, int32_t t_max,
                                    float* cache_dev, void* out_dev, int32_t out_dtype, int32_t* n_frames_dev);
+
+/* The live partials of one TICK in one call (ABI v5): B growing windows, each with a sample buffer and a log-mel cache of its own.
+ * pcm_rows_dev / cache_rows_dev: device arrays of B device pointers (row b: float32 samples so far; float32 [>= t_max][n_mels] cache).
+ * new_pcm_dev (may be NULL: nothing to append): the new samples of all rows as one flat float32 block, row b's are
+ * new_pcm[new_off[b] .. new_off[b + 1]) (new_off_dev int32[B + 1]) and are appended at sample old_n_dev[b] of its buffer before the
+ * features are computed; n_samples_dev[b] = the row's sample count afterwards; first_frame_dev as above.  out_dev [B][t_max][n_mels]:
+ * row b is bit-identical to s2s_logmel_parakeet_cached (and therefore to s2s_logmel_parakeet) on that window alone. */
+int32_t s2s_logmel_parakeet_cached_rows(void* frontend, void* stream, int32_t B, int32_t t_max, float* const* pcm_rows_dev,
+                                        float* const* cache_rows_dev, const int32_t* n_samples_dev, const int32_t* first_frame_dev,
+                                        const float* new_pcm_dev, const int32_t* new_off_dev, const int32_t* old_n_dev, void* out_dev,
+                                        int32_t out_dtype, int32_t* n_frames_dev);
 
 /* ------------------------------------------------------------------------- *
  * Primitive operators (exported so the parity tests can pin each kernel

@@ -471,12 +471,16 @@ constexpr int T3_M = 256, T3_N = 128, T3_A_BYTES = T3_M * ROWB, T3_W_BYTES = T3_
 // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left unconstrained); gfx9 encoding: vmcnt = {simm16[15:14], simm16[3:0]}
 #define S2S_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
 
-template <typename T, typename CT, bool GEN>
-__global__ __launch_bounds__(512) void gemm_tile3_kernel(
+template <typename T, typename CT, bool GEN, int WM = 4>
+__global__ __launch_bounds__(128 * WM) void gemm_tile3_kernel(
     const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
     const float* residual, CT* C, long ldc, int M, int N, int K, int act, int tiles_m, RowMap rm) {
     constexpr int EPC = MfmaTraits<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);
+    // WM = 4: the 256 x 128 tile of 8 waves, 3-stage ring.  WM = 2 (round 6, mid-sized M: a few hundred .. a few thousand rows, where a launch has
+    // at most one tile per CU and its time is the tile's own latency): 128 x 128, 4 waves, FOUR stages - three slabs in flight.
+    constexpr int TM = 64 * WM, NT = 128 * WM, NWL = 1024 / NT, LPS = 4 + NWL;      // rows, threads, W loads and all loads per thread and slab
+    constexpr int A_BYTES = TM * ROWB, STAGE = A_BYTES + T3_W_BYTES, NST = WM == 4 ? T3_NST : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     {
         const int z1 = blockIdx.y / rm.nz2, z2 = blockIdx.y % rm.nz2;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(wg, tiles_m, (int)gridDim.x / tiles_m, tm, tn);
-    const int m0 = tm * T3_M, n0 = tn * T3_N;
+    const int m0 = tm * TM, n0 = tn * T3_N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -506,12 +510,12 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     // tap boundary per slab; crossing it adds tap_stride - tap_len), still without divisions in the loop.
     const T* zero = reinterpret_cast<const T*>(g_zero_page);
     const T* pa[4];
-    const T* pw[2];
-    int sa[4], sw[2];
-    int ka[GEN ? 4 : 1], kin[GEN ? 4 : 1], kw[GEN ? 2 : 1];
+    const T* pw[NWL];
+    int sa[4], sw[NWL];
+    int ka[GEN ? 4 : 1], kin[GEN ? 4 : 1], kw[GEN ? NWL : 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 512, row = c >> 3, m = m0 + row;
+        const int c = tid + i * NT, row = c >> 3, m = m0 + row;
         const int lch = (c & 7) ^ (row & 7);
         pa[i] = zero;
         sa[i] = 0;
@@ -534,8 +538,8 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + i * 512, row = c >> 3, n = n0 + row;
+    for (int i = 0; i < NWL; ++i) {
+        const int c = tid + i * NT, row = c >> 3, n = n0 + row;
         const int lch = (c & 7) ^ (row & 7);
         pw[i] = zero;
         sw[i] = 0;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     }
     const int wave_base = __builtin_amdgcn_readfirstlane(wave * 1024);
     auto issue = [&](int stage) {
-        unsigned char* base = lds3 + stage * T3_STAGE + wave_base;
+        unsigned char* base = lds3 + stage * STAGE + wave_base;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const T* src = pa[i];
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
                 if (ka[i] >= K) src = zero;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + i * (NT * 16)), 16, 0, 0);
             pa[i] += sa[i];
             if constexpr (GEN) {
                 ka[i] += BK;
@@ -569,14 +573,14 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NWL; ++i) {
             const T* src = pw[i];
             if constexpr (GEN) {
                 if (kw[i] >= K) src = zero;
                 kw[i] += BK;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + T3_A_BYTES + i * 8192), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + i * (NT * 16)), 16, 0, 0);
             pw[i] += sw[i];
         }
     };
@@ -584,14 +588,17 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
     const int nk = (K + BK - 1) / BK;
     issue(0);
     if (nk > 1) issue(1);
+    if (NST == 4 && nk > 2) issue(2);
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) S2S_WAIT_VMCNT(6);   // slab t has landed; the 6 loads of slab t + 1 may still be in flight
+        // slab t has landed; the loads of the NST - 2 younger slabs may still be in flight
+        if (NST == 4 && t + 2 < nk) S2S_WAIT_VMCNT(2 * LPS);
+        else if (t + 1 < nk) S2S_WAIT_VMCNT(LPS);
         else S2S_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading slab t - 1's stage
-        if (t + 2 < nk) issue(stage >= 1 ? stage - 1 : T3_NST - 1);   // (t + 2) % 3 == (t - 1) % 3
-        const unsigned char* sA = lds3 + stage * T3_STAGE;
-        const unsigned char* sW = sA + T3_A_BYTES;
+        if (t + NST - 1 < nk) issue(stage >= 1 ? stage - 1 : NST - 1);   // (t + NST - 1) % NST == (t - 1) % NST
+        const unsigned char* sA = lds3 + stage * STAGE;
+        const unsigned char* sW = sA + A_BYTES;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(512) void gemm_tile3_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fw[j], acc[i][j], 0, 0, 0);
             }
         }
-        stage = stage + 1 == T3_NST ? 0 : stage + 1;
+        stage = stage + 1 == NST ? 0 : stage + 1;
     }
 
     // Epilogue through LDS: the C fragments (column-strided per lane) are staged as a 64 x 64 f32 tile per wave
@@ -1978,6 +1985,15 @@ static bool tile3_disabled() {
     return off;
 }
 
+// S2S_TILE3_MID=0: mid-sized launches on gemm_tile_kernel as in rounds 1 - 5 (A/B switch)
+static bool tile3_mid_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("S2S_TILE3_MID");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
 template <typename T, typename CT>
 static int launch_gemm(hipStream_t st, const GemmArgs& g) {
     RowMap rm;
@@ -2148,6 +2164,29 @@ static int launch_gemm(hipStream_t st, const GemmArgs& g) {
                      (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
         else
             launch_k(gemm_tile3_kernel<T, CT, false>, dim3(tiles_m * tiles_n, nz), dim3(512), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+    } else if (constexpr int BK3 = ROWB / (int)sizeof(T); (g.tap_len == 0 || g.tap_len >= BK3) && K >= 3 * BK3 && tile3_mid_enabled() && !tile3_disabled()) {
+        // mid-sized launches (fewer than 192 tiles of 256 x 128: at most one 128 x 128 tile per CU, the launch takes as long as ONE tile): the
+        // 4-stage 128 x 128 instantiation keeps three K slabs in flight where gemm_tile_kernel drains its only one before every k-step
+        // (FastConformer projections at live-partial batch sizes: 19 -> 9 us at K = 1024, 56 -> 26 us at K = 4096, profiles/r06_bench_mid_gemm.txt)
+        const int tiles_m = cdiv(M, 128), tiles_n = cdiv(N, T3_N);
+        constexpr int lds_bytes = 4 * (128 * ROWB + T3_W_BYTES);
+        const bool gen = g.tap_len > 0 || K % BK3 != 0;
+        static bool attr_mid[64] = {};
+        int dev = 0;
+        S2S_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_mid[dev]) {
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            S2S_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tile3_kernel<T, CT, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            if (dev >= 0 && dev < 64) attr_mid[dev] = true;
+        }
+        ProfScope prof(st, S2S_PROF_GEMM_TILE, 2.0 * M * N * K * nz,
+                       ((double)N * K * sizeof(T) + (double)M * K * sizeof(T) + (double)M * N * sizeof(CT)) * nz);
+        if (gen)
+            launch_k(gemm_tile3_kernel<T, CT, true, 2>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
+                     (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
+        else
+            launch_k(gemm_tile3_kernel<T, CT, false, 2>, dim3(tiles_m * tiles_n, nz), dim3(256), lds_bytes, st,
                      (const T*)g.A, g.lda, (const T*)g.W, g.bias, g.residual, (CT*)g.C, g.ldc, M, N, K, g.act, tiles_m, rm);
     } else {
         const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);

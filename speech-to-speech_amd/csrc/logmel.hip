@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     const float* __restrict__ basis, const float* __restrict__ melw,
     const float* __restrict__ window, int n_bin_tiles, int n_mel_tiles, int mel_ksteps,
     int n_mels, int n_frames, float* __restrict__ out, unsigned int* __restrict__ wmax, int time_major,
-    int window_samples, const float* __restrict__ norm, const int* __restrict__ first_frame = nullptr) {
+    int window_samples, const float* __restrict__ norm, const int* __restrict__ first_frame = nullptr,
+    const float* const* __restrict__ pcm_rows = nullptr, float* const* __restrict__ out_rows = nullptr) {
+    // pcm_rows / out_rows (s2s_logmel_parakeet_cached_rows): item b reads its samples from pcm_rows[b] and writes its frames to out_rows[b]
+    // ([frames][n_mels]) - the rows of a batch live in buffers of their own (one growing window each)
     // first_frame (s2s_logmel_parakeet_cached): frames below first_frame[b] are already in `out` from an earlier, shorter prefix of the same
     // signal - a frame only depends on the 400 samples around it, so a tile that ends below it has nothing to do
     if (first_frame && (int)blockIdx.x * FT + FT <= first_frame[blockIdx.y]) return;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
     const int l15 = lane & 15;
     const int lg = lane >> 4;
 
-    const float* x = pcm + (long)b * pcm_stride;
+    const float* x = pcm_rows ? pcm_rows[b] : pcm + (long)b * pcm_stride;
     int n = n_samples[b];
     if (KIND == S2S_FRONTEND_WHISPER) n = min(n, window_samples);
     // zero-mean / unit-variance waveform normalisation (the Smart-Turn feature path): {mean, 1 / sqrt(var + 1e-7)} per item
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void logmel_tile_kernel(
         }
     } else {
         // out[b][t][mel]: each frame row is n_mels contiguous floats
-        float* ob = out + (long)b * n_frames * n_mels;
+        float* ob = out_rows ? out_rows[b] : out + (long)b * n_frames * n_mels;
         for (int i = tid; i < FT * n_mels; i += 256) {
             const int fr = i / n_mels, mel = i - fr * n_mels;
             if (t0 + fr < n_frames) ob[(long)(t0 + fr) * n_mels + mel] = stage[fr * sstride + mel];
@@ -255,13 +258,13 @@ __global__ void whisper_finalize_tm_kernel(const float* __restrict__ in, OutT* _
 // Parakeet per-feature statistics over the valid frames: two-pass mean / unbiased std.
 // grid = (n_mels/32, B), block = (32, 8)
 __global__ void parakeet_stats_kernel(const float* __restrict__ x, const int* __restrict__ n_samples,
-                                      int t_max, int n_mels, float* __restrict__ stats) {
+                                      int t_max, int n_mels, float* __restrict__ stats, const float* const* __restrict__ x_rows = nullptr) {
     __shared__ float red[8][33];
     const int b = blockIdx.y;
     const int mel = blockIdx.x * 32 + threadIdx.x;
     const int ty = threadIdx.y;
     const int T = min(n_samples[b] / HOP, t_max);
-    const float* xb = x + (long)b * t_max * n_mels;
+    const float* xb = x_rows ? x_rows[b] : x + (long)b * t_max * n_mels;
     float s = 0.f;
     if (mel < n_mels)
         for (int t = ty; t < T; t += 8) s += xb[(long)t * n_mels + mel];
@@ -294,7 +297,7 @@ template <typename OutT>
 __global__ void parakeet_normalize_kernel(const float* __restrict__ x, const int* __restrict__ n_samples,
                                           const float* __restrict__ stats, int t_max, int n_mels,
                                           OutT* __restrict__ out, int* __restrict__ n_frames_out,
-                                          long total) {
+                                          long total, const float* const* __restrict__ x_rows = nullptr) {
     const long per_item = (long)t_max * n_mels;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
@@ -307,7 +310,7 @@ __global__ void parakeet_normalize_kernel(const float* __restrict__ x, const int
         if (t < T) {
             const float mean = stats[((long)b * 2 + 0) * n_mels + mel];
             const float inv = stats[((long)b * 2 + 1) * n_mels + mel];
-            v = (x[i] - mean) * inv;
+            v = ((x_rows ? x_rows[b][r] : x[i]) - mean) * inv;
         }
         Elem<OutT>::st(out + i, v);
         if (r == 0 && n_frames_out) n_frames_out[b] = T;
@@ -568,6 +571,54 @@ extern "C" int32_t s2s_logmel_parakeet(void* frontend, void* stream, const float
     else
         parakeet_normalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(
             f->scratch, n_samples_dev, f->stats, t_max, f->n_mels, (__hip_bfloat16*)out_dev, n_frames_dev, total);
+    S2S_LAUNCH_CHECK();
+    return S2S_OK;
+}
+
+// new samples of a batch of growing windows, uploaded as ONE flat block: row b gets new_pcm[new_off[b] .. new_off[b + 1]) appended at old_n[b]
+__global__ void pcm_append_rows_kernel(float* const* __restrict__ pcm_rows, const float* __restrict__ new_pcm, const int* __restrict__ new_off,
+                                       const int* __restrict__ old_n) {
+    const int b = blockIdx.y;
+    const int o0 = new_off[b], cnt = new_off[b + 1] - o0;
+    float* dst = pcm_rows[b] + old_n[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) dst[i] = new_pcm[o0 + i];
+}
+
+/* The live partials of a TICK in one call (round 6): B growing windows, each with a pcm row and a log-mel cache of its own (device pointer
+ * tables), their new samples in one flat block.  Same kernels and per-window results as B calls of s2s_logmel_parakeet_cached - the per-window
+ * driver work (three launches, three small uploads) was 0.24 ms x the batch, 43 % of a 48-window pass (profiles/r06_bench_partial_pass.txt). */
+extern "C" int32_t s2s_logmel_parakeet_cached_rows(void* frontend, void* stream, int32_t B, int32_t t_max, float* const* pcm_rows_dev,
+                                                   float* const* cache_rows_dev, const int32_t* n_samples_dev, const int32_t* first_frame_dev,
+                                                   const float* new_pcm_dev, const int32_t* new_off_dev, const int32_t* old_n_dev, void* out_dev,
+                                                   int32_t out_dtype, int32_t* n_frames_dev) {
+    Frontend* f = (Frontend*)frontend;
+    S2S_REQUIRE(f && f->kind == S2S_FRONTEND_PARAKEET, "not a Parakeet front-end");
+    S2S_REQUIRE(B >= 0 && B <= f->max_batch, "batch %d exceeds max_batch %d", B, f->max_batch);
+    S2S_REQUIRE(t_max > 0 && t_max <= f->max_frames, "t_max %d out of range (1..%d)", t_max, f->max_frames);
+    S2S_REQUIRE(out_dtype == S2S_F32 || out_dtype == S2S_BF16, "bad out_dtype %d", out_dtype);
+    if (B == 0) return S2S_OK;
+    S2S_REQUIRE(pcm_rows_dev && cache_rows_dev && n_samples_dev && first_frame_dev && out_dev, "null device pointer");
+    S2S_REQUIRE(!new_pcm_dev || (new_off_dev && old_n_dev), "new samples without their offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (new_pcm_dev) {
+        pcm_append_rows_kernel<<<dim3(8, B), 256, 0, st>>>(pcm_rows_dev, new_pcm_dev, new_off_dev, old_n_dev);
+        S2S_LAUNCH_CHECK();
+    }
+    dim3 grid(cdiv(t_max, FT), B);
+    logmel_tile_kernel<S2S_FRONTEND_PARAKEET><<<grid, 256, tile_lds_bytes(f), st>>>(
+        nullptr, 0, n_samples_dev, f->basis, f->melw, f->window, f->n_bin_tiles, f->n_mel_tiles, f->mel_ksteps, f->n_mels, t_max, nullptr, nullptr, 1, 0,
+        nullptr, first_frame_dev, (const float* const*)pcm_rows_dev, cache_rows_dev);
+    S2S_LAUNCH_CHECK();
+    parakeet_stats_kernel<<<dim3(cdiv(f->n_mels, 32), B), dim3(32, 8), 0, st>>>(nullptr, n_samples_dev, t_max, f->n_mels, f->stats, (const float* const*)cache_rows_dev);
+    S2S_LAUNCH_CHECK();
+    const long total = (long)B * t_max * f->n_mels;
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+    if (out_dtype == S2S_F32)
+        parakeet_normalize_kernel<float><<<blocks, 256, 0, st>>>(nullptr, n_samples_dev, f->stats, t_max, f->n_mels, (float*)out_dev, n_frames_dev, total,
+                                                                 (const float* const*)cache_rows_dev);
+    else
+        parakeet_normalize_kernel<__hip_bfloat16><<<blocks, 256, 0, st>>>(nullptr, n_samples_dev, f->stats, t_max, f->n_mels, (__hip_bfloat16*)out_dev,
+                                                                        n_frames_dev, total, (const float* const*)cache_rows_dev);
     S2S_LAUNCH_CHECK();
     return S2S_OK;
 }

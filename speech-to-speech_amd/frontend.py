@@ -146,6 +146,22 @@ class LogMelFrontend:
             )
         return out, n_frames
 
+    def parakeet_cached_rows(self, pcm_rows: torch.Tensor, cache_rows: torch.Tensor, n_samples: torch.Tensor, first_frame: torch.Tensor,
+                             new_pcm: torch.Tensor | None, new_off: torch.Tensor | None, old_n: torch.Tensor | None, t_max: int, out: torch.Tensor,
+                             n_frames: torch.Tensor) -> None:
+        """The growing windows of a whole tick (s2s_logmel_parakeet_cached_rows): pcm_rows / cache_rows are int64 device tensors of B device
+        pointers, new_pcm the flat block of all rows' new samples (row b: new_off[b] .. new_off[b + 1], appended at old_n[b])."""
+        assert self.kind == "parakeet" and out.is_contiguous() and pcm_rows.dtype == torch.int64 and cache_rows.dtype == torch.int64
+        B = int(pcm_rows.numel())
+        with torch.cuda.device(self.device):
+            native.check(
+                self._lib.s2s_logmel_parakeet_cached_rows(self._handle, native.stream_handle(), B, int(t_max), native.ptr(pcm_rows), native.ptr(cache_rows),
+                                                          native.ptr(n_samples), native.ptr(first_frame), native.ptr(new_pcm) if new_pcm is not None else None,
+                                                          native.ptr(new_off) if new_off is not None else None, native.ptr(old_n) if old_n is not None else None,
+                                                          native.ptr(out), native.dtype_code(out.dtype), native.ptr(n_frames)),
+                "s2s_logmel_parakeet_cached_rows",
+            )
+
     def parakeet_cached(self, pcm_row: torch.Tensor, n_samples: torch.Tensor, first_frame: torch.Tensor, t_max: int, cache: torch.Tensor,
                         out_row: torch.Tensor, n_frames_row: torch.Tensor) -> None:
         """One growing window (s2s_logmel_parakeet_cached, B = 1): pcm_row [1][cap] holds the window's samples so far, cache [cap_frames][n_mels]

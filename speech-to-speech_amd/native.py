@@ -68,6 +68,7 @@ _SIGNATURES = {
     "s2s_logmel_whisper": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32],
     "s2s_logmel_parakeet": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp],
     "s2s_logmel_parakeet_cached": [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp],
+    "s2s_logmel_parakeet_cached_rows": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "s2s_op_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32],
     "s2s_op_gemm_ex": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32],
     "s2s_op_gemm_dec": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _i64, _i32, _vp, _i64,

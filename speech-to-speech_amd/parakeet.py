@@ -192,10 +192,9 @@ class ParakeetEngine:
         feats, nf = self.frontend.parakeet(pcm, ns, T, out_dtype=self.dtype)
         return feats, nf, T
 
-    def stream_features(self, st: ProgressiveStream, audio: np.ndarray, key: Any, t_max: int, out_row: torch.Tensor, nf_row: torch.Tensor) -> None:
-        """Features of a growing window into row `out_row` [1][t_max][n_mels] of a batch: uploads the samples that are new since the stream's last
-        partial and computes the log-mel frames they can change (frame t depends on samples t * 160 - 200 .. t * 160 + 199 and, through the
-        pre-emphasis, one more to the left), the rest comes from the stream's cache."""
+    def _stream_advance(self, st: ProgressiveStream, audio: np.ndarray, key: Any) -> tuple[int, int, np.ndarray, int]:
+        """Host part of a partial: is `audio` an extension of what the stream has on the device?  -> (old_n, first_frame, new samples, checksum
+        of the whole window); the stream's device buffers exist afterwards (a restarted stream counts from 0)."""
         n = len(audio)
         cap = (self.max_feat_frames - 1) * 160
         assert 0 < n <= cap
@@ -214,20 +213,73 @@ class ParakeetEngine:
             st.n, st.key = 0, key
             dg = _PrefixDigest()
             st.stats["restarts"] += 1
-        new = np.ascontiguousarray(audio[st.n:n], dtype=np.float32)
+        old_n = st.n
+        new = np.ascontiguousarray(audio[old_n:n], dtype=np.float32)
         if len(new):
-            st.pcm[0, st.n:n].copy_(torch.from_numpy(new))
             dg.update(new)
-        first = max(0, (st.n - 200) // 160) if st.n > 0 else 0
-        ns = torch.tensor([n], dtype=torch.int32, device=self.device)
-        ff = torch.tensor([first], dtype=torch.int32, device=self.device)
-        self.frontend.parakeet_cached(st.pcm, ns, ff, t_max, st.cache, out_row, nf_row)
+        first = max(0, (old_n - 200) // 160) if old_n > 0 else 0
+        return old_n, first, new, dg.value()
+
+    def _stream_account(self, st: ProgressiveStream, n: int, n_new: int, first: int, t_max: int, digest: int) -> None:
         st.stats["partials"] += 1
-        st.stats["samples_uploaded"] += len(new)
+        st.stats["samples_uploaded"] += n_new
         st.stats["samples_total"] += n
         st.stats["frames_computed"] += (min(t_max, n // 160 + 1) - first // 64 * 64)       # (whole 64-frame tiles from the one that holds `first`)
         st.stats["frames_total"] += n // 160 + 1
-        st.n, st.digest = n, dg.value()
+        st.n, st.digest = n, digest
+
+    def stream_features(self, st: ProgressiveStream, audio: np.ndarray, key: Any, t_max: int, out_row: torch.Tensor, nf_row: torch.Tensor) -> None:
+        """Features of a growing window into row `out_row` [1][t_max][n_mels] of a batch: uploads the samples that are new since the stream's last
+        partial and computes the log-mel frames they can change (frame t depends on samples t * 160 - 200 .. t * 160 + 199 and, through the
+        pre-emphasis, one more to the left), the rest comes from the stream's cache."""
+        n = len(audio)
+        old_n, first, new, digest = self._stream_advance(st, audio, key)
+        if len(new):
+            st.pcm[0, old_n:n].copy_(torch.from_numpy(new))
+        ns = torch.tensor([n], dtype=torch.int32, device=self.device)
+        ff = torch.tensor([first], dtype=torch.int32, device=self.device)
+        self.frontend.parakeet_cached(st.pcm, ns, ff, t_max, st.cache, out_row, nf_row)
+        self._stream_account(st, n, len(new), first, t_max, digest)
+
+    def stream_features_rows(self, streams: Sequence[ProgressiveStream], audios: Sequence[np.ndarray], keys: Sequence[Any], t_max: int, out: torch.Tensor,
+                             nf: torch.Tensor) -> None:
+        """The growing windows of a whole tick into out [B][t_max][n_mels]: per window only host work (checksum, copy of its new samples into a
+        pinned block, a row of the tables); ONE upload of the new samples, one of the tables and one s2s_logmel_parakeet_cached_rows call for all
+        of them - per-window uploads and launches were 43 % of a 48-window partial pass.  Row b is bit-identical to `stream_features` on it."""
+        B = len(streams)
+        assert B == out.shape[0] and out.is_contiguous()
+        if getattr(self, "_rows_event", None) is not None:
+            self._rows_event.synchronize()             # the previous call's uploads have left the pinned blocks
+        meta = [self._stream_advance(st, a, k) for st, a, k in zip(streams, audios, keys)]
+        total = sum(len(m[2]) for m in meta)
+        if getattr(self, "_rows_host", None) is None or self._rows_host[0].numel() < max(total, 1) or self._rows_host[1].shape[1] < B + 1:
+            self._rows_host = (torch.empty((max(total, self.max_batch * 16000),), dtype=torch.float32, pin_memory=True),
+                               torch.empty((4, max(B, self.max_batch) + 1), dtype=torch.int32, pin_memory=True),
+                               torch.empty((2, max(B, self.max_batch)), dtype=torch.int64, pin_memory=True))
+        stage, ints, ptrs = self._rows_host
+        stage_np, ints_np, ptrs_np = stage.numpy(), ints.numpy(), ptrs.numpy()
+        off = 0
+        for b, (st, a, (old_n, first, new, _)) in enumerate(zip(streams, audios, meta)):
+            stage_np[off : off + len(new)] = new
+            ints_np[0, b], ints_np[1, b], ints_np[2, b], ints_np[3, b] = len(a), first, old_n, off
+            ptrs_np[0, b], ptrs_np[1, b] = st.pcm.data_ptr(), st.cache.data_ptr()
+            off += len(new)
+        ints_np[3, B] = off
+        W = ints.shape[1]
+        d_ints = torch.empty((4, W), dtype=torch.int32, device=self.device)
+        d_ptrs = torch.empty((2, ptrs.shape[1]), dtype=torch.int64, device=self.device)
+        d_ints.copy_(ints, non_blocking=True)
+        d_ptrs.copy_(ptrs, non_blocking=True)
+        d_new = None
+        if total:
+            d_new = torch.empty((total,), dtype=torch.float32, device=self.device)
+            d_new.copy_(stage[:total], non_blocking=True)
+        self._rows_event = torch.cuda.Event()
+        self._rows_event.record()
+        self.frontend.parakeet_cached_rows(d_ptrs[0, :B], d_ptrs[1, :B], d_ints[0], d_ints[1], d_new, d_ints[3] if total else None, d_ints[2] if total else None,
+                                           t_max, out, nf)
+        for st, a, (old_n, first, new, digest) in zip(streams, audios, meta):
+            self._stream_account(st, len(a), len(new), first, t_max, digest)
 
     def encode(self, feats: torch.Tensor, n_frames: torch.Tensor) -> None:
         B, T, _ = feats.shape
@@ -291,9 +343,9 @@ class ParakeetEngine:
                 if plain:
                     pcm, ns = pack_pcm([chunk[j] for j in plain], self.device)
                     self.frontend.parakeet(pcm, ns, T, out_dtype=self.dtype, out=feats[: len(plain)], n_frames=nf[: len(plain)])
-                for r in range(len(plain), len(order)):
-                    j = order[r]
-                    self.stream_features(streams[j], chunk[j], (options[owner[b0 + j]] or {}).get("stream_key"), T, feats[r : r + 1], nf[r : r + 1])
+                live = order[len(plain):]
+                self.stream_features_rows([streams[j] for j in live], [chunk[j] for j in live], [(options[owner[b0 + j]] or {}).get("stream_key") for j in live],
+                                          T, feats[len(plain):], nf[len(plain):])
                 own_c, off_c = [owner[b0 + j] for j in order], [offset[b0 + j] for j in order]
                 owner[b0 : b0 + len(chunk)], offset[b0 : b0 + len(chunk)] = own_c, off_c
             else:

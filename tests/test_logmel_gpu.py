@@ -143,7 +143,7 @@ def test_smart_turn_tick_batcher_one_launch_same_features():
         seen.append(np.array(f))
         return f.reshape(f.shape[0], -1).mean(1)
 
-    an = MI355XSmartTurnAnalyzer(classifier, threshold=0.5, max_batch=8, warmup=False, tick_ms=80.0, features=st)
+    an = MI355XSmartTurnAnalyzer(classifier, threshold=0.5, max_batch=8, warmup=False, tick_ms=500.0, features=st)      # (a long tick: five thread starts fit into it on a busy box too)
     res = {}
     ths = [threading.Thread(target=lambda i=i: res.__setitem__(i, an.predict(audios[i]))) for i in range(5)]
     [t.start() for t in ths]

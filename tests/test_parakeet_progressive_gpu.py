@@ -145,6 +145,45 @@ def test_cached_features_are_bit_identical_to_the_whole_window(rig):
         assert st2.stats["restarts"] == 2 and torch.equal(row, eng.frontend.parakeet(pcm, ns, 351, out_dtype=dtype)[0])
 
 
+def test_a_tick_of_growing_windows_in_one_call_is_bit_identical_per_window(rig):
+    """s2s_logmel_parakeet_cached_rows (ABI v5): the partial windows of a tick - different lengths, different growth, one of them restarted with
+    another signal, one without new samples - in ONE call with ONE upload of the new samples: every row equals s2s_logmel_parakeet on that window
+    alone bit for bit (float32 and bf16), and the streams' counters say that only the new samples crossed PCIe."""
+    from speech_to_speech_amd.parakeet import ProgressiveStream
+
+    dims, sd, pool, tok = rig
+    eng = pool._engines["parakeet"]
+    B = 4
+    turns = [synth_audio(10 * 16000, 700 + i) for i in range(B)]
+    for dtype in (torch.float32, torch.bfloat16):
+        streams = [ProgressiveStream() for _ in range(B)]
+        lens = [4000, 12000, 30000, 8000]
+        for tick in range(7):
+            grow = [8000, 8000 + 777 * (tick % 2), 8000, 0 if tick == 3 else 8000]
+            lens = [min(len(t), n + g) for t, n, g in zip(turns, lens, grow)] if tick else lens
+            wins = [t[:n] for t, n in zip(turns, lens)]
+            keys = [0] * B
+            if tick == 4:                                  # row 2: the window moved (sentences were fixed) - another start, other samples
+                turns[2] = synth_audio(10 * 16000, 790)
+                lens[2] = 20000
+                wins[2], keys[2] = turns[2][:20000], 5
+            elif tick > 4:
+                keys[2] = 5
+            T = max(8, max(lens) // 160 + 1)
+            out = torch.empty((B, T, dims.n_mels), dtype=dtype, device="cuda:0")
+            nf = torch.empty((B,), dtype=torch.int32, device="cuda:0")
+            eng.stream_features_rows(streams, wins, keys, T, out, nf)
+            pcm, ns = pack_pcm(wins, eng.device)
+            want, wnf = eng.frontend.parakeet(pcm, ns, T, out_dtype=dtype)
+            assert torch.equal(nf, wnf)
+            for b in range(B):
+                assert torch.equal(out[b], want[b]), f"{dtype} tick {tick} row {b}: batched cached features differ from the whole-window features"
+        st = [s.stats for s in streams]
+        print(f"{dtype}: uploaded {[round(s_['samples_uploaded'] / s_['samples_total'], 3) for s_ in st]} of the samples, restarts {[s_['restarts'] for s_ in st]}")
+        assert [s_["restarts"] for s_ in st] == [1, 1, 2, 1] and all(s_["samples_uploaded"] < 0.5 * s_["samples_total"] for s_ in st)
+        assert st[0]["samples_uploaded"] == lens[0]
+
+
 @pytest.mark.parametrize("incremental", [False, True])
 def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig, incremental):
     """(incremental = True: every window is a ProgressiveStream - only new samples uploaded, only new log-mel tiles computed, same results.)

@@ -40,3 +40,7 @@ if __name__ == "__main__":
         for (M, N, K) in [(96000, 3840, 1280), (96000, 1280, 1280), (96000, 5120, 1280), (96000, 1280, 5120), (8192, 8192, 8192), (4096, 4096, 4096),
                           (983040, 96, 672), (327680, 192, 1344), (81920, 384, 2688), (16384, 768, 5376), (983040, 96, 96)]:
             time_gemm(M, N, K, cdt=torch.bfloat16, iters=10)
+    if which in ("mid",):      # FastConformer encoder projections at live-partial batch sizes (C5: a few hundred .. a few thousand rows)
+        for M in (256, 512, 1024, 2048, 3072, 4096):
+            for (N, K) in [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (2048, 1024)]:
+                time_gemm(M, N, K, cdt=torch.bfloat16, iters=100)
