@@ -33,6 +33,8 @@ class MI355XParakeetSTTHandlerArguments:
     parakeet_tdt_max_batch: int = field(default=128)
     parakeet_tdt_batch_window_ms: float = field(default=4.0)
     parakeet_tdt_batch_cap: int = field(default=0, metadata={"help": "Largest final-STT batch the pool forms (0 = the engine's max_batch)."})
+    parakeet_tdt_stt_workers: int = field(default=0, metadata={"help": "STT workers of the device's session pool (thread + HIP stream + engine replica each; 0 = leave the pool as "
+                                                                       "it is).  With live transcription a pass is a chain of short launches: 3 workers overlap them (measured best)."})
     parakeet_tdt_max_seconds: float = field(default=30.0)
     language: Optional[str] = field(default="en")
 
