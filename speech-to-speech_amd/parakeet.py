@@ -168,6 +168,21 @@ class ParakeetEngine:
             native.check(self._lib.s2s_parakeet_finalize(h), "s2s_parakeet_finalize")
         self.frontend = LogMelFrontend("parakeet", dims.n_mels, max_batch=self.max_batch, device=self.device)
         self._B = 0
+        self._rows_host = self._rows_dev = self._rows_event = None
+        if self.device.type == "cuda":
+            self._rows_alloc(self.max_batch * 32000, self.max_batch)       # (pinned allocations synchronise the device: not in serving time)
+
+    def _rows_alloc(self, total: int, B: int) -> None:
+        """Staging of `stream_features_rows`: a pinned block + its device twin for the new samples of a tick, the int32 / pointer tables."""
+        have = self._rows_host
+        if have is not None and have[0].numel() >= total and have[1].shape[1] >= B + 1:
+            return
+        total = max(total, have[0].numel() if have else 0)
+        W = max(B, self.max_batch, (have[1].shape[1] - 1) if have else 0) + 1
+        self._rows_host = (torch.empty((total,), dtype=torch.float32, pin_memory=True), torch.empty((4, W), dtype=torch.int32, pin_memory=True),
+                           torch.empty((2, W), dtype=torch.int64, pin_memory=True))
+        self._rows_dev = (torch.empty((total,), dtype=torch.float32, device=self.device), torch.empty((4, W), dtype=torch.int32, device=self.device),
+                          torch.empty((2, W), dtype=torch.int64, device=self.device))
 
     def replica(self, max_batch: int | None = None) -> "ParakeetEngine":
         """A second engine instance on the same GPU sharing this one's weight tensors (no copy of what was uploaded); it owns its workspace
@@ -248,14 +263,11 @@ class ParakeetEngine:
         of them - per-window uploads and launches were 43 % of a 48-window partial pass.  Row b is bit-identical to `stream_features` on it."""
         B = len(streams)
         assert B == out.shape[0] and out.is_contiguous()
-        if getattr(self, "_rows_event", None) is not None:
-            self._rows_event.synchronize()             # the previous call's uploads have left the pinned blocks
+        if self._rows_event is not None:
+            self._rows_event.synchronize()             # the previous call's uploads and kernels are done with the staging blocks
         meta = [self._stream_advance(st, a, k) for st, a, k in zip(streams, audios, keys)]
         total = sum(len(m[2]) for m in meta)
-        if getattr(self, "_rows_host", None) is None or self._rows_host[0].numel() < max(total, 1) or self._rows_host[1].shape[1] < B + 1:
-            self._rows_host = (torch.empty((max(total, self.max_batch * 16000),), dtype=torch.float32, pin_memory=True),
-                               torch.empty((4, max(B, self.max_batch) + 1), dtype=torch.int32, pin_memory=True),
-                               torch.empty((2, max(B, self.max_batch)), dtype=torch.int64, pin_memory=True))
+        self._rows_alloc(max(total, 1), B)
         stage, ints, ptrs = self._rows_host
         stage_np, ints_np, ptrs_np = stage.numpy(), ints.numpy(), ptrs.numpy()
         off = 0
@@ -265,19 +277,17 @@ class ParakeetEngine:
             ptrs_np[0, b], ptrs_np[1, b] = st.pcm.data_ptr(), st.cache.data_ptr()
             off += len(new)
         ints_np[3, B] = off
-        W = ints.shape[1]
-        d_ints = torch.empty((4, W), dtype=torch.int32, device=self.device)
-        d_ptrs = torch.empty((2, ptrs.shape[1]), dtype=torch.int64, device=self.device)
+        d_stage, d_ints, d_ptrs = self._rows_dev      # (engine-owned: the previous tick's kernels are done - the event above / the pass's read-back)
         d_ints.copy_(ints, non_blocking=True)
         d_ptrs.copy_(ptrs, non_blocking=True)
         d_new = None
         if total:
-            d_new = torch.empty((total,), dtype=torch.float32, device=self.device)
+            d_new = d_stage[:total]
             d_new.copy_(stage[:total], non_blocking=True)
-        self._rows_event = torch.cuda.Event()
-        self._rows_event.record()
         self.frontend.parakeet_cached_rows(d_ptrs[0, :B], d_ptrs[1, :B], d_ints[0], d_ints[1], d_new, d_ints[3] if total else None, d_ints[2] if total else None,
                                            t_max, out, nf)
+        self._rows_event = torch.cuda.Event()          # behind the kernels that read the staging blocks
+        self._rows_event.record()
         for st, a, (old_n, first, new, digest) in zip(streams, audios, meta):
             self._stream_account(st, len(a), len(new), first, t_max, digest)
 

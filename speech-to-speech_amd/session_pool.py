@@ -313,7 +313,9 @@ class SessionPool:
             ev.wait(timeout)
 
     def warm_stt(self, model: str, timeout: float = 300.0) -> None:
-        """Build the replicas of the two-stage STT pipeline now (on the worker thread), not on the first request."""
+        """Build the replicas of the extra STT workers and of the two-stage STT pipeline now, not on the first request (an engine build allocates,
+        pins host memory and synchronises the device: inside serving time that is a late audio block for somebody)."""
+        self._stt_extra_build(model)
         if self.stt_stages <= 1:
             return
         fut: Future = Future()
