@@ -662,15 +662,15 @@ def probe_sustained(r, bound_ms):
 
 def sustained_search(probe, n_hint, bound_ms, max_probes=6, start=0.7, extra_probes=3):
     """Largest N (bisected to about +-5 %) whose probe meets `probe_sustained`.  Starts at `start` x the closed-loop throughput of the timed region
-    and moves by +-25 % / bisection; while no probe has FAILED yet the search keeps stepping up (up to `extra_probes` more) so that the figure is a
-    knee, not just the largest load tried."""
+    and moves by +-25 % / bisection; while no probe has FAILED yet, or the bracket is still wider than 10 %, the search goes on (up to `extra_probes`
+    more) so that the figure is a knee, not just the largest load tried."""
     tried = []
     lo, hi = 0, None
     n = max(1, int(n_hint * start))
     best = None
     k = 0
     retried = False
-    while k < max_probes or (hi is None and k < max_probes + extra_probes):
+    while k < max_probes or (k < max_probes + extra_probes and (hi is None or hi - lo > max(8, lo // 10))):      # (extra probes: no knee yet, or a bracket wider than 10 %)
         k += 1
         r = probe(n)
         r["sustained"] = probe_sustained(r, bound_ms)
@@ -1082,7 +1082,7 @@ def main():
             elif B > 1:
                 # (start 0.6 x the closed-loop rate, <= 6 probes: lands within 3 % of the knee for closed-loop rates of 1.3 .. 2.2 x the knee -
                 # the driver's 20-step timed region amortises the pipeline tail and reports a higher closed-loop rate than an 8-step run)
-                best, tried = sustained_search(probe, xrt / world, args.ttfa_bound_ms, max_probes=args.max_probes, start=0.6)
+                best, tried = sustained_search(probe, xrt / world, args.ttfa_bound_ms, max_probes=args.max_probes, start=1.0 if wl == "c5" else 0.6)      # (c5: the 32-session closed loop underestimates the pool)
             # confirmation: the sustained figure must hold for OTHER arrival phases too (round 3's figure moved by +-27 % between runs: a
             # single 20 s probe at a bistable knee is a draw); a failed repeat steps the figure down to the largest smaller probe that held
             repeats = []
