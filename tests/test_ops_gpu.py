@@ -37,6 +37,9 @@ def _ref(A, W, bias, resid, act):
 
 SHAPES = [(128, 128, 64), (300, 200, 136), (1500, 384, 384), (64, 1280, 1280), (1, 51864, 384), (17, 100, 72),
           (65, 130, 264),
+          # mid-sized launches (fewer than 192 big tiles): the 128 x 128 tile with the FOUR-stage ring (round 6) - 3, 4 and 5 K-slabs (ring
+          # start-up and tail), K not a multiple of the slab (zero-page path), ragged M / N edges
+          (1109, 1024, 192), (700, 1000, 200), (333, 257, 320),
           # large-M shapes that take the 256x128 / 3-stage ring kernel (ragged M and N edges; 3, 5 and 6 K-slabs)
           (9000, 650, 192), (8192, 1024, 320),
           # encoder-sized bf16 projections: the 256x256 tile kernel (8 waves of 128x64, 4-stage ring of 32-wide K slabs) - ragged M / N

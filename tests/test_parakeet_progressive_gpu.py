@@ -226,3 +226,44 @@ def test_growing_turns_fix_sentences_like_the_oracle_driven_streamer(rig, increm
             print(f"stream: {s_['partials']} partials in {s_['restarts']} windows, uploaded {s_['samples_uploaded'] / s_['samples_total']:.1%} of the samples, "
                   f"computed {s_['frames_computed'] / s_['frames_total']:.1%} of the log-mel frames a whole-window recompute handles")
             assert s_["partials"] >= total // step and s_["restarts"] >= 2 and s_["samples_uploaded"] < 0.6 * s_["samples_total"]
+
+
+def test_three_stt_workers_on_replicas_answer_like_the_single_engine(rig):
+    """SessionPool(stt_workers = 3) / ensure_stt_workers: finals and live partials of many sessions spread over three workers - each a thread, a HIP
+    stream and a ParakeetEngine.replica() that shares the first engine's weights - give exactly the transcripts the single float32 engine gives
+    (which is step-exact against the oracle, above); every worker served something; the replicas own no second copy of the uploaded weights."""
+    dims, sd, pool0, tok = rig
+    eng0 = pool0._engines["parakeet"]
+    audios = [synth_audio(16000 + 4000 * (i % 7), 300 + i) for i in range(18)]
+    want = [eng0.transcribe_batch([a], [None])[0]["ids"] for a in audios]
+    pool = SessionPool("cuda:0", max_batch=4, batch_window_ms=2.0)
+    try:
+        pool.ensure_engine("parakeet", lambda: ParakeetEngine(dims, sd, dtype=torch.float32, max_batch=4, max_seconds=12.0))
+        pool.ensure_stt_workers(3)
+        reps = list(pool._stt_extra_reps["parakeet"].values())
+        assert len(reps) == 2 and all(r is not pool._engines["parakeet"] for r in reps)
+        base = pool._engines["parakeet"]
+        assert all(r._weights[k].data_ptr() == base._weights[k].data_ptr() for r in reps for k in base._weights)        # shared, not copied
+        served = {}
+        for k, r in enumerate([base] + reps):
+            orig = r.transcribe_batch
+
+            def counted(a, o, orig=orig, k=k):
+                served[k] = served.get(k, 0) + len(a)
+                return orig(a, o)
+
+            r.transcribe_batch = counted
+        got = [None] * len(audios)
+
+        def one(i):
+            got[i] = pool.transcribe("parakeet", audios[i], live=bool(i % 2))["ids"]
+
+        for rnd in range(3):                             # three bursts, so that every worker gets its share
+            ts = [threading.Thread(target=one, args=(i,)) for i in range(len(audios))]
+            [t.start() for t in ts]
+            [t.join(timeout=120) for t in ts]
+            assert got == want, f"burst {rnd}: a worker's transcript differs from the single engine's"
+        print(f"requests served per worker: {served}")
+        assert len(served) == 3 and sum(served.values()) == 3 * len(audios)
+    finally:
+        pool.shutdown()
