@@ -171,6 +171,9 @@ class ParakeetEngine:
         self._rows_host = self._rows_dev = self._rows_event = None
         if self.device.type == "cuda":
             self._rows_alloc(self.max_batch * 32000, self.max_batch)       # (pinned allocations synchronise the device: not in serving time)
+            size = 3 * self.max_batch * 10 * max(self.tm_enc, 8) + self.max_batch      # TDT results of the longest pass (tdt_greedy)
+            self._tdt_dev = torch.empty((size,), dtype=torch.int32, device=self.device)
+            self._tdt_host = torch.empty((size,), dtype=torch.int32, pin_memory=True)
 
     def _rows_alloc(self, total: int, B: int) -> None:
         """Staging of `stream_features_rows`: a pinned block + its device twin for the new samples of a tick, the int32 / pointer tables."""
@@ -309,16 +312,26 @@ class ParakeetEngine:
     def tdt_greedy(self, max_steps: int = 0):
         """-> per session (tokens incl. blanks, durations, frame index of each step)."""
         ms = max_steps if max_steps > 0 else 10 * self._T - 1
-        toks = torch.zeros((self._B, ms), dtype=torch.int32, device=self.device)
-        durs = torch.zeros_like(toks)
-        frames = torch.zeros_like(toks)
-        n = torch.zeros((self._B,), dtype=torch.int32, device=self.device)
+        B = self._B
+        # engine-owned result blocks (device + pinned twin), grown on demand: no fill kernels, no allocation and ONE synchronisation per pass
+        # (entries past a session's step count are never read)
+        need = 3 * B * ms + B
+        if getattr(self, "_tdt_dev", None) is None or self._tdt_dev.numel() < need:
+            size = max(need, 3 * self.max_batch * 10 * 64 + self.max_batch)
+            self._tdt_dev = torch.empty((size,), dtype=torch.int32, device=self.device)
+            self._tdt_host = torch.empty((size,), dtype=torch.int32, pin_memory=True)
+        dev = self._tdt_dev[:need]
+        toks, durs, frames, n = dev[: B * ms].view(B, ms), dev[B * ms : 2 * B * ms].view(B, ms), dev[2 * B * ms : 3 * B * ms].view(B, ms), dev[3 * B * ms :]
         with torch.cuda.device(self.device):
             native.check(self._lib.s2s_parakeet_tdt_greedy(self._h, native.stream_handle(), ms, native.ptr(toks), native.ptr(durs),
                                                            native.ptr(frames), native.ptr(n)), "s2s_parakeet_tdt_greedy")
-        n_h, t_h, d_h, f_h = n.cpu().numpy(), toks.cpu().numpy(), durs.cpu().numpy(), frames.cpu().numpy()
-        return ([t_h[b, : n_h[b]].tolist() for b in range(self._B)], [d_h[b, : n_h[b]].tolist() for b in range(self._B)],
-                [f_h[b, : n_h[b]].tolist() for b in range(self._B)])
+            host = self._tdt_host[:need]
+            host.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        h = host.numpy()
+        t_h, d_h, f_h, n_h = h[: B * ms].reshape(B, ms), h[B * ms : 2 * B * ms].reshape(B, ms), h[2 * B * ms : 3 * B * ms].reshape(B, ms), h[3 * B * ms :]
+        return ([t_h[b, : n_h[b]].tolist() for b in range(B)], [d_h[b, : n_h[b]].tolist() for b in range(B)],
+                [f_h[b, : n_h[b]].tolist() for b in range(B)])
 
     def transcribe_batch(self, audios: Sequence[np.ndarray], options: Sequence[dict]) -> list[dict]:
         """SessionPool entry point: {"ids": non-blank token ids, "starts_s" / "ends_s": start / end time of each token in
